@@ -1,0 +1,39 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def golden_csr(g, prefix=""):
+    import scipy.sparse as sp
+    shape = tuple(int(v) for v in g[prefix + "shape"])
+    return sp.csr_matrix((g[prefix + "data"], g[prefix + "indices"], g[prefix + "indptr"]), shape=shape)
+
+
+def coo_arrays(X):
+    A = X.tocoo()
+    return (np.ascontiguousarray(A.row, np.int32), np.ascontiguousarray(A.col, np.int32),
+            np.ascontiguousarray(A.data, np.float32))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.plsa_oracle import Oracle
+    o = Oracle(fast=False)
+    o.set_threads(1)          # sequential == the order the goldens were produced in
+    return o

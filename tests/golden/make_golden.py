@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference); the produced
+``tests/golden/*.npz`` files are committed and are the only thing that travels.
+Nothing from the reference's source text is stored -- the fixtures hold inputs
+and the outputs the reference computed for them.
+
+How the reference is executed: numba is not importable in
+this image, so ``numba`` is replaced by a no-op shim (``njit`` returns the
+function unchanged, ``prange = range``) and the reference's own statements run
+as plain Python/NumPy.  Under NumPy 2 (NEP 50) ``0.0 + np.float32`` stays
+float32, so the accumulators are fp32 exactly like numba's typed locals and the
+execution order is strictly sequential.  ``enstop/__init__.py`` is bypassed with
+a synthetic package object because it imports dask/hdbscan/umap; for
+``enstop_.py`` (bootstrap member + ensemble stack only) those three imports are
+satisfied with empty placeholder modules -- no function of theirs is ever
+called by the goldens generated here (topic clustering stays unpinned).
+
+Usage:  python tests/golden/make_golden.py        (writes next to this file)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.sparse as sp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+# --------------------------------------------------------------------------- shim
+def install_shims():
+    nb = types.ModuleType("numba")
+
+    def _jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+
+    class _Sink:
+        def __getattr__(self, n):
+            return self
+
+        def __call__(self, *a, **k):
+            return self
+
+        def __getitem__(self, i):
+            return self
+
+    nb.njit = _jit
+    nb.jit = _jit
+    nb.prange = range
+    nb.types = _Sink()
+    nb.float32 = _Sink()
+    cuda = types.ModuleType("numba.cuda")
+    cuda.is_available = lambda: False
+    nb.cuda = cuda
+    sys.modules["numba"] = nb
+    sys.modules["numba.cuda"] = cuda
+
+    pkg = types.ModuleType("enstop")
+    pkg.__path__ = [os.path.join(REF, "enstop")]
+    sys.modules["enstop"] = pkg
+    np.float = float  # enstop/utils.py:277 uses the removed alias
+
+    # placeholders so `import enstop.enstop_` succeeds; never called below
+    for name in ("dask", "hdbscan", "hdbscan._hdbscan_linkage", "hdbscan.hdbscan_",
+                 "umap", "umap.distances"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["hdbscan._hdbscan_linkage"].mst_linkage_core = None
+    sys.modules["hdbscan._hdbscan_linkage"].label = None
+    sys.modules["hdbscan.hdbscan_"]._tree_to_labels = None
+    sys.modules["umap.distances"].hellinger = None
+
+
+install_shims()
+import enstop.utils  # noqa: E402
+import enstop.plsa as ref  # noqa: E402
+import enstop.enstop_ as ref_ens  # noqa: E402
+
+
+# --------------------------------------------------------------------------- data
+def make_counts(n, m, density, seed, max_count=6, empty_rows=()):
+    rs = np.random.RandomState(seed)
+    X = sp.random(n, m, density=density, random_state=rs, format="csr", dtype=np.float64)
+    X.data = np.ceil(X.data * max_count)
+    X = X.tolil()
+    for r in range(n):                      # no accidental empty rows / keep it canonical
+        if X[r].nnz == 0 and r not in empty_rows:
+            X[r, rs.randint(m)] = 1.0
+    for r in empty_rows:
+        X[r] = 0
+    X = X.tocsr()
+    X.eliminate_zeros()
+    X.sort_indices()
+    return X
+
+
+def random_factors(n, m, k, seed):
+    rs = np.random.RandomState(seed)
+    V = rs.rand(k, m)
+    U = rs.rand(n, k)
+    V /= V.sum(axis=1, keepdims=True)
+    U /= U.sum(axis=1, keepdims=True)
+    return U.astype(np.float32), V.astype(np.float32)
+
+
+class Recorder:
+    """Wraps module-level functions of the reference to record the LL trace and
+    the number of E-steps (= EM iterations actually executed)."""
+
+    def __init__(self):
+        self.ll = []
+        self.n_e = 0
+        self._ll = ref.log_likelihood
+        self._e = ref.plsa_e_step
+
+    def __enter__(self):
+        def ll(*a):
+            v = self._ll(*a)
+            self.ll.append(np.float32(v))
+            return v
+
+        def e(*a):
+            self.n_e += 1
+            return self._e(*a)
+
+        ref.log_likelihood = ll
+        ref.plsa_e_step = e
+        return self
+
+    def __exit__(self, *exc):
+        ref.log_likelihood = self._ll
+        ref.plsa_e_step = self._e
+
+
+def csr_parts(X):
+    X = X.tocsr()
+    return dict(indptr=X.indptr.astype(np.int32), indices=X.indices.astype(np.int32),
+                data=X.data.astype(np.float32), shape=np.array(X.shape, dtype=np.int64))
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+# --------------------------------------------------------------------------- kernel-level goldens
+def gen_kernels(name, n, m, k, density, seed, thresh, zero_doc=None):
+    X = make_counts(n, m, density, seed)
+    A = X.tocoo().astype(np.float32)
+    U, V = random_factors(n, m, k, seed + 1)
+    if zero_doc is not None:
+        U[zero_doc] = 0.0                    # norm == 0 branch of the E-step (plsa.py:104)
+    rs = np.random.RandomState(seed + 2)
+    sw = (0.25 + 1.5 * rs.rand(n)).astype(np.float32)
+    ones = np.ones(n, dtype=np.float32)
+
+    P = np.full((A.nnz, k), -7.0, dtype=np.float32)     # poison: every cell must be written
+    ref.plsa_e_step(A.row, A.col, A.data, V, U, P, np.float32(thresh))
+
+    Vm, Um = V.copy(), U.copy()
+    npwz = np.zeros(k, np.float32); npdz = np.zeros(n, np.float32)
+    ref.plsa_m_step(A.row, A.col, A.data, Vm, Um, P, npwz, npdz)
+
+    Vw, Uw = V.copy(), U.copy()
+    npwz_w = np.zeros(k, np.float32); npdz_w = np.zeros(n, np.float32)
+    ref.plsa_m_step_w_sample_weight(A.row, A.col, A.data, Vw, Uw, P, sw, npwz_w, npdz_w)
+
+    Ur = U.copy()
+    npdz_r = np.zeros(n, np.float32)
+    ref.plsa_refit_m_step(A.row, A.col, A.data, V, Ur, P, ones, npdz_r)
+
+    with np.errstate(divide="ignore"):
+        ll1 = ref.log_likelihood(A.row, A.col, A.data, V, U, ones)
+        llw = ref.log_likelihood(A.row, A.col, A.data, V, U, sw)
+        ll_after = ref.log_likelihood(A.row, A.col, A.data, Vm, Um, ones)
+
+    save(name, **csr_parts(X), k=np.int64(k), thresh=np.float32(thresh), U=U, V=V, sw=sw,
+         P=P, V_m=Vm, U_m=Um, norm_pwz=npwz, norm_pdz=npdz,
+         V_mw=Vw, U_mw=Uw, norm_pwz_w=npwz_w, norm_pdz_w=npdz_w,
+         U_refit=Ur, norm_pdz_refit=npdz_r,
+         ll_ones=np.float32(ll1), ll_sw=np.float32(llw), ll_after_m=np.float32(ll_after))
+
+
+# --------------------------------------------------------------------------- driver-level goldens
+def gen_fit(name, n, m, k, density, seed, n_iter, n_iter_per_test, tol, thresh=1e-32,
+            weighted=False, tuple_init=False, fit_seed=7):
+    X = make_counts(n, m, density, seed)
+    rs = np.random.RandomState(seed + 3)
+    sw = (0.5 + rs.rand(n)).astype(np.float32) if weighted else np.ones(n, np.float32)
+    if tuple_init:
+        Ui, Vi = random_factors(n, m, k, seed + 4)
+        Ui = Ui.astype(np.float64) * 3.0        # un-normalised on purpose: plsa_init normalises
+        Vi = Vi.astype(np.float64) * 0.5
+        init = (Ui.copy(), Vi.copy())
+    else:
+        init = "random"
+    # the initial factors exactly as plsa_fit derives them (plsa.py:707-710)
+    if tuple_init:
+        U0, V0 = ref.plsa_init(X, k, init=(Ui.copy(), Vi.copy()))
+    else:
+        U0, V0 = ref.plsa_init(X, k, init="random", rng=np.random.RandomState(fit_seed))
+    U0 = U0.astype(np.float32, order="C"); V0 = V0.astype(np.float32, order="C")
+    with Recorder() as rec, np.errstate(divide="ignore"):
+        U, V = ref.plsa_fit(X, k, sw, init=init, n_iter=n_iter, n_iter_per_test=n_iter_per_test,
+                            tolerance=tol, e_step_thresh=thresh, random_state=fit_seed)
+    extra = {}
+    if tuple_init:
+        extra = dict(U_init=Ui, V_init=Vi)
+    save(name, **csr_parts(X), k=np.int64(k), sw=sw, n_iter=np.int64(n_iter),
+         n_iter_per_test=np.int64(n_iter_per_test), tol=np.float64(tol), thresh=np.float64(thresh),
+         fit_seed=np.int64(fit_seed), U0=U0, V0=V0, U=U, V=V,
+         ll_trace=np.array(rec.ll, np.float32), iters=np.int64(rec.n_e), **extra)
+    print("   %s: iters=%d ll[0]=%.6g ll[-1]=%.6g" % (name, rec.n_e, rec.ll[0], rec.ll[-1]))
+
+
+def gen_refit(name, n, m, k, density, seed, n_iter, n_iter_per_test, tol, weighted=False):
+    X = make_counts(n, m, density, seed)
+    _, topics = random_factors(n, m, k, seed + 5)
+    rs = np.random.RandomState(seed + 6)
+    sw = (0.5 + rs.rand(n)).astype(np.float32) if weighted else np.ones(n, np.float32)
+    with Recorder() as rec, np.errstate(divide="ignore"):
+        U = ref.plsa_refit(X, topics, sw, n_iter=n_iter, n_iter_per_test=n_iter_per_test,
+                           tolerance=tol, random_state=np.random.RandomState(42))
+    save(name, **csr_parts(X), k=np.int64(k), topics=topics, sw=sw, n_iter=np.int64(n_iter),
+         n_iter_per_test=np.int64(n_iter_per_test), tol=np.float64(tol), U=U,
+         ll_trace=np.array(rec.ll, np.float32), iters=np.int64(rec.n_e))
+    print("   %s: iters=%d" % (name, rec.n_e))
+
+
+def gen_estimator(name, dtype, empty_rows, seed):
+    n, m, k = 48, 64, 5
+    X = make_counts(n, m, 0.15, seed, empty_rows=empty_rows)
+    if dtype == "float":
+        Xin = X.astype(np.float64)
+        Xin.data = Xin.data * 0.37          # float input -> L1 row-normalised (utils.py:276-280)
+    else:
+        Xin = X.astype(np.int64)
+    model = ref.PLSA(n_components=k, n_iter=30, n_iter_per_test=10, tolerance=0.0, random_state=11)
+    with np.errstate(divide="ignore"):
+        emb = model.fit_transform(Xin)
+        Xt = make_counts(20, m, 0.2, seed + 9)
+        tr = model.transform(Xt.astype(np.int64))
+    parts = csr_parts(Xin)
+    save(name, indptr=parts["indptr"], indices=parts["indices"],
+         data=Xin.data.copy(), shape=parts["shape"], k=np.int64(k),
+         embedding=np.asarray(emb), embedding_dtype=np.array(str(np.asarray(emb).dtype)),
+         components=model.components_,
+         t_indptr=Xt.indptr.astype(np.int32), t_indices=Xt.indices.astype(np.int32),
+         t_data=Xt.data.astype(np.int64), t_shape=np.array(Xt.shape, np.int64), transformed=tr)
+
+
+def gen_member(name, seed):
+    """plsa_topics (enstop_.py:56-115): bootstrap + fit, and the serial ensemble stack."""
+    n, m, k = 70, 90, 6
+    X = make_counts(n, m, 0.12, seed)
+    kw = dict(n_iter=20, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-16)
+    with np.errstate(divide="ignore"):
+        # (a) RandomState instance shared by bootstrap and init (stream continues)
+        rs = np.random.RandomState(5)
+        Va = ref_ens.plsa_topics(X, k, random_state=rs, **kw)
+        idx_a = np.random.RandomState(5).randint(0, n, size=n)
+        # (b) int seed: bootstrap and init both re-seed (enstop_.py:86 + plsa.py:707)
+        Vb = ref_ens.plsa_topics(X, k, random_state=9, **kw)
+        idx_b = np.random.RandomState(9).randint(0, n, size=n)
+        # (c) bootstrap disabled
+        Vc = ref_ens.plsa_topics(X, k, random_state=9, bootstrap=False, **kw)
+        # (d) serial ensemble with one shared stream -> vstack (enstop_.py:220-231)
+        rs = np.random.RandomState(21)
+        Vd = ref_ens.ensemble_of_topics(X, k, model="plsa", n_jobs=1, n_runs=3,
+                                        parallelism="none", random_state=rs, **kw)
+    save(name, **csr_parts(X), k=np.int64(k), n_iter=np.int64(20), thresh=np.float64(1e-16),
+         V_rs5=Va, idx_rs5=idx_a, V_int9=Vb, idx_int9=idx_b, V_nobootstrap=Vc, V_stack_rs21=Vd)
+
+
+if __name__ == "__main__":
+    gen_kernels("kernels_k6", n=40, m=50, k=6, density=0.15, seed=100, thresh=1e-32)
+    gen_kernels("kernels_k8_thresh", n=36, m=44, k=8, density=0.2, seed=110, thresh=2.5e-3, zero_doc=3)
+    gen_kernels("kernels_k20", n=64, m=200, k=20, density=0.06, seed=120, thresh=1e-16)
+    gen_kernels("kernels_k33", n=20, m=30, k=33, density=0.25, seed=130, thresh=1e-32)
+
+    gen_fit("fit_k8_tol0", n=60, m=90, k=8, density=0.15, seed=200, n_iter=25, n_iter_per_test=10, tol=0.0)
+    gen_fit("fit_k5_earlystop", n=50, m=70, k=5, density=0.15, seed=210, n_iter=100, n_iter_per_test=10, tol=1e-3)
+    gen_fit("fit_k4_weighted", n=50, m=60, k=4, density=0.2, seed=220, n_iter=21, n_iter_per_test=5, tol=0.0, weighted=True)
+    gen_fit("fit_k8_thresh", n=40, m=64, k=8, density=0.2, seed=230, n_iter=15, n_iter_per_test=10, tol=0.0, thresh=2e-3)
+    gen_fit("fit_k6_tupleinit", n=40, m=50, k=6, density=0.2, seed=240, n_iter=12, n_iter_per_test=4, tol=0.0, tuple_init=True)
+    gen_fit("fit_k16_mid", n=300, m=400, k=16, density=0.05, seed=250, n_iter=30, n_iter_per_test=10, tol=0.0)
+    gen_fit("fit_k20_50it", n=120, m=300, k=20, density=0.05, seed=260, n_iter=50, n_iter_per_test=10, tol=0.0)
+
+    gen_refit("refit_k6", n=40, m=60, k=6, density=0.2, seed=300, n_iter=50, n_iter_per_test=5, tol=0.001)
+    gen_refit("refit_k8_weighted", n=30, m=50, k=8, density=0.2, seed=310, n_iter=20, n_iter_per_test=10, tol=0.005, weighted=True)
+
+    gen_estimator("estimator_int", "int", empty_rows=(), seed=400)
+    gen_estimator("estimator_float", "float", empty_rows=(), seed=410)
+    gen_estimator("estimator_int_emptyrows", "int", empty_rows=(0, 17, 47), seed=420)
+
+    gen_member("member_k6", seed=500)

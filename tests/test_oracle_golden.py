@@ -1,0 +1,139 @@
+"""Pins the CPU oracle (oracle/plsa_oracle.c) to vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU-only; runs in the build container and on the GPU box."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_csr, coo_arrays
+
+KERNEL_CASES = ["kernels_k6", "kernels_k8_thresh", "kernels_k20", "kernels_k33"]
+FIT_CASES = ["fit_k8_tol0", "fit_k5_earlystop", "fit_k4_weighted", "fit_k8_thresh",
+             "fit_k6_tupleinit", "fit_k16_mid", "fit_k20_50it"]
+
+
+@pytest.mark.parametrize("case", KERNEL_CASES)
+def test_e_step_bit_exact(oracle, case):
+    g = load_golden(case)
+    r, c, v = coo_arrays(golden_csr(g))
+    P = np.full_like(g["P"], -7.0)
+    oracle.plsa_e_step(r, c, v, g["V"].copy(), g["U"].copy(), P, g["thresh"])
+    np.testing.assert_array_equal(P, g["P"])
+
+
+@pytest.mark.parametrize("case", KERNEL_CASES)
+def test_m_steps_bit_exact(oracle, case):
+    g = load_golden(case)
+    r, c, v = coo_arrays(golden_csr(g))
+    n, k = g["U"].shape
+    V, U = g["V"].copy(), g["U"].copy()
+    a, b = np.zeros(k, np.float32), np.zeros(n, np.float32)
+    oracle.plsa_m_step(r, c, v, V, U, g["P"], a, b)
+    np.testing.assert_array_equal(V, g["V_m"]); np.testing.assert_array_equal(U, g["U_m"])
+    np.testing.assert_array_equal(a, g["norm_pwz"]); np.testing.assert_array_equal(b, g["norm_pdz"])
+
+    V, U = g["V"].copy(), g["U"].copy()
+    oracle.plsa_m_step_w_sample_weight(r, c, v, V, U, g["P"], g["sw"], a, b)
+    np.testing.assert_array_equal(V, g["V_mw"]); np.testing.assert_array_equal(U, g["U_mw"])
+    np.testing.assert_array_equal(a, g["norm_pwz_w"]); np.testing.assert_array_equal(b, g["norm_pdz_w"])
+
+    U = g["U"].copy()
+    oracle.plsa_refit_m_step(r, c, v, g["V"].copy(), U, g["P"], np.ones(n, np.float32), b)
+    np.testing.assert_array_equal(U, g["U_refit"]); np.testing.assert_array_equal(b, g["norm_pdz_refit"])
+
+
+@pytest.mark.parametrize("case", KERNEL_CASES)
+def test_log_likelihood(oracle, case):
+    g = load_golden(case)
+    r, c, v = coo_arrays(golden_csr(g))
+    n = g["U"].shape[0]
+    ones = np.ones(n, np.float32)
+    for sw, key, VV, UU in ((ones, "ll_ones", g["V"], g["U"]), (g["sw"], "ll_sw", g["V"], g["U"]),
+                            (ones, "ll_after_m", g["V_m"], g["U_m"])):
+        got = oracle.log_likelihood(r, c, v, VV, UU, sw)
+        if np.isinf(g[key]):
+            assert got == g[key]
+        else:
+            # numpy float32 log vs libm logf: last-ulp differences only
+            np.testing.assert_allclose(got, g[key], rtol=2e-6)
+
+
+@pytest.mark.parametrize("case", FIT_CASES)
+def test_fit_matches_reference(oracle, case):
+    g = load_golden(case)
+    X = golden_csr(g)
+    init = (g["U_init"], g["V_init"]) if "U_init" in g else "random"
+    U, V, trace, iters = oracle.plsa_fit(X, int(g["k"]), g["sw"], init=init, n_iter=int(g["n_iter"]),
+                                        n_iter_per_test=int(g["n_iter_per_test"]),
+                                        tolerance=float(g["tol"]), e_step_thresh=float(g["thresh"]),
+                                        random_state=int(g["fit_seed"]), return_trace=True)
+    assert iters == int(g["iters"])
+    assert trace.shape == g["ll_trace"].shape
+    fin = np.isfinite(g["ll_trace"])
+    np.testing.assert_array_equal(np.isfinite(trace), fin)
+    np.testing.assert_allclose(trace[fin], g["ll_trace"][fin], rtol=2e-6)
+    # factors never depend on the log-likelihood value (only on the stop decision): bit-exact
+    np.testing.assert_array_equal(U, g["U"])
+    np.testing.assert_array_equal(V, g["V"])
+
+
+@pytest.mark.parametrize("case", ["fit_k8_tol0", "fit_k6_tupleinit"])
+def test_init_matches_reference(oracle, case):
+    g = load_golden(case)
+    X = golden_csr(g)
+    init = (g["U_init"], g["V_init"]) if "U_init" in g else "random"
+    U, V = oracle.plsa_fit(X, int(g["k"]), g["sw"], init=init, n_iter=0, random_state=int(g["fit_seed"]))
+    np.testing.assert_array_equal(U, g["U0"]); np.testing.assert_array_equal(V, g["V0"])
+
+
+@pytest.mark.parametrize("case", ["refit_k6", "refit_k8_weighted"])
+def test_refit_matches_reference(oracle, case):
+    g = load_golden(case)
+    X = golden_csr(g)
+    U, trace, iters = oracle.plsa_refit(X, g["topics"], g["sw"], n_iter=int(g["n_iter"]),
+                                       n_iter_per_test=int(g["n_iter_per_test"]),
+                                       tolerance=float(g["tol"]),
+                                       random_state=np.random.RandomState(42), return_trace=True)
+    assert iters == int(g["iters"]) == int(g["n_iter"])      # refit never early-stops (plsa.py:913)
+    np.testing.assert_allclose(trace, g["ll_trace"], rtol=2e-6)
+    np.testing.assert_array_equal(U, g["U"])
+
+
+def test_member_bootstrap_matches_reference(oracle):
+    """enstop_.py:84-115: bootstrap rows with rng.randint, then plsa_fit with the SAME stream."""
+    g = load_golden("member_k6")
+    X = golden_csr(g)
+    n, k = X.shape[0], int(g["k"])
+    ones = np.ones(n, np.float32)
+    kw = dict(n_iter=int(g["n_iter"]), n_iter_per_test=10, tolerance=0.0, e_step_thresh=float(g["thresh"]))
+    rs = np.random.RandomState(5)
+    idx = rs.randint(0, n, size=n)
+    np.testing.assert_array_equal(idx, g["idx_rs5"])
+    _, V = oracle.plsa_fit(X[idx], k, ones, random_state=rs, **kw)
+    np.testing.assert_array_equal(V, g["V_rs5"])
+    idx = np.random.RandomState(9).randint(0, n, size=n)
+    _, V = oracle.plsa_fit(X[idx], k, ones, random_state=9, **kw)
+    np.testing.assert_array_equal(V, g["V_int9"])
+    _, V = oracle.plsa_fit(X, k, ones, random_state=9, **kw)
+    np.testing.assert_array_equal(V, g["V_nobootstrap"])
+    rs = np.random.RandomState(21)
+    stack = []
+    for _ in range(3):
+        idx = rs.randint(0, n, size=n)
+        stack.append(oracle.plsa_fit(X[idx], k, ones, random_state=rs, **kw)[1])
+    np.testing.assert_array_equal(np.vstack(stack), g["V_stack_rs21"])
+
+
+def test_threaded_oracle_agrees(oracle):
+    """The multi-threaded run (used as the timed CPU baseline) only reorders the LL reduction."""
+    from oracle.plsa_oracle import Oracle
+    g = load_golden("fit_k16_mid")
+    X = golden_csr(g)
+    o = Oracle(fast=True)
+    o.set_threads(4)
+    U, V, trace, iters = o.plsa_fit(X, int(g["k"]), g["sw"], n_iter=int(g["n_iter"]),
+                                    n_iter_per_test=int(g["n_iter_per_test"]), tolerance=0.0,
+                                    random_state=int(g["fit_seed"]), return_trace=True)
+    oracle.set_threads(1)
+    assert iters == int(g["iters"])
+    np.testing.assert_allclose(trace, g["ll_trace"], rtol=1e-5)
+    np.testing.assert_allclose(U, g["U"], rtol=0, atol=1e-4 * g["U"].max())
+    np.testing.assert_allclose(V, g["V"], rtol=0, atol=1e-4 * g["V"].max())
