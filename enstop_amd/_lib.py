@@ -1,0 +1,83 @@
+"""ctypes binding of libplsa_hip.so (the C ABI of include/plsa_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is visible, every entry
+point raises.  The library is built in-tree by ``python -m enstop_amd.build`` (or
+``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplsa_hip.so")
+
+PLSA_FUSED = 1
+PLSA_DETERMINISTIC = 2
+PLSA_TRACE_LL = 4
+
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_ctx = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+_vp = C.c_void_p          # nullable array arguments are passed as raw addresses
+
+# name -> (restype, argtypes); must list every symbol include/plsa_hip.h declares
+SIGNATURES = {
+    "plsa_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "plsa_create": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
+    "plsa_destroy": (None, [_ctx]),
+    "plsa_last_error": (C.c_char_p, [_ctx]),
+    "plsa_synchronize": (C.c_int, [_ctx]),
+    "plsa_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(_i64)]),
+    "plsa_upload_csr": (C.c_int, [_ctx, _i32p, _i32p, _f32p, _i64, _i64, _i64]),
+    "plsa_bootstrap": (C.c_int, [_ctx, _vp, _i64]),
+    "plsa_active_shape": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "plsa_download_active_csr": (C.c_int, [_ctx, _i32p, _i32p, _f32p]),
+    "plsa_set_factors": (C.c_int, [_ctx, _vp, _vp, _i64, _i64, _i32]),
+    "plsa_get_factors": (C.c_int, [_ctx, _vp, _vp]),
+    "plsa_copy_components_to_device": (C.c_int, [_ctx, _vp]),
+    "plsa_e_step": (C.c_int, [_ctx, C.c_float, _vp]),
+    "plsa_set_p": (C.c_int, [_ctx, _f32p]),
+    "plsa_m_step": (C.c_int, [_ctx, _vp, _i32, _i32, _vp, _vp]),
+    "plsa_log_likelihood": (C.c_int, [_ctx, _vp, C.POINTER(C.c_double)]),
+    "plsa_fit": (C.c_int, [_ctx, _vp, _i32, _i32, C.c_double, C.c_float, _i32, C.POINTER(_i32), _vp,
+                           C.POINTER(_i32)]),
+    "plsa_refit": (C.c_int, [_ctx, _vp, _i32, _i32, C.c_double, C.c_float, _i32, C.POINTER(_i32), _vp,
+                             C.POINTER(_i32)]),
+    "plsa_timing_enable": (C.c_int, [_ctx, _i32]),
+    "plsa_timing_reset": (C.c_int, [_ctx]),
+    "plsa_timing_get": (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "plsa_timing_report": (C.c_int, [_ctx, C.c_char_p, _i64]),
+    "plsa_host_normalize_rows": (None, [_f64p, _i64, _i64]),
+    "plsa_generate_synthetic": (C.c_int, [_ctx, _i64, _i64, _i64, C.c_double, C.c_uint64,
+                                          C.POINTER(_i64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libplsa_hip.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "enstop_amd: %s not found -- build the HIP extension first "
+            "(python -m enstop_amd.build). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    """Address of a C-contiguous ndarray, or None."""
+    return None if a is None else a.ctypes.data

@@ -1,0 +1,29 @@
+"""In-tree build of libplsa_hip.so for gfx950:  python -m enstop_amd.build"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "plsa_hip.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "plsa_kernels.hpp"), os.path.join(HERE, "csrc", "plsa_synth.hpp"),
+        os.path.join(os.path.dirname(HERE), "include", "plsa_hip.h")]
+OUT = os.path.join(HERE, "libplsa_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
+         "-Wall", "-Wno-unused-function"]
+
+
+def build(force=False, verbose=True):
+    deps = [d for d in DEPS if os.path.exists(d)]
+    if (not force and os.path.exists(OUT)
+            and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps)):
+        return OUT
+    cmd = [HIPCC] + FLAGS + [SRC, "-o", OUT]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,1083 @@
+// plsa_hip.hip -- host side of libplsa_hip.so: context, HBM layout, kernel dispatch, EM drivers and
+// the C ABI declared in include/plsa_hip.h.  gfx950 only; no other back-end exists.
+//
+// HBM layout per context (n docs, m words, k topics, kp = 4*ceil(k/4)):
+//   base CSR     indptr i32[n+1], col i32[nnz], val f32[nnz]      the uploaded corpus
+//   active CSR   same arrays for the matrix the EM runs on (== base, or a bootstrap resample)
+//   rowidx       i32[nnz]   COO row ids of the active matrix (nnz-parallel E-step)
+//   CSC copy     colptr i32[m+1], csc_row/csc_pos i32[nnz], csc_val f32[nnz], column items
+//                (built lazily, only for PLSA_DETERMINISTIC)
+//   U[2]         f32[n,kp]  P(z|d), double-buffered (a rejected iteration is simply not swapped in)
+//   Vt[2], Vacc  f32[m,kp]  P(w|z) word-major, double-buffered, + the un-normalised accumulator
+//   P            f32[nnz,kp] materialised responsibilities (only when not PLSA_FUSED)
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/plsa_hip.h"
+#include "plsa_kernels.hpp"
+#include "plsa_synth.hpp"
+
+using plsa::i64;
+
+namespace {
+
+thread_local std::string g_err;  // errors before a context exists
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct Timed {
+    int name_id;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct plsa_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+    int grid_cap = 2048;
+
+    // corpus
+    i64 bn = 0, bm = 0, bnnz = 0;
+    DevBuf b_indptr, b_col, b_val;
+    bool active_is_base = true;
+    i64 n = 0, m = 0, nnz = 0;
+    DevBuf a_indptr, a_col, a_val, rowidx;
+    const int *indptr = nullptr, *col = nullptr;
+    const float *val = nullptr;
+    bool rowidx_valid = false;
+
+    // CSC copy + column items
+    bool csc_valid = false;
+    int seg = 128;
+    i64 n_items = 0;
+    DevBuf colptr, csc_row, csc_val, csc_pos, item_first, item_col, item_start, partial;
+
+    // factors
+    int k = 0, kp = 0, lpn = 1, ch = 1;
+    DevBuf U[2], Vt[2], Vacc;
+    int cu = 0, cv = 0;
+    i64 fac_n = 0, fac_m = 0;
+    bool vacc_zero = false;
+    DevBuf P;
+    bool p_valid = false;
+
+    // small buffers
+    DevBuf sw, ll_partials, ll_out, colsum_partials, norm_pwz, norm_pdz, tmp0, tmp1, tmp2, cubtmp;
+    double *h_ll = nullptr;  // pinned
+
+    // timing
+    bool timing = false;
+    std::vector<std::string> names;
+    std::vector<Timed> timed;
+    std::vector<hipEvent_t> pool;
+    std::vector<double> acc_ms;
+    std::vector<i64> acc_n;
+};
+
+namespace {
+
+int fail(plsa_ctx *c, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_err = buf;
+    return 1;
+}
+
+#define HIPCHK(c, expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail((c), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,      \
+                        __LINE__);                                                                 \
+    } while (0)
+
+#define CHK(expr)                                                                                  \
+    do {                                                                                           \
+        int r_ = (expr);                                                                           \
+        if (r_) return r_;                                                                         \
+    } while (0)
+
+int ensure(plsa_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return 0;
+    if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return 0;
+}
+
+void release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+int name_id(plsa_ctx *c, const char *name) {
+    for (size_t i = 0; i < c->names.size(); ++i)
+        if (c->names[i] == name) return (int)i;
+    c->names.emplace_back(name);
+    c->acc_ms.push_back(0.0);
+    c->acc_n.push_back(0);
+    return (int)c->names.size() - 1;
+}
+
+hipEvent_t get_event(plsa_ctx *c) {
+    if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// folds finished event pairs into the per-kernel totals (requires the stream to be idle)
+int timing_flush(plsa_ctx *c) {
+    if (c->timed.empty()) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto &t : c->timed) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, t.a, t.b));
+        c->acc_ms[t.name_id] += ms;
+        c->acc_n[t.name_id] += 1;
+        c->pool.push_back(t.a);
+        c->pool.push_back(t.b);
+    }
+    c->timed.clear();
+    return 0;
+}
+
+struct Scope {  // brackets one kernel launch with events when timing is on
+    plsa_ctx *c;
+    Timed t;
+    bool on;
+    Scope(plsa_ctx *c_, const char *name) : c(c_), on(c_->timing) {
+        if (on) {
+            t.name_id = name_id(c, name);
+            t.a = get_event(c);
+            t.b = get_event(c);
+            (void)hipEventRecord(t.a, c->stream);
+        }
+    }
+    ~Scope() {
+        if (on) {
+            (void)hipEventRecord(t.b, c->stream);
+            c->timed.push_back(t);
+        }
+    }
+};
+
+template <class Fn>
+int dispatch_shape(plsa_ctx *c, Fn &&fn) {
+#define PLSA_SHAPE(L, H)                                                                           \
+    if (c->lpn == L && c->ch == H) {                                                               \
+        fn(std::integral_constant<int, L>{}, std::integral_constant<int, H>{});                    \
+        return 0;                                                                                  \
+    }
+    PLSA_SHAPE(1, 1) PLSA_SHAPE(2, 1) PLSA_SHAPE(4, 1) PLSA_SHAPE(8, 1) PLSA_SHAPE(16, 1)
+    PLSA_SHAPE(32, 1) PLSA_SHAPE(64, 1) PLSA_SHAPE(64, 2) PLSA_SHAPE(64, 4)
+#undef PLSA_SHAPE
+    return fail(c, "unsupported topic count k=%d (max 1024)", c->k);
+}
+
+int launch_check(plsa_ctx *c, const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+int grid_for(plsa_ctx *c, i64 work_items, int items_per_block) {
+    i64 need = (work_items + items_per_block - 1) / items_per_block;
+    if (need < 1) need = 1;
+    return (int)std::min<i64>(need, c->grid_cap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// corpus helpers
+// ---------------------------------------------------------------------------------------------
+void set_active_pointers(plsa_ctx *c) {
+    if (c->active_is_base) {
+        c->indptr = c->b_indptr.as<int>(); c->col = c->b_col.as<int>(); c->val = c->b_val.as<float>();
+        c->n = c->bn; c->m = c->bm; c->nnz = c->bnnz;
+    } else {
+        c->indptr = c->a_indptr.as<int>(); c->col = c->a_col.as<int>(); c->val = c->a_val.as<float>();
+    }
+    c->rowidx_valid = false;
+    c->csc_valid = false;
+    c->p_valid = false;
+}
+
+int ensure_rowidx(plsa_ctx *c) {
+    if (c->rowidx_valid) return 0;
+    CHK(ensure(c, c->rowidx, sizeof(int) * (size_t)c->nnz));
+    if (c->n > 0) {
+        Scope s(c, "k_expand_rows");
+        hipLaunchKernelGGL(plsa::k_expand_rows, dim3(grid_for(c, c->n, 4)), dim3(256), 0, c->stream,
+                           c->indptr, (int)c->n, c->rowidx.as<int>());
+    }
+    CHK(launch_check(c, "k_expand_rows"));
+    c->rowidx_valid = true;
+    return 0;
+}
+
+int exclusive_sum_int(plsa_ctx *c, const int *in, int *out, i64 count) {
+    size_t bytes = 0;
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)count, c->stream));
+    CHK(ensure(c, c->cubtmp, bytes));
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cubtmp.p, bytes, in, out, (int)count, c->stream));
+    return 0;
+}
+
+int ensure_csc(plsa_ctx *c) {
+    if (c->csc_valid) return 0;
+    CHK(ensure_rowidx(c));
+    const i64 nnz = c->nnz, m = c->m;
+    CHK(ensure(c, c->colptr, sizeof(int) * (size_t)(m + 1)));
+    CHK(ensure(c, c->csc_row, sizeof(int) * (size_t)nnz));
+    CHK(ensure(c, c->csc_val, sizeof(float) * (size_t)nnz));
+    CHK(ensure(c, c->csc_pos, sizeof(int) * (size_t)nnz));
+    CHK(ensure(c, c->tmp0, sizeof(int) * (size_t)std::max<i64>(nnz, m + 1)));  // counts, then sorted keys
+    CHK(ensure(c, c->tmp1, sizeof(int) * (size_t)nnz));                         // iota
+    // column histogram -> colptr
+    HIPCHK(c, hipMemsetAsync(c->tmp0.p, 0, sizeof(int) * (size_t)(m + 1), c->stream));
+    if (nnz > 0)
+        hipLaunchKernelGGL(plsa::k_col_count, dim3(grid_for(c, nnz, 256)), dim3(256), 0, c->stream,
+                           c->col, nnz, c->tmp0.as<int>());
+    CHK(launch_check(c, "k_col_count"));
+    CHK(exclusive_sum_int(c, c->tmp0.as<int>(), c->colptr.as<int>(), m + 1));
+    // stable sort of entry positions by column: within a column entries stay in document order
+    if (nnz > 0) {
+        hipLaunchKernelGGL(plsa::k_iota, dim3(grid_for(c, nnz, 256)), dim3(256), 0, c->stream,
+                           c->tmp1.as<int>(), nnz);
+        int bits = 1;
+        while (((i64)1 << bits) < m) ++bits;
+        size_t bytes = 0;
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, c->col, c->tmp0.as<int>(),
+                                                     c->tmp1.as<int>(), c->csc_pos.as<int>(), nnz, 0,
+                                                     bits, c->stream));
+        CHK(ensure(c, c->cubtmp, bytes));
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, bytes, c->col, c->tmp0.as<int>(),
+                                                     c->tmp1.as<int>(), c->csc_pos.as<int>(), nnz, 0,
+                                                     bits, c->stream));
+        hipLaunchKernelGGL(plsa::k_csc_gather, dim3(grid_for(c, nnz, 256)), dim3(256), 0, c->stream,
+                           c->csc_pos.as<int>(), c->rowidx.as<int>(), c->val, nnz,
+                           c->csc_row.as<int>(), c->csc_val.as<float>());
+        CHK(launch_check(c, "k_csc_gather"));
+    }
+    // column items
+    CHK(ensure(c, c->item_first, sizeof(int) * (size_t)(m + 1)));
+    HIPCHK(c, hipMemsetAsync(c->tmp0.p, 0, sizeof(int) * (size_t)(m + 1), c->stream));
+    hipLaunchKernelGGL(plsa::k_item_counts, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                       c->colptr.as<int>(), (int)m, c->seg, c->tmp0.as<int>());
+    CHK(exclusive_sum_int(c, c->tmp0.as<int>(), c->item_first.as<int>(), m + 1));
+    int n_items = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_items, c->item_first.as<int>() + m, sizeof(int), hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n_items = n_items;
+    CHK(ensure(c, c->item_col, sizeof(int) * (size_t)n_items));
+    CHK(ensure(c, c->item_start, sizeof(int) * (size_t)n_items));
+    hipLaunchKernelGGL(plsa::k_item_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                       c->colptr.as<int>(), c->item_first.as<int>(), (int)m, c->seg,
+                       c->item_col.as<int>(), c->item_start.as<int>());
+    CHK(launch_check(c, "k_item_fill"));
+    c->csc_valid = true;
+    return 0;
+}
+
+int upload_sw(plsa_ctx *c, const float *sw, const float **d_sw) {
+    *d_sw = nullptr;
+    if (!sw) return 0;
+    CHK(ensure(c, c->sw, sizeof(float) * (size_t)c->n));
+    HIPCHK(c, hipMemcpyAsync(c->sw.p, sw, sizeof(float) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+    *d_sw = c->sw.as<float>();
+    return 0;
+}
+
+int need_factors(plsa_ctx *c) {
+    if (c->k <= 0 || !c->U[0].p || !c->Vt[0].p) return fail(c, "factors not set (call plsa_set_factors)");
+    if (c->n <= 0) return fail(c, "no corpus uploaded");
+    if (c->fac_n != c->n || c->fac_m != c->m)
+        return fail(c, "factors were set for a %lld x %lld matrix but the active matrix is %lld x %lld "
+                       "(call plsa_set_factors after plsa_upload_csr / plsa_bootstrap)",
+                    (long long)c->fac_n, (long long)c->fac_m, (long long)c->n, (long long)c->m);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel wrappers
+// ---------------------------------------------------------------------------------------------
+int run_e_step(plsa_ctx *c, float thresh) {
+    CHK(ensure_rowidx(c));
+    CHK(ensure(c, c->P, sizeof(float) * (size_t)c->nnz * (size_t)c->kp));
+    const i64 tiles = (c->nnz + 63) / 64;
+    const int grid = grid_for(c, tiles, 4);
+    CHK(dispatch_shape(c, [&](auto L, auto H) {
+        Scope s(c, "k_e_step");
+        hipLaunchKernelGGL((plsa::k_e_step<decltype(L)::value, decltype(H)::value>), dim3(grid),
+                           dim3(256), 0, c->stream, c->rowidx.as<int>(), c->col, c->nnz,
+                           c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(), c->P.as<float>(), c->kp,
+                           thresh);
+    }));
+    CHK(launch_check(c, "k_e_step"));
+    c->p_valid = true;
+    return 0;
+}
+
+int ensure_vacc_zero(plsa_ctx *c) {
+    if (c->vacc_zero) return 0;
+    HIPCHK(c, hipMemsetAsync(c->Vacc.p, 0, sizeof(float) * (size_t)c->m * c->kp, c->stream));
+    c->vacc_zero = true;
+    return 0;
+}
+
+// document-owned pass: writes U[1-cu]; optional atomics into Vacc; optional LL partials
+int run_row_pass(plsa_ctx *c, bool from_p, bool atomic_v, bool want_ll, const float *d_sw,
+                 float thresh, float *d_norm_pdz, int *ll_blocks) {
+    const int grid = grid_for(c, c->n, 256 / c->lpn);
+    if (atomic_v) CHK(ensure_vacc_zero(c));
+    if (want_ll) CHK(ensure(c, c->ll_partials, sizeof(double) * (size_t)grid));
+    CHK(dispatch_shape(c, [&](auto L, auto H) {
+        constexpr int LPN = decltype(L)::value, CHn = decltype(H)::value;
+        const int *ip = c->indptr, *cl = c->col;
+        const float *vl = c->val, *U = c->U[c->cu].as<float>(), *Vt = c->Vt[c->cv].as<float>();
+        const float *P = c->P.as<float>();
+        float *Un = c->U[1 - c->cu].as<float>(), *Va = c->Vacc.as<float>();
+        double *llp = c->ll_partials.as<double>();
+        const int n = (int)c->n, kp = c->kp;
+        auto go = [&](auto FP, auto AV, auto LL, const char *name) {
+            Scope s(c, name);
+            hipLaunchKernelGGL((plsa::k_row_pass<LPN, CHn, decltype(FP)::value, decltype(AV)::value,
+                                                 decltype(LL)::value>),
+                               dim3(grid), dim3(256), 0, c->stream, ip, cl, vl, n, U, Vt, P, Un, Va,
+                               d_sw, d_norm_pdz, kp, thresh, llp);
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        if (from_p) {
+            if (atomic_v) go(T{}, T{}, F{}, "k_row_pass<P,atomicV>");
+            else go(T{}, F{}, F{}, "k_row_pass<P>");
+        } else if (atomic_v) {
+            if (want_ll) go(F{}, T{}, T{}, "k_row_pass<fused,atomicV,LL>");
+            else go(F{}, T{}, F{}, "k_row_pass<fused,atomicV>");
+        } else {
+            if (want_ll) go(F{}, F{}, T{}, "k_row_pass<fused,LL>");
+            else go(F{}, F{}, F{}, "k_row_pass<fused>");
+        }
+    }));
+    CHK(launch_check(c, "k_row_pass"));
+    if (atomic_v) c->vacc_zero = false;
+    if (ll_blocks) *ll_blocks = grid;
+    return 0;
+}
+
+// vocabulary-owned pass (no atomics): partial k-vectors per column item, then per-column sums -> Vacc
+int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh) {
+    CHK(ensure_csc(c));
+    CHK(ensure(c, c->partial, sizeof(float) * (size_t)std::max<i64>(c->n_items, 1) * c->kp));
+    CHK(dispatch_shape(c, [&](auto L, auto H) {
+        constexpr int LPN = decltype(L)::value, CHn = decltype(H)::value;
+        const int grid = grid_for(c, c->n_items, 256 / LPN);
+        const int grid2 = grid_for(c, c->m, 256 / LPN);
+        if (c->n_items > 0) {
+            if (from_p) {
+                Scope s(c, "k_col_pass<P>");
+                hipLaunchKernelGGL((plsa::k_col_pass<LPN, CHn, true>), dim3(grid), dim3(256), 0,
+                                   c->stream, c->item_col.as<int>(), c->item_start.as<int>(),
+                                   c->colptr.as<int>(), c->n_items, c->seg, c->csc_row.as<int>(),
+                                   c->csc_val.as<float>(), c->csc_pos.as<int>(),
+                                   c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
+                                   c->P.as<float>(), d_sw, c->partial.as<float>(), c->kp, thresh);
+            } else {
+                Scope s(c, "k_col_pass<fused>");
+                hipLaunchKernelGGL((plsa::k_col_pass<LPN, CHn, false>), dim3(grid), dim3(256), 0,
+                                   c->stream, c->item_col.as<int>(), c->item_start.as<int>(),
+                                   c->colptr.as<int>(), c->n_items, c->seg, c->csc_row.as<int>(),
+                                   c->csc_val.as<float>(), c->csc_pos.as<int>(),
+                                   c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
+                                   c->P.as<float>(), d_sw, c->partial.as<float>(), c->kp, thresh);
+            }
+        }
+        {
+            Scope s(c, "k_col_reduce");
+            hipLaunchKernelGGL((plsa::k_col_reduce<LPN, CHn>), dim3(grid2), dim3(256), 0, c->stream,
+                               c->item_first.as<int>(), (int)c->m, c->partial.as<float>(),
+                               c->Vacc.as<float>(), c->kp);
+        }
+    }));
+    CHK(launch_check(c, "k_col_pass"));
+    c->vacc_zero = false;
+    return 0;
+}
+
+// Vacc -> normalised topics in Vt[1-cv]  (plsa.py:196-199)
+int run_v_normalise(plsa_ctx *c, bool rezero, float *d_norm_pwz) {
+    const int nb = (int)std::min<i64>(plsa::NORM_BLOCKS, std::max<i64>(1, c->m));
+    CHK(ensure(c, c->colsum_partials, sizeof(double) * (size_t)nb * c->kp));
+    {
+        Scope s(c, "k_colsum_partial");
+        hipLaunchKernelGGL(plsa::k_colsum_partial, dim3(nb), dim3(256), 256 * sizeof(double), c->stream,
+                           c->Vacc.as<float>(), (int)c->m, c->kp, c->colsum_partials.as<double>());
+    }
+    {
+        Scope s(c, "k_v_normalise");
+        const i64 total4 = c->m * c->kp / 4;
+        hipLaunchKernelGGL(plsa::k_v_normalise, dim3(grid_for(c, total4, 256)), dim3(256),
+                           c->kp * sizeof(float), c->stream, c->Vacc.as<float>(),
+                           c->Vt[1 - c->cv].as<float>(), (int)c->m, c->kp,
+                           c->colsum_partials.as<double>(), nb, d_norm_pwz, rezero ? 1 : 0);
+    }
+    CHK(launch_check(c, "k_v_normalise"));
+    c->vacc_zero = rezero;
+    return 0;
+}
+
+int finish_ll(plsa_ctx *c, int blocks, double *out) {
+    CHK(ensure(c, c->ll_out, sizeof(double)));
+    {
+        Scope s(c, "k_ll_final");
+        hipLaunchKernelGGL(plsa::k_ll_final, dim3(1), dim3(256), 0, c->stream,
+                           c->ll_partials.as<double>(), blocks, c->ll_out.as<double>());
+    }
+    CHK(launch_check(c, "k_ll_final"));
+    HIPCHK(c, hipMemcpyAsync(c->h_ll, c->ll_out.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out = *c->h_ll;
+    return 0;
+}
+
+int run_loglik(plsa_ctx *c, const float *d_sw, double *out) {
+    const int grid = grid_for(c, c->n, 256 / c->lpn);
+    CHK(ensure(c, c->ll_partials, sizeof(double) * (size_t)grid));
+    CHK(dispatch_shape(c, [&](auto L, auto H) {
+        constexpr int LPN = decltype(L)::value, CHn = decltype(H)::value;
+        Scope s(c, "k_loglik");
+        hipLaunchKernelGGL((plsa::k_loglik<LPN, CHn>), dim3(grid), dim3(256), 0, c->stream, c->indptr,
+                           c->col, c->val, (int)c->n, c->U[c->cu].as<float>(),
+                           c->Vt[c->cv].as<float>(), d_sw, c->kp, c->ll_partials.as<double>());
+    }));
+    CHK(launch_check(c, "k_loglik"));
+    return finish_ll(c, grid, out);
+}
+
+// one M-step from the materialised P: U[1-cu], and (update_v) Vt[1-cv]; swaps the buffers in
+int run_m_step_from_p(plsa_ctx *c, const float *d_sw, bool update_v, bool deterministic,
+                      float *d_norm_pwz, float *d_norm_pdz) {
+    if (!c->p_valid) return fail(c, "plsa_m_step: no P(z|w,d) on the device (run plsa_e_step or plsa_set_p)");
+    if (update_v && deterministic) {
+        CHK(run_row_pass(c, true, false, false, d_sw, 0.f, d_norm_pdz, nullptr));
+        CHK(run_col_pass(c, true, d_sw, 0.f));
+        CHK(run_v_normalise(c, false, d_norm_pwz));
+    } else if (update_v) {
+        CHK(run_row_pass(c, true, true, false, d_sw, 0.f, d_norm_pdz, nullptr));
+        CHK(run_v_normalise(c, true, d_norm_pwz));
+    } else {
+        CHK(run_row_pass(c, true, false, false, nullptr, 0.f, d_norm_pdz, nullptr));
+    }
+    c->cu ^= 1;
+    if (update_v) c->cv ^= 1;
+    return 0;
+}
+
+// the reference's stop test, plsa.py:634-638: float32 arithmetic, float64 comparison with tolerance
+bool stop_test(float cur, float &prev, double tol) {
+    const float change = fabsf(cur - prev);
+    if (change == 0.0f || (double)(change / fabsf(cur)) < tol) return true;
+    prev = cur;
+    return false;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int plsa_device_count(int *count) {
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) { *count = 0; return fail(nullptr, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return 0;
+}
+
+const char *plsa_last_error(const plsa_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int plsa_create(int device, plsa_ctx **out) {
+    *out = nullptr;
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        return fail(nullptr, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= cnt) return fail(nullptr, "device %d out of range [0,%d)", device, cnt);
+    plsa_ctx *c = new plsa_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess) {
+        delete c;
+        return fail(nullptr, "hipSetDevice(%d) failed", device);
+    }
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string arch = c->prop.gcnArchName;
+        delete c;
+        return fail(nullptr, "libplsa_hip is built for gfx950 (MI355X) only; device %d is %s", device,
+                    arch.c_str());
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_ll, sizeof(double) * 2, hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return fail(nullptr, "stream / pinned buffer creation failed");
+    }
+    int mult = 8;
+    if (const char *s = getenv("PLSA_GRID_MULT")) mult = std::max(1, atoi(s));
+    c->grid_cap = c->prop.multiProcessorCount * mult;
+    if (const char *s = getenv("PLSA_COL_SEG")) c->seg = std::max(1, atoi(s));
+    *out = c;
+    return 0;
+}
+
+void plsa_destroy(plsa_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,
+                     &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
+                     &c->item_start, &c->partial, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,
+                     &c->P, &c->sw, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
+                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp};
+    for (DevBuf *b : all) release(*b);
+    for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    if (c->h_ll) (void)hipHostFree(c->h_ll);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int plsa_synchronize(plsa_ctx *c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_device_info(plsa_ctx *c, char *name64, char *arch64, int *cus, int64_t *hbm_bytes) {
+    if (name64) { strncpy(name64, c->prop.name, 63); name64[63] = 0; }
+    if (arch64) { strncpy(arch64, c->prop.gcnArchName, 63); arch64[63] = 0; }
+    if (cus) *cus = c->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)c->prop.totalGlobalMem;
+    return 0;
+}
+
+int plsa_upload_csr(plsa_ctx *c, const int32_t *indptr, const int32_t *indices, const float *data,
+                    int64_t n, int64_t m, int64_t nnz) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n <= 0 || m <= 0 || nnz < 0) return fail(c, "plsa_upload_csr: bad shape n=%lld m=%lld nnz=%lld",
+                                                 (long long)n, (long long)m, (long long)nnz);
+    if (n >= INT32_MAX || m >= INT32_MAX || nnz >= INT32_MAX)
+        return fail(c, "plsa_upload_csr: n, m and nnz must each be < 2^31");
+    if (indptr[0] != 0 || indptr[n] != nnz) return fail(c, "plsa_upload_csr: indptr[0] != 0 or indptr[n] != nnz");
+    CHK(ensure(c, c->b_indptr, sizeof(int) * (size_t)(n + 1)));
+    CHK(ensure(c, c->b_col, sizeof(int) * (size_t)nnz));
+    CHK(ensure(c, c->b_val, sizeof(float) * (size_t)nnz));
+    HIPCHK(c, hipMemcpyAsync(c->b_indptr.p, indptr, sizeof(int) * (size_t)(n + 1), hipMemcpyHostToDevice, c->stream));
+    if (nnz) {
+        HIPCHK(c, hipMemcpyAsync(c->b_col.p, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->b_val.p, data, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->bn = n; c->bm = m; c->bnnz = nnz;
+    c->active_is_base = true;
+    set_active_pointers(c);
+    return 0;
+}
+
+int plsa_bootstrap(plsa_ctx *c, const int64_t *idx, int64_t n_out) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->bn <= 0) return fail(c, "plsa_bootstrap: no corpus uploaded");
+    if (!idx) {
+        c->active_is_base = true;
+        set_active_pointers(c);
+        return 0;
+    }
+    if (n_out <= 0 || n_out >= INT32_MAX) return fail(c, "plsa_bootstrap: bad n_out");
+    // idx -> device, row lengths (int64), exclusive scan -> output row pointers
+    CHK(ensure(c, c->tmp0, sizeof(i64) * (size_t)n_out));
+    CHK(ensure(c, c->tmp1, sizeof(i64) * (size_t)(n_out + 1)));
+    CHK(ensure(c, c->tmp2, sizeof(i64) * (size_t)(n_out + 1) + 16));
+    i64 *d_idx = c->tmp0.as<i64>();
+    int *d_len = c->tmp1.as<int>();
+    i64 *d_ptr = c->tmp2.as<i64>();
+    int *d_bad = reinterpret_cast<int *>(d_ptr + n_out + 1);
+    HIPCHK(c, hipMemcpyAsync(d_idx, idx, sizeof(i64) * (size_t)n_out, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(d_len, 0, sizeof(int) * (size_t)(n_out + 1), c->stream));
+    hipLaunchKernelGGL(plsa::k_boot_lengths, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
+                       c->b_indptr.as<int>(), d_idx, (i64)n_out, c->bn, d_len, d_bad);
+    CHK(launch_check(c, "k_boot_lengths"));
+    {
+        // int lengths summed into int64 pointers (a resample may exceed the base nnz)
+        auto in64 = hipcub::TransformInputIterator<i64, hipcub::CastOp<i64>, int *>(d_len, hipcub::CastOp<i64>());
+        size_t bytes = 0;
+        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in64, d_ptr, (int)(n_out + 1), c->stream));
+        CHK(ensure(c, c->cubtmp, bytes));
+        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cubtmp.p, bytes, in64, d_ptr, (int)(n_out + 1), c->stream));
+    }
+    i64 total = 0;
+    int bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, d_ptr + n_out, sizeof(i64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bad) return fail(c, "plsa_bootstrap: row index out of range [0,%lld)", (long long)c->bn);
+    if (total >= INT32_MAX) return fail(c, "plsa_bootstrap: resampled nnz %lld >= 2^31", (long long)total);
+    CHK(ensure(c, c->a_indptr, sizeof(int) * (size_t)(n_out + 1)));
+    CHK(ensure(c, c->a_col, sizeof(int) * (size_t)total));
+    CHK(ensure(c, c->a_val, sizeof(float) * (size_t)total));
+    {
+        Scope s(c, "k_boot_gather");
+        hipLaunchKernelGGL(plsa::k_boot_gather, dim3(grid_for(c, n_out + 1, 4)), dim3(256), 0, c->stream,
+                           c->b_indptr.as<int>(), c->b_col.as<int>(), c->b_val.as<float>(), d_idx,
+                           (i64)n_out, d_ptr, c->a_indptr.as<int>(), c->a_col.as<int>(),
+                           c->a_val.as<float>());
+    }
+    CHK(launch_check(c, "k_boot_gather"));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->active_is_base = false;
+    c->n = n_out; c->m = c->bm; c->nnz = total;
+    set_active_pointers(c);
+    return 0;
+}
+
+int plsa_active_shape(plsa_ctx *c, int64_t *n, int64_t *m, int64_t *nnz) {
+    if (n) *n = c->n;
+    if (m) *m = c->m;
+    if (nnz) *nnz = c->nnz;
+    return 0;
+}
+
+int plsa_download_active_csr(plsa_ctx *c, int32_t *indptr, int32_t *indices, float *data) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n <= 0) return fail(c, "no corpus uploaded");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (indptr) HIPCHK(c, hipMemcpy(indptr, c->indptr, sizeof(int) * (size_t)(c->n + 1), hipMemcpyDeviceToHost));
+    if (indices && c->nnz) HIPCHK(c, hipMemcpy(indices, c->col, sizeof(int) * (size_t)c->nnz, hipMemcpyDeviceToHost));
+    if (data && c->nnz) HIPCHK(c, hipMemcpy(data, c->val, sizeof(float) * (size_t)c->nnz, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int plsa_set_factors(plsa_ctx *c, const float *U, const float *V, int64_t n, int64_t m, int32_t k) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n <= 0) return fail(c, "plsa_set_factors: upload a corpus first");
+    if (n != c->n || m != c->m)
+        return fail(c, "plsa_set_factors: factor shapes (n=%lld, m=%lld) do not match the active matrix (%lld x %lld)",
+                    (long long)n, (long long)m, (long long)c->n, (long long)c->m);
+    if (k <= 0 || k > 1024) return fail(c, "plsa_set_factors: k=%d outside [1,1024]", k);
+    if (!U) return fail(c, "plsa_set_factors: U is NULL");
+    if (!V && (k != c->k || !c->Vt[0].p)) return fail(c, "plsa_set_factors: V is NULL but no topics with k=%d are resident", k);
+    const int kp = (k + 3) / 4 * 4;
+    c->k = k; c->kp = kp;
+    c->fac_n = n; c->fac_m = m;
+    int lpn = 1;
+    while (lpn < kp / 4 && lpn < 64) lpn *= 2;
+    c->lpn = lpn;
+    c->ch = (kp / 4 + lpn - 1) / lpn;
+    if (c->ch == 3) c->ch = 4;
+    for (int i = 0; i < 2; ++i) CHK(ensure(c, c->U[i], sizeof(float) * (size_t)n * kp));
+    for (int i = 0; i < 2; ++i) CHK(ensure(c, c->Vt[i], sizeof(float) * (size_t)m * kp));
+    CHK(ensure(c, c->Vacc, sizeof(float) * (size_t)m * kp));
+    c->vacc_zero = false;
+    c->p_valid = false;
+    c->cu = 0;
+    if (kp != k) HIPCHK(c, hipMemsetAsync(c->U[0].p, 0, sizeof(float) * (size_t)n * kp, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->U[0].p, sizeof(float) * kp, U, sizeof(float) * k, sizeof(float) * k,
+                               (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (V) {
+        c->cv = 0;
+        CHK(ensure(c, c->tmp0, sizeof(float) * (size_t)k * m));
+        HIPCHK(c, hipMemcpyAsync(c->tmp0.p, V, sizeof(float) * (size_t)k * m, hipMemcpyHostToDevice, c->stream));
+        dim3 grid((unsigned)((m + 31) / 32), (unsigned)((kp + 31) / 32));
+        hipLaunchKernelGGL(plsa::k_v_to_vt, grid, dim3(256), 0, c->stream, c->tmp0.as<float>(),
+                           c->Vt[0].as<float>(), k, (int)m, kp);
+        CHK(launch_check(c, "k_v_to_vt"));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_get_factors(plsa_ctx *c, float *U, float *V) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    if (U)
+        HIPCHK(c, hipMemcpy2DAsync(U, sizeof(float) * c->k, c->U[c->cu].p, sizeof(float) * c->kp,
+                                   sizeof(float) * c->k, (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    if (V) {
+        CHK(ensure(c, c->tmp0, sizeof(float) * (size_t)c->k * c->m));
+        dim3 grid((unsigned)((c->m + 31) / 32), (unsigned)((c->kp + 31) / 32));
+        hipLaunchKernelGGL(plsa::k_vt_to_v, grid, dim3(256), 0, c->stream, c->Vt[c->cv].as<float>(),
+                           c->tmp0.as<float>(), c->k, (int)c->m, c->kp);
+        CHK(launch_check(c, "k_vt_to_v"));
+        HIPCHK(c, hipMemcpyAsync(V, c->tmp0.p, sizeof(float) * (size_t)c->k * c->m, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_copy_components_to_device(plsa_ctx *c, void *dst) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    dim3 grid((unsigned)((c->m + 31) / 32), (unsigned)((c->kp + 31) / 32));
+    hipLaunchKernelGGL(plsa::k_vt_to_v, grid, dim3(256), 0, c->stream, c->Vt[c->cv].as<float>(),
+                       reinterpret_cast<float *>(dst), c->k, (int)c->m, c->kp);
+    CHK(launch_check(c, "k_vt_to_v"));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_e_step(plsa_ctx *c, float thresh, float *P_out) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    CHK(run_e_step(c, thresh));
+    if (P_out && c->nnz)
+        HIPCHK(c, hipMemcpy2DAsync(P_out, sizeof(float) * c->k, c->P.p, sizeof(float) * c->kp,
+                                   sizeof(float) * c->k, (size_t)c->nnz, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_set_p(plsa_ctx *c, const float *P) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    CHK(ensure(c, c->P, sizeof(float) * (size_t)c->nnz * c->kp));
+    if (c->kp != c->k) HIPCHK(c, hipMemsetAsync(c->P.p, 0, sizeof(float) * (size_t)c->nnz * c->kp, c->stream));
+    if (c->nnz)
+        HIPCHK(c, hipMemcpy2DAsync(c->P.p, sizeof(float) * c->kp, P, sizeof(float) * c->k,
+                                   sizeof(float) * c->k, (size_t)c->nnz, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->p_valid = true;
+    return 0;
+}
+
+int plsa_m_step(plsa_ctx *c, const float *sw, int32_t update_v, int32_t deterministic, float *norm_pwz,
+                float *norm_pdz) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    const float *d_sw = nullptr;
+    CHK(upload_sw(c, sw, &d_sw));
+    CHK(ensure(c, c->norm_pwz, sizeof(float) * (size_t)c->kp));
+    CHK(ensure(c, c->norm_pdz, sizeof(float) * (size_t)c->n));
+    CHK(run_m_step_from_p(c, d_sw, update_v != 0, deterministic != 0, c->norm_pwz.as<float>(),
+                          c->norm_pdz.as<float>()));
+    if (norm_pwz && update_v)
+        HIPCHK(c, hipMemcpyAsync(norm_pwz, c->norm_pwz.p, sizeof(float) * (size_t)c->k, hipMemcpyDeviceToHost, c->stream));
+    if (norm_pdz)
+        HIPCHK(c, hipMemcpyAsync(norm_pdz, c->norm_pdz.p, sizeof(float) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_log_likelihood(plsa_ctx *c, const float *sw, double *ll) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    const float *d_sw = nullptr;
+    CHK(upload_sw(c, sw, &d_sw));
+    return run_loglik(c, d_sw, ll);
+}
+
+// plsa_fit_inner, enstop/plsa.py:583-640.
+//
+// Materialised mode (flags without PLSA_FUSED) follows the reference's kernel sequence literally:
+// E-step -> M-step -> (every n_iter_per_test iterations) log-likelihood.
+//
+// Fused mode never writes P(z|w,d).  The log-likelihood the reference evaluates after iteration i
+// (i % n_iter_per_test == 0) is the likelihood of the factors that iteration i+1 reads, so it is
+// accumulated for free inside iteration i+1's document pass; the stop decision therefore arrives one
+// pass late and, when it says "stop", iteration i+1's output (sitting in the alternate buffers) is
+// discarded by not swapping -- the returned factors and iteration count are exactly the reference's.
+int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_test, double tolerance,
+             float thresh, int32_t flags, int32_t *iters_done, float *ll_trace, int32_t *n_ll) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    if (n_iter < 0 || n_iter_per_test <= 0) return fail(c, "plsa_fit: bad n_iter / n_iter_per_test");
+    const bool fused = flags & PLSA_FUSED, det = flags & PLSA_DETERMINISTIC, trace = flags & PLSA_TRACE_LL;
+    const float *d_sw = nullptr;
+    CHK(upload_sw(c, sw, &d_sw));
+    int nll = 0, iters = 0;
+    double ll = 0.0;
+    CHK(run_loglik(c, d_sw, &ll));                                   // plsa.py:591
+    float prev = (float)ll;
+    if (ll_trace) ll_trace[nll] = prev;
+    nll++;
+
+    if (!fused) {
+        for (int i = 0; i < n_iter; ++i) {
+            CHK(run_e_step(c, thresh));                              // plsa.py:597
+            CHK(run_m_step_from_p(c, d_sw, true, det, nullptr, nullptr));  // plsa.py:606-628
+            iters++;
+            if (i % n_iter_per_test == 0) {                          // plsa.py:630
+                if (i == n_iter - 1 && !trace) break;                // outcome cannot matter any more
+                CHK(run_loglik(c, d_sw, &ll));
+                const float cur = (float)ll;
+                if (ll_trace) ll_trace[nll] = cur;
+                nll++;
+                if (stop_test(cur, prev, tolerance)) break;
+            }
+        }
+    } else {
+        bool pending = false;  // a test is due on the factors currently in (cu, cv)
+        bool stopped = false;
+        for (int i = 0; i < n_iter; ++i) {
+            int blocks = 0;
+            CHK(run_row_pass(c, false, !det, pending, d_sw, thresh, nullptr, &blocks));
+            if (det) CHK(run_col_pass(c, false, d_sw, thresh));
+            CHK(run_v_normalise(c, !det, nullptr));
+            if (pending) {
+                CHK(finish_ll(c, blocks, &ll));
+                const float cur = (float)ll;
+                if (ll_trace) ll_trace[nll] = cur;
+                nll++;
+                if (stop_test(cur, prev, tolerance)) { stopped = true; break; }  // discard this pass
+            }
+            c->cu ^= 1; c->cv ^= 1;
+            iters++;
+            pending = (i % n_iter_per_test == 0);
+        }
+        if (!stopped && pending && trace) {  // test of the last iteration: result-neutral
+            CHK(run_loglik(c, d_sw, &ll));
+            if (ll_trace) ll_trace[nll] = (float)ll;
+            nll++;
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (iters_done) *iters_done = iters;
+    if (n_ll) *n_ll = nll;
+    return 0;
+}
+
+// plsa_refit_inner, enstop/plsa.py:884-920: topics frozen, only P(z|d) moves.
+int plsa_refit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_test, double tolerance,
+               float thresh, int32_t flags, int32_t *iters_done, float *ll_trace, int32_t *n_ll) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    if (n_iter < 0 || n_iter_per_test <= 0) return fail(c, "plsa_refit: bad n_iter / n_iter_per_test");
+    const bool fused = flags & PLSA_FUSED, trace = flags & PLSA_TRACE_LL;
+    const float *d_sw = nullptr;
+    CHK(upload_sw(c, sw, &d_sw));
+    int nll = 0, iters = 0;
+    double ll = 0.0;
+    CHK(run_loglik(c, d_sw, &ll));
+    float prev = (float)ll;
+    if (ll_trace) ll_trace[nll] = prev;
+    nll++;
+    // plsa.py:913-918: the test only acts on a positive log-likelihood
+    auto refit_stop = [&](float cur) {
+        if (cur > 0.0f) {
+            const float change = fabsf(cur - prev);
+            if ((double)(change / fabsf(cur)) < tolerance) return true;
+            prev = cur;
+        }
+        return false;
+    };
+    if (!fused) {
+        for (int i = 0; i < n_iter; ++i) {
+            CHK(run_e_step(c, thresh));
+            CHK(run_m_step_from_p(c, nullptr, false, false, nullptr, nullptr));
+            iters++;
+            if (i % n_iter_per_test == 0) {
+                if (i == n_iter - 1 && !trace) break;
+                CHK(run_loglik(c, d_sw, &ll));
+                const float cur = (float)ll;
+                if (ll_trace) ll_trace[nll] = cur;
+                nll++;
+                if (refit_stop(cur)) break;
+            }
+        }
+    } else {
+        bool pending = false, stopped = false;
+        for (int i = 0; i < n_iter; ++i) {
+            int blocks = 0;
+            // the refit M-step ignores sample weights for P(z|d) (plsa.py:806-809); they only enter
+            // the log-likelihood, which this pass accumulates when a test is pending
+            CHK(run_row_pass(c, false, false, pending, d_sw, thresh, nullptr, &blocks));
+            if (pending) {
+                CHK(finish_ll(c, blocks, &ll));
+                const float cur = (float)ll;
+                if (ll_trace) ll_trace[nll] = cur;
+                nll++;
+                if (refit_stop(cur)) { stopped = true; break; }
+            }
+            c->cu ^= 1;
+            iters++;
+            pending = (i % n_iter_per_test == 0);
+        }
+        if (!stopped && pending && trace) {
+            CHK(run_loglik(c, d_sw, &ll));
+            if (ll_trace) ll_trace[nll] = (float)ll;
+            nll++;
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (iters_done) *iters_done = iters;
+    if (n_ll) *n_ll = nll;
+    return 0;
+}
+
+int plsa_timing_enable(plsa_ctx *c, int32_t on) {
+    if (!on) CHK(timing_flush(c));
+    c->timing = on != 0;
+    return 0;
+}
+
+int plsa_timing_reset(plsa_ctx *c) {
+    CHK(timing_flush(c));
+    std::fill(c->acc_ms.begin(), c->acc_ms.end(), 0.0);
+    std::fill(c->acc_n.begin(), c->acc_n.end(), 0);
+    return 0;
+}
+
+int plsa_timing_get(plsa_ctx *c, const char *prefix, double *total_ms, int64_t *launches) {
+    CHK(timing_flush(c));
+    double t = 0.0;
+    i64 n = 0;
+    const size_t pl = strlen(prefix);
+    for (size_t i = 0; i < c->names.size(); ++i)
+        if (c->names[i].compare(0, pl, prefix) == 0) { t += c->acc_ms[i]; n += c->acc_n[i]; }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = n;
+    return 0;
+}
+
+int plsa_timing_report(plsa_ctx *c, char *buf, int64_t cap) {
+    CHK(timing_flush(c));
+    std::string s;
+    char line[256];
+    for (size_t i = 0; i < c->names.size(); ++i) {
+        if (!c->acc_n[i]) continue;
+        snprintf(line, sizeof line, "%s %lld %.6f\n", c->names[i].c_str(), (long long)c->acc_n[i], c->acc_ms[i]);
+        s += line;
+    }
+    if (cap > 0) { strncpy(buf, s.c_str(), (size_t)cap - 1); buf[cap - 1] = 0; }
+    return 0;
+}
+
+// enstop/utils.py:22-41 with axis=1 (float64, sequential marginal, guarded division)
+void plsa_host_normalize_rows(double *a, int64_t rows, int64_t cols) {
+    for (int64_t i = 0; i < rows; ++i) {
+        double *r = a + i * cols;
+        double marginal = 0.0;
+        for (int64_t j = 0; j < cols; ++j) marginal += r[j];
+        if (marginal > 0.0)
+            for (int64_t j = 0; j < cols; ++j) r[j] /= marginal;
+    }
+}
+
+// Synthetic corpus in HBM (see plsa_synth.hpp).  The mean token count per document is calibrated
+// by a short secant iteration so that the number of DISTINCT (doc, word) pairs lands within 0.5 %
+// of nnz_target; the final matrix depends only on the arguments.
+int plsa_generate_synthetic(plsa_ctx *c, int64_t n, int64_t m, int64_t nnz_target, double zipf_s,
+                            uint64_t seed, int64_t *nnz_out) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n <= 0 || m <= 1 || nnz_target < n || n >= INT32_MAX || m >= INT32_MAX)
+        return fail(c, "plsa_generate_synthetic: bad arguments (need nnz_target >= n, m > 1)");
+    // Zipf CDF over ranks (host, float64) and an affine permutation rank -> word id
+    std::vector<double> cdf((size_t)m);
+    double tot = 0.0;
+    for (int64_t r = 0; r < m; ++r) { tot += std::pow((double)(r + 1), -zipf_s); cdf[(size_t)r] = tot; }
+    for (int64_t r = 0; r < m; ++r) cdf[(size_t)r] /= tot;
+    cdf[(size_t)m - 1] = 1.0;
+    uint64_t a = (uint64_t)((double)m * 0.6180339887498949) | 1ull;
+    auto gcd = [](uint64_t x, uint64_t y) { while (y) { uint64_t t = x % y; x = y; y = t; } return x; };
+    while (gcd(a, (uint64_t)m) != 1) a += 2;
+    const uint64_t b = plsa::mix64(seed ^ 0xABCDEFull) % (uint64_t)m;
+    DevBuf d_cdf, d_tok, d_ptr, d_keys, d_keys2, d_flag, d_pos;
+    auto cleanup = [&]() { release(d_cdf); release(d_tok); release(d_ptr); release(d_keys);
+                           release(d_keys2); release(d_flag); release(d_pos); };
+#define SYN(expr) do { int r_ = (expr); if (r_) { cleanup(); return r_; } } while (0)
+#define SYNHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); \
+        return fail(c, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    SYN(ensure(c, d_cdf, sizeof(double) * (size_t)m));
+    SYNHIP(hipMemcpyAsync(d_cdf.p, cdf.data(), sizeof(double) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+    SYN(ensure(c, d_tok, sizeof(int) * (size_t)(n + 1)));
+    SYN(ensure(c, d_ptr, sizeof(i64) * (size_t)(n + 1)));
+    const double sigma = 0.6;
+    double mean_tokens = 1.4 * (double)nnz_target / (double)n;
+    i64 T = 0;
+    int nnz = 0;
+    int dbits = 1;
+    while (((i64)1 << dbits) < n) ++dbits;
+    for (int round = 0; round < 8; ++round) {
+        const double mu = std::log(mean_tokens) - 0.5 * sigma * sigma;
+        hipLaunchKernelGGL(plsa::k_synth_doc_tokens, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream,
+                           (int)n, mu, sigma, (int)std::min<i64>(m * 4, 1 << 20), seed, d_tok.as<int>());
+        {
+            auto in64 = hipcub::TransformInputIterator<i64, hipcub::CastOp<i64>, int *>(d_tok.as<int>(), hipcub::CastOp<i64>());
+            size_t bytes = 0;
+            SYNHIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in64, d_ptr.as<i64>(), (int)(n + 1), c->stream));
+            SYN(ensure(c, c->cubtmp, bytes));
+            SYNHIP(hipcub::DeviceScan::ExclusiveSum(c->cubtmp.p, bytes, in64, d_ptr.as<i64>(), (int)(n + 1), c->stream));
+        }
+        SYNHIP(hipMemcpyAsync(&T, d_ptr.as<i64>() + n, sizeof(i64), hipMemcpyDeviceToHost, c->stream));
+        SYNHIP(hipStreamSynchronize(c->stream));
+        if (T >= INT32_MAX) { cleanup(); return fail(c, "plsa_generate_synthetic: %lld tokens >= 2^31", (long long)T); }
+        SYN(ensure(c, d_keys, sizeof(unsigned long long) * (size_t)T));
+        SYN(ensure(c, d_keys2, sizeof(unsigned long long) * (size_t)T));
+        SYN(ensure(c, d_flag, sizeof(int) * (size_t)T));
+        SYN(ensure(c, d_pos, sizeof(int) * (size_t)T));
+        hipLaunchKernelGGL(plsa::k_synth_draw, dim3(grid_for(c, n, 4)), dim3(256), 0, c->stream, (int)n, (int)m,
+                           d_ptr.as<i64>(), d_cdf.as<double>(), a, b, seed, d_keys.as<unsigned long long>());
+        {
+            size_t bytes = 0;
+            SYNHIP(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, d_keys.as<unsigned long long>(),
+                                                     d_keys2.as<unsigned long long>(), T, 0, 32 + dbits, c->stream));
+            SYN(ensure(c, c->cubtmp, bytes));
+            SYNHIP(hipcub::DeviceRadixSort::SortKeys(c->cubtmp.p, bytes, d_keys.as<unsigned long long>(),
+                                                     d_keys2.as<unsigned long long>(), T, 0, 32 + dbits, c->stream));
+        }
+        hipLaunchKernelGGL(plsa::k_synth_heads, dim3(grid_for(c, T, 256)), dim3(256), 0, c->stream,
+                           d_keys2.as<unsigned long long>(), T, d_flag.as<int>());
+        {
+            size_t bytes = 0;
+            SYNHIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, d_flag.as<int>(), d_pos.as<int>(), (int)T, c->stream));
+            SYN(ensure(c, c->cubtmp, bytes));
+            SYNHIP(hipcub::DeviceScan::ExclusiveSum(c->cubtmp.p, bytes, d_flag.as<int>(), d_pos.as<int>(), (int)T, c->stream));
+        }
+        int last_pos = 0, last_flag = 0;
+        SYNHIP(hipMemcpyAsync(&last_pos, d_pos.as<int>() + (T - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        SYNHIP(hipMemcpyAsync(&last_flag, d_flag.as<int>() + (T - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        SYNHIP(hipStreamSynchronize(c->stream));
+        nnz = last_pos + last_flag;
+        const double rel = ((double)nnz - (double)nnz_target) / (double)nnz_target;
+        if (std::fabs(rel) < 0.005 || round == 7) break;
+        // distinct pairs grow sub-linearly in tokens: damped multiplicative correction
+        mean_tokens *= std::pow((double)nnz_target / (double)nnz, 1.25);
+    }
+    SYN(ensure(c, c->b_indptr, sizeof(int) * (size_t)(n + 1)));
+    SYN(ensure(c, c->b_col, sizeof(int) * (size_t)nnz));
+    SYN(ensure(c, c->b_val, sizeof(float) * (size_t)nnz));
+    hipLaunchKernelGGL(plsa::k_synth_emit, dim3(grid_for(c, T, 256)), dim3(256), 0, c->stream,
+                       d_keys2.as<unsigned long long>(), T, d_flag.as<int>(), d_pos.as<int>(), (int)n, nnz,
+                       c->b_indptr.as<int>(), c->b_col.as<int>(), c->b_val.as<float>());
+    SYN(launch_check(c, "k_synth_emit"));
+    SYNHIP(hipStreamSynchronize(c->stream));
+#undef SYN
+#undef SYNHIP
+    cleanup();
+    c->bn = n; c->bm = m; c->bnnz = nnz;
+    c->active_is_base = true;
+    set_active_pointers(c);
+    if (nnz_out) *nnz_out = nnz;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,597 @@
+// plsa_kernels.hpp -- gfx950 (CDNA4, wave64) device kernels of the pLSA EM engine.
+//
+// Work decomposition shared by every kernel: a "group" of LPN adjacent lanes (LPN = 1..64, power
+// of two) handles one non-zero (or one document row / one vocabulary column); each lane owns CH
+// float4 chunks of the k-vector, chunk c = lane_in_group + LPN*j.  k is padded to kp = 4*ceil(k/4)
+// in every device layout (U [n,kp], Vt [m,kp] word-major, P [nnz,kp]); pad entries are zero and can
+// never pass the `> thresh` test, so they do not perturb norms.  For k = 64: LPN = 16, CH = 1 -> a
+// wave covers 4 non-zeros per step and every gather / store is one 16-byte access per lane, 256
+// contiguous bytes per non-zero.
+//
+// Reference statements implemented here (paths relative to the reference root):
+//   E-step            enstop/plsa.py:91-105      M-step scatter    enstop/plsa.py:182-194, 287-300
+//   M-step normalise  enstop/plsa.py:196-202     log-likelihood    enstop/plsa.py:375-384
+//   refit M-step      enstop/plsa.py:801-814
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace plsa {
+
+typedef long long i64;
+
+// ------------------------------------------------------------------------------------------------
+// cross-lane sums inside a group of LPN lanes: DPP butterflies (no LDS traffic) up to 16 lanes,
+// ds_bpermute-based xor shuffles across the 16-lane DPP rows.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+template <int LPN>
+__device__ __forceinline__ float group_sum(float v) {
+    if (LPN >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
+    if (LPN >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
+    if (LPN >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror      : other quad of the 8
+    if (LPN >= 16) v += dpp_mov<0x140>(v);  // row_mirror           : other half of the 16
+    if (LPN >= 32) v += __shfl_xor(v, 16, 64);
+    if (LPN >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ __forceinline__ float hsum(const float4 &a) { return (a.x + a.y) + (a.z + a.w); }
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_nt(float *p, const float4 &v) {
+    f4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));  // global_store_dwordx4 ... nt
+}
+
+// responsibilities of one non-zero for this lane's chunks.
+//   keep[j] = (Vt*U > thresh) ? Vt*U : 0        (plsa.py:97-102)
+//   returns the lane-partial of the thresholded norm; *unth gets the un-thresholded partial
+template <int CH, bool WANT_UNTH>
+__device__ __forceinline__ float products(const float4 (&u)[CH], const float4 (&vt)[CH],
+                                          float thresh, float4 (&keep)[CH], float &unth) {
+    float part = 0.f;
+    unth = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        float4 v;
+        v.x = vt[j].x * u[j].x; v.y = vt[j].y * u[j].y; v.z = vt[j].z * u[j].z; v.w = vt[j].w * u[j].w;
+        if (WANT_UNTH) unth += hsum(v);
+        keep[j].x = v.x > thresh ? v.x : 0.f;
+        keep[j].y = v.y > thresh ? v.y : 0.f;
+        keep[j].z = v.z > thresh ? v.z : 0.f;
+        keep[j].w = v.w > thresh ? v.w : 0.f;
+        part += hsum(keep[j]);
+    }
+    return part;
+}
+
+template <int LPN, int CH>
+__device__ __forceinline__ void load_chunks(const float *row, int li, int kp, float4 (&out)[CH]) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int c4 = 4 * (li + LPN * j);
+        out[j] = (c4 < kp) ? ld4(row + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_e_step: the materialising E-step, plsa.py:91-105.  nnz-parallel: a wave takes a tile of 64
+// consecutive non-zeros, loads their (doc, word) ids with one coalesced access each, then walks the
+// tile 64/LPN non-zeros at a time.  Per non-zero: gather U[d,:] and Vt[w,:] (kp floats each),
+// multiply, threshold, group-sum, scale, stream the kp responsibilities out (non-temporal: P is
+// written once and not re-read by this kernel, it must not evict the factor rows from L2).
+// Algorithmic bytes: 4(n+1) + 4 nnz + 4k nnz + 4k(n+m)   (SURVEY.md section 8d).
+// ------------------------------------------------------------------------------------------------
+template <int LPN, int CH>
+__global__ __launch_bounds__(256) void k_e_step(const int *__restrict__ rowidx,
+                                                const int *__restrict__ colidx, i64 nnz,
+                                                const float *__restrict__ U,
+                                                const float *__restrict__ Vt, float *__restrict__ P,
+                                                int kp, float thresh) {
+    constexpr int GPW = 64 / LPN;  // groups (= non-zeros in flight) per wave
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane / LPN, li = lane % LPN;
+    const i64 tiles = (nnz + 63) >> 6;
+    for (i64 t = (i64)blockIdx.x * 4 + wave; t < tiles; t += (i64)gridDim.x * 4) {
+        const i64 base = t << 6;
+        const i64 mine = base + lane;
+        const int d_l = mine < nnz ? __builtin_nontemporal_load(rowidx + mine) : 0;
+        const int w_l = mine < nnz ? __builtin_nontemporal_load(colidx + mine) : 0;
+#pragma unroll 4
+        for (int s = 0; s < LPN; ++s) {
+            const int src = s * GPW + g;
+            const int d = __shfl(d_l, src, 64);
+            const int w = __shfl(w_l, src, 64);
+            const i64 nz = base + src;
+            float4 u[CH], vt[CH], keep[CH];
+            load_chunks<LPN, CH>(U + (i64)d * kp, li, kp, u);
+            load_chunks<LPN, CH>(Vt + (i64)w * kp, li, kp, vt);
+            float unth;
+            const float norm = group_sum<LPN>(products<CH, false>(u, vt, thresh, keep, unth));
+            // plsa.py:103-105: divide only when norm > 0 (otherwise the row is all zeros already)
+            const float inv = norm > 0.f ? 1.0f / norm : 0.f;
+            if (nz < nnz) {
+                float *prow = P + nz * kp;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int c4 = 4 * (li + LPN * j);
+                    if (c4 < kp) {
+                        float4 p;
+                        p.x = keep[j].x * inv; p.y = keep[j].y * inv;
+                        p.z = keep[j].z * inv; p.w = keep[j].w * inv;
+                        st4_nt(prow + c4, p);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_row_pass: document-owned half of the M-step (plsa.py:182-194 restricted to P(z|d), then the
+// P(z|d) part of 196-202), optionally fused with the E-step (FROM_P = false: responsibilities are
+// recomputed in registers and never touch HBM), with the log-likelihood of the CURRENT factors
+// (WANT_LL, plsa.py:375-384) and, when ATOMIC_V, with the P(w|z) scatter as float atomics into the
+// zero-initialised word-major accumulator Vt_new.
+// A group owns one row: no atomics on U, the row norm is a group sum, the normalised row is written
+// once.  Groups walk rows in a grid-stride loop.
+// ------------------------------------------------------------------------------------------------
+template <int LPN, int CH, bool FROM_P, bool ATOMIC_V, bool WANT_LL>
+__global__ __launch_bounds__(256) void k_row_pass(const int *__restrict__ indptr,
+                                                  const int *__restrict__ colidx,
+                                                  const float *__restrict__ vals, int n,
+                                                  const float *__restrict__ U,
+                                                  const float *__restrict__ Vt,
+                                                  const float *__restrict__ P,
+                                                  float *__restrict__ U_new,
+                                                  float *__restrict__ Vt_new,
+                                                  const float *__restrict__ sw,
+                                                  float *__restrict__ norm_pdz_out, int kp,
+                                                  float thresh, double *__restrict__ ll_partials) {
+    constexpr int GPB = 256 / LPN;  // groups per block
+    const int li = threadIdx.x % LPN;
+    const int gid = threadIdx.x / LPN;
+    double ll = 0.0;
+    for (i64 r = (i64)blockIdx.x * GPB + gid; r < n; r += (i64)gridDim.x * GPB) {
+        const int d = (int)r;
+        const int j0 = indptr[d], j1 = indptr[d + 1];
+        float4 u[CH], acc[CH];
+        if (!FROM_P || WANT_LL) load_chunks<LPN, CH>(U + (i64)d * kp, li, kp, u);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float swd = sw ? sw[d] : 1.0f;  // x1.0f is exact: one path for plsa.py:188 and :293
+        for (int jb = j0; jb < j1; jb += LPN) {
+            // one coalesced load of up to LPN (word, count) pairs of this row, then broadcast
+            const int jm = jb + li;
+            const int w_l = jm < j1 ? colidx[jm] : 0;
+            const float x_l = jm < j1 ? vals[jm] : 0.f;
+            const int cnt = min(LPN, j1 - jb);
+            for (int s = 0; s < cnt; ++s) {
+                const int w = __shfl(w_l, s, LPN);
+                const float x = __shfl(x_l, s, LPN);
+                float4 pz[CH];
+                float dot = 0.f;
+                if (FROM_P) {
+                    load_chunks<LPN, CH>(P + (i64)(jb + s) * kp, li, kp, pz);
+                    if (WANT_LL) {
+                        float4 vt[CH], keep[CH];
+                        float unth;
+                        load_chunks<LPN, CH>(Vt + (i64)w * kp, li, kp, vt);
+                        products<CH, true>(u, vt, thresh, keep, unth);
+                        dot = group_sum<LPN>(unth);
+                    }
+                } else {
+                    float4 vt[CH];
+                    float unth;
+                    load_chunks<LPN, CH>(Vt + (i64)w * kp, li, kp, vt);
+                    const float part = products<CH, WANT_LL>(u, vt, thresh, pz, unth);
+                    const float norm = group_sum<LPN>(part);
+                    if (WANT_LL) dot = group_sum<LPN>(unth);
+                    const float inv = norm > 0.f ? 1.0f / norm : 0.f;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        pz[j].x *= inv; pz[j].y *= inv; pz[j].z *= inv; pz[j].w *= inv;
+                    }
+                }
+                if (WANT_LL && li == 0) ll += (double)(x * logf(dot) * swd);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    float4 sv;  // s = x * P(z|w,d)        plsa.py:188
+                    sv.x = x * pz[j].x; sv.y = x * pz[j].y; sv.z = x * pz[j].z; sv.w = x * pz[j].w;
+                    acc[j].x += sv.x; acc[j].y += sv.y; acc[j].z += sv.z; acc[j].w += sv.w;
+                    if (ATOMIC_V) {
+                        const int c4 = 4 * (li + LPN * j);
+                        if (c4 < kp) {
+                            float *dst = Vt_new + (i64)w * kp + c4;
+                            sv.x *= swd; sv.y *= swd; sv.z *= swd; sv.w *= swd;  // plsa.py:294
+                            atomicAdd(dst + 0, sv.x);
+                            atomicAdd(dst + 1, sv.y);
+                            atomicAdd(dst + 2, sv.z);
+                            atomicAdd(dst + 3, sv.w);
+                        }
+                    }
+                }
+            }
+        }
+        // norm_pdz[d] and the division, plsa.py:194, 200-202
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) part += hsum(acc[j]);
+        const float rown = group_sum<LPN>(part);
+        if (norm_pdz_out && li == 0) norm_pdz_out[d] = rown;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int c4 = 4 * (li + LPN * j);
+            if (c4 < kp) {
+                float4 o = acc[j];
+                if (rown > 0.f) { o.x /= rown; o.y /= rown; o.z /= rown; o.w /= rown; }
+                st4(U_new + (i64)d * kp + c4, o);
+            }
+        }
+    }
+    if (WANT_LL) {
+        // block reduction of the per-group log-likelihood partials -> one double per block
+        __shared__ double red[256];
+        red[threadIdx.x] = ll;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) ll_partials[blockIdx.x] = red[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_col_pass: vocabulary-owned half of the M-step without atomics (PLSA_DETERMINISTIC).  The
+// active matrix is also held column-major (CSC: colptr, csc_row, csc_val, csc_pos = position of the
+// entry in CSR order).  Long columns (Zipf head words) are cut into items of at most SEG entries;
+// a group owns one item, accumulates x * P(z|w,d) [* sample_weight] in registers and writes one
+// partial k-vector; k_col_reduce adds the partials of a column in item order.
+// FROM_P = false recomputes the responsibilities from U (gather) and Vt (registers).
+// ------------------------------------------------------------------------------------------------
+template <int LPN, int CH, bool FROM_P>
+__global__ __launch_bounds__(256) void k_col_pass(const int *__restrict__ item_col,
+                                                  const int *__restrict__ item_start,
+                                                  const int *__restrict__ colptr, i64 n_items,
+                                                  int seg, const int *__restrict__ csc_row,
+                                                  const float *__restrict__ csc_val,
+                                                  const int *__restrict__ csc_pos,
+                                                  const float *__restrict__ U,
+                                                  const float *__restrict__ Vt,
+                                                  const float *__restrict__ P,
+                                                  const float *__restrict__ sw,
+                                                  float *__restrict__ partial, int kp, float thresh) {
+    constexpr int GPB = 256 / LPN;
+    const int li = threadIdx.x % LPN;
+    const int gid = threadIdx.x / LPN;
+    for (i64 it = (i64)blockIdx.x * GPB + gid; it < n_items; it += (i64)gridDim.x * GPB) {
+        const int w = item_col[it];
+        const int j0 = item_start[it];
+        const int j1 = min(j0 + seg, colptr[w + 1]);
+        float4 vt[CH], acc[CH];
+        if (!FROM_P) load_chunks<LPN, CH>(Vt + (i64)w * kp, li, kp, vt);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int jb = j0; jb < j1; jb += LPN) {
+            const int jm = jb + li;
+            const int d_l = jm < j1 ? csc_row[jm] : 0;
+            const float x_l = jm < j1 ? csc_val[jm] : 0.f;
+            const int p_l = (FROM_P && jm < j1) ? csc_pos[jm] : 0;
+            const int cnt = min(LPN, j1 - jb);
+            for (int s = 0; s < cnt; ++s) {
+                const int d = __shfl(d_l, s, LPN);
+                float x = __shfl(x_l, s, LPN);
+                float4 pz[CH];
+                if (FROM_P) {
+                    const int pos = __shfl(p_l, s, LPN);
+                    load_chunks<LPN, CH>(P + (i64)pos * kp, li, kp, pz);
+                } else {
+                    float4 u[CH];
+                    float unth;
+                    load_chunks<LPN, CH>(U + (i64)d * kp, li, kp, u);
+                    const float norm = group_sum<LPN>(products<CH, false>(u, vt, thresh, pz, unth));
+                    const float inv = norm > 0.f ? 1.0f / norm : 0.f;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        pz[j].x *= inv; pz[j].y *= inv; pz[j].z *= inv; pz[j].w *= inv;
+                    }
+                }
+                const float swd = sw ? sw[d] : 1.0f;  // x1.0f is exact: one path for plsa.py:188 and :293
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    float4 sv;
+                    sv.x = x * pz[j].x; sv.y = x * pz[j].y; sv.z = x * pz[j].z; sv.w = x * pz[j].w;
+                    sv.x *= swd; sv.y *= swd; sv.z *= swd; sv.w *= swd;
+                    acc[j].x += sv.x; acc[j].y += sv.y; acc[j].z += sv.z; acc[j].w += sv.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int c4 = 4 * (li + LPN * j);
+            if (c4 < kp) st4(partial + it * kp + c4, acc[j]);
+        }
+    }
+}
+
+// adds the item partials of each column (fixed order) into the un-normalised Vt_new.
+template <int LPN, int CH>
+__global__ __launch_bounds__(256) void k_col_reduce(const int *__restrict__ item_first, int m,
+                                                    const float *__restrict__ partial,
+                                                    float *__restrict__ Vt_new, int kp) {
+    constexpr int GPB = 256 / LPN;
+    const int li = threadIdx.x % LPN;
+    const int gid = threadIdx.x / LPN;
+    for (i64 c = (i64)blockIdx.x * GPB + gid; c < m; c += (i64)gridDim.x * GPB) {
+        const int i0 = item_first[c], i1 = item_first[c + 1];
+        float4 acc[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int it = i0; it < i1; ++it) {
+            float4 p[CH];
+            load_chunks<LPN, CH>(partial + (i64)it * kp, li, kp, p);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                acc[j].x += p[j].x; acc[j].y += p[j].y; acc[j].z += p[j].z; acc[j].w += p[j].w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int c4 = 4 * (li + LPN * j);
+            if (c4 < kp) st4(Vt_new + c * kp + c4, acc[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// P(w|z) normalisation, plsa.py:196-199: norm_pwz[z] = sum_w Vt_new[w,z], then divide.
+//   k_colsum_partial : NORM_BLOCKS blocks, each sums a contiguous slab of words -> partials (f64)
+//   k_v_normalise    : every block re-adds the NORM_BLOCKS partials (fixed order) into LDS, divides
+//                      its slab, writes the normalised topics into Vt and (optionally) re-zeroes
+//                      the accumulator for the next atomic pass.
+// ------------------------------------------------------------------------------------------------
+constexpr int NORM_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ Vt_new, int m,
+                                                        int kp, double *__restrict__ partials) {
+    // thread t owns column z = t % kp for rows t / kp, t / kp + rows_per_pass, ...  (kp <= 256)
+    // for kp > 256 the thread loops over z as well.
+    extern __shared__ double sred[];  // [256]
+    const i64 per = ((i64)m + gridDim.x - 1) / gridDim.x;
+    const i64 w0 = (i64)blockIdx.x * per, w1 = min((i64)m, w0 + per);
+    for (int zb = 0; zb < kp; zb += 256) {
+        const int span = min(256, kp - zb);          // columns handled in this sweep
+        const int rpp = 256 / span;                  // rows per pass
+        const int z = zb + (int)threadIdx.x % span;
+        const int ro = (int)threadIdx.x / span;
+        float s = 0.f;
+        if (ro < rpp)
+            for (i64 w = w0 + ro; w < w1; w += rpp) s += Vt_new[w * kp + z];
+        sred[threadIdx.x] = (ro < rpp) ? (double)s : 0.0;
+        __syncthreads();
+        if ((int)threadIdx.x < span) {
+            double tot = 0.0;
+            for (int r = 0; r < rpp; ++r) tot += sred[r * span + threadIdx.x];
+            partials[(i64)blockIdx.x * kp + zb + threadIdx.x] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_v_normalise(float *__restrict__ Vt_new,
+                                                     float *__restrict__ Vt, int m, int kp,
+                                                     const double *__restrict__ partials,
+                                                     int n_partials, float *__restrict__ norm_pwz,
+                                                     int rezero) {
+    extern __shared__ float snorm[];  // [kp]
+    for (int z = threadIdx.x; z < kp; z += 256) {
+        double tot = 0.0;
+        for (int b = 0; b < n_partials; ++b) tot += partials[(i64)b * kp + z];
+        snorm[z] = (float)tot;
+        if (blockIdx.x == 0 && norm_pwz) norm_pwz[z] = (float)tot;
+    }
+    __syncthreads();
+    const i64 total4 = (i64)m * kp / 4;
+    const int kq = kp / 4;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total4; i += (i64)gridDim.x * 256) {
+        const int z4 = (int)(i % kq) * 4;
+        float4 v = ld4(Vt_new + i * 4);
+        const float n0 = snorm[z4], n1 = snorm[z4 + 1], n2 = snorm[z4 + 2], n3 = snorm[z4 + 3];
+        if (n0 > 0.f) v.x /= n0;
+        if (n1 > 0.f) v.y /= n1;
+        if (n2 > 0.f) v.z /= n2;
+        if (n3 > 0.f) v.w /= n3;
+        st4(Vt + i * 4, v);
+        if (rezero) st4(Vt_new + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
+// final, fixed-order sum of the per-block log-likelihood partials
+__global__ void k_ll_final(const double *__restrict__ partials, int nb, double *__restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// standalone log-likelihood, plsa.py:375-384 (row-owned; same traversal as k_row_pass)
+template <int LPN, int CH>
+__global__ __launch_bounds__(256) void k_loglik(const int *__restrict__ indptr,
+                                                const int *__restrict__ colidx,
+                                                const float *__restrict__ vals, int n,
+                                                const float *__restrict__ U,
+                                                const float *__restrict__ Vt,
+                                                const float *__restrict__ sw, int kp,
+                                                double *__restrict__ ll_partials) {
+    constexpr int GPB = 256 / LPN;
+    const int li = threadIdx.x % LPN;
+    const int gid = threadIdx.x / LPN;
+    double ll = 0.0;
+    for (i64 r = (i64)blockIdx.x * GPB + gid; r < n; r += (i64)gridDim.x * GPB) {
+        const int d = (int)r;
+        const int j0 = indptr[d], j1 = indptr[d + 1];
+        float4 u[CH];
+        load_chunks<LPN, CH>(U + (i64)d * kp, li, kp, u);
+        const float swd = sw ? sw[d] : 1.0f;  // x1.0f is exact: one path for plsa.py:188 and :293
+        for (int jb = j0; jb < j1; jb += LPN) {
+            const int jm = jb + li;
+            const int w_l = jm < j1 ? colidx[jm] : 0;
+            const float x_l = jm < j1 ? vals[jm] : 0.f;
+            const int cnt = min(LPN, j1 - jb);
+            for (int s = 0; s < cnt; ++s) {
+                const int w = __shfl(w_l, s, LPN);
+                const float x = __shfl(x_l, s, LPN);
+                float4 vt[CH];
+                load_chunks<LPN, CH>(Vt + (i64)w * kp, li, kp, vt);
+                float part = 0.f;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    part += (vt[j].x * u[j].x + vt[j].y * u[j].y) + (vt[j].z * u[j].z + vt[j].w * u[j].w);
+                }
+                const float dot = group_sum<LPN>(part);
+                if (li == 0) ll += (double)(x * logf(dot) * swd);
+            }
+        }
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = ll;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ll_partials[blockIdx.x] = red[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout / corpus utility kernels
+// ------------------------------------------------------------------------------------------------
+// rowidx[j] = d for j in [indptr[d], indptr[d+1])  (COO row ids of the nnz-parallel E-step)
+__global__ void k_expand_rows(const int *__restrict__ indptr, int n, int *__restrict__ rowidx) {
+    const int lane = threadIdx.x & 63;
+    const i64 wid = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const i64 nw = ((i64)gridDim.x * blockDim.x) >> 6;
+    for (i64 d = wid; d < n; d += nw) {
+        const int j0 = indptr[d], j1 = indptr[d + 1];
+        for (int j = j0 + lane; j < j1; j += 64) rowidx[j] = (int)d;
+    }
+}
+
+// V [k,m] (reference layout) -> Vt [m,kp] (device layout), 32x32 tiles through LDS
+__global__ void k_v_to_vt(const float *__restrict__ V, float *__restrict__ Vt, int k, int m, int kp) {
+    __shared__ float tile[32][33];
+    const int w0 = blockIdx.x * 32, z0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty = 0..7
+    for (int r = ty; r < 32; r += 8) {
+        const int z = z0 + r, w = w0 + tx;
+        tile[r][tx] = (z < k && w < m) ? V[(i64)z * m + w] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int w = w0 + r, z = z0 + tx;
+        if (w < m && z < kp) Vt[(i64)w * kp + z] = tile[tx][r];
+    }
+}
+
+__global__ void k_vt_to_v(const float *__restrict__ Vt, float *__restrict__ V, int k, int m, int kp) {
+    __shared__ float tile[32][33];
+    const int w0 = blockIdx.x * 32, z0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int w = w0 + r, z = z0 + tx;
+        tile[r][tx] = (w < m && z < kp) ? Vt[(i64)w * kp + z] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int z = z0 + r, w = w0 + tx;
+        if (z < k && w < m) V[(i64)z * m + w] = tile[tx][r];
+    }
+}
+
+// bootstrap (enstop_.py:87-88): out row i := base row idx[i]
+__global__ void k_boot_lengths(const int *__restrict__ base_indptr, const i64 *__restrict__ idx,
+                               i64 n_out, i64 n_base, int *__restrict__ lens, int *__restrict__ bad) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_out) {
+        const i64 r = idx[i];
+        if (r < 0 || r >= n_base) { lens[i] = 0; atomicOr(bad, 1); }
+        else lens[i] = base_indptr[r + 1] - base_indptr[r];
+    }
+}
+
+__global__ void k_boot_gather(const int *__restrict__ base_indptr, const int *__restrict__ base_col,
+                              const float *__restrict__ base_val, const i64 *__restrict__ idx,
+                              i64 n_out, const i64 *__restrict__ out_ptr64,
+                              int *__restrict__ out_indptr, int *__restrict__ out_col,
+                              float *__restrict__ out_val) {
+    const int lane = threadIdx.x & 63;
+    const i64 wid = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const i64 nw = ((i64)gridDim.x * blockDim.x) >> 6;
+    for (i64 i = wid; i <= n_out; i += nw) {
+        if (lane == 0) out_indptr[i] = (int)out_ptr64[i];
+        if (i == n_out) break;
+        const i64 r = idx[i];
+        const int s0 = base_indptr[r], len = base_indptr[r + 1] - s0;
+        const i64 o0 = out_ptr64[i];
+        for (int j = lane; j < len; j += 64) {
+            out_col[o0 + j] = base_col[s0 + j];
+            out_val[o0 + j] = base_val[s0 + j];
+        }
+    }
+}
+
+// CSC construction helpers
+__global__ void k_iota(int *__restrict__ a, i64 nn) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += (i64)gridDim.x * blockDim.x)
+        a[i] = (int)i;
+}
+__global__ void k_col_count(const int *__restrict__ colidx, i64 nnz, int *__restrict__ counts) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (i64)gridDim.x * blockDim.x)
+        atomicAdd(counts + colidx[i], 1);
+}
+__global__ void k_csc_gather(const int *__restrict__ pos, const int *__restrict__ rowidx,
+                             const float *__restrict__ vals, i64 nnz, int *__restrict__ csc_row,
+                             float *__restrict__ csc_val) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (i64)gridDim.x * blockDim.x) {
+        const int p = pos[i];
+        csc_row[i] = rowidx[p];
+        csc_val[i] = vals[p];
+    }
+}
+__global__ void k_item_counts(const int *__restrict__ colptr, int m, int seg, int *__restrict__ cnt) {
+    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m) cnt[c] = (colptr[c + 1] - colptr[c] + seg - 1) / seg;
+}
+__global__ void k_item_fill(const int *__restrict__ colptr, const int *__restrict__ item_first, int m,
+                            int seg, int *__restrict__ item_col, int *__restrict__ item_start) {
+    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m) {
+        const int i0 = item_first[c], i1 = item_first[c + 1];
+        for (int i = i0; i < i1; ++i) {
+            item_col[i] = (int)c;
+            item_start[i] = colptr[c] + (i - i0) * seg;
+        }
+    }
+}
+
+__global__ void k_fill_zero4(float *__restrict__ p, i64 n4) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (i64)gridDim.x * blockDim.x)
+        st4(p + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+}  // namespace plsa

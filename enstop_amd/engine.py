@@ -1,0 +1,235 @@
+"""Engine: one MI355X + one HIP stream + the device-resident corpus and factors.
+
+Thin object wrapper over the C ABI (include/plsa_hip.h); every method is one or two ABI calls.
+The reference keeps all of this state in NumPy arrays handed from function to function
+(enstop/plsa.py:707-730); here it lives in HBM for the lifetime of the Engine.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import PLSA_DETERMINISTIC, PLSA_FUSED, PLSA_TRACE_LL, ptr
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+def default_device():
+    """One process per GPU: LOCAL_RANK (torchrun) selects the device unless overridden."""
+    return int(os.environ.get("ENSTOP_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def default_flags():
+    """Fit schedule: fused (no nnz x k materialisation) unless ENSTOP_AMD_MATERIALISE=1;
+    atomic-free column-owned P(w|z) update when ENSTOP_AMD_DETERMINISTIC=1."""
+    flags = 0 if os.environ.get("ENSTOP_AMD_MATERIALISE", "0") == "1" else PLSA_FUSED
+    if os.environ.get("ENSTOP_AMD_DETERMINISTIC", "0") == "1":
+        flags |= PLSA_DETERMINISTIC
+    return flags
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Engine:
+    def __init__(self, device=None):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        dev = default_device() if device is None else int(device)
+        if self._L.plsa_create(dev, C.byref(self._h)):
+            raise DeviceError(self._L.plsa_last_error(None).decode())
+        self.device = dev
+        self.k = 0
+        self.base_rows = 0
+
+    # -- lifetime --------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.plsa_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ok(self, rc):
+        if rc:
+            raise DeviceError(self._L.plsa_last_error(self._h).decode())
+
+    def synchronize(self):
+        self._ok(self._L.plsa_synchronize(self._h))
+
+    def device_info(self):
+        name, arch = C.create_string_buffer(64), C.create_string_buffer(64)
+        cus, hbm = C.c_int(0), C.c_int64(0)
+        self._ok(self._L.plsa_device_info(self._h, name, arch, C.byref(cus), C.byref(hbm)))
+        return dict(name=name.value.decode(), arch=arch.value.decode(), cus=cus.value, hbm_bytes=hbm.value)
+
+    # -- corpus ----------------------------------------------------------------------------------
+    def upload_csr(self, X):
+        """X: scipy CSR (any dtype; values are cast to float32 like plsa.py:714)."""
+        X = X.tocsr()
+        n, m = X.shape
+        indptr = np.ascontiguousarray(X.indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(X.indices, dtype=np.int32)
+        data = _f32(X.data)
+        if indices.size and (indices.min() < 0 or indices.max() >= m):
+            raise ValueError("column index out of range")
+        self._ok(self._L.plsa_upload_csr(self._h, indptr, indices, data, n, m, data.shape[0]))
+        self.base_rows = n
+        return self
+
+    def generate_synthetic(self, n, m, nnz, zipf_s=1.07, seed=0):
+        out = C.c_int64(0)
+        self._ok(self._L.plsa_generate_synthetic(self._h, n, m, nnz, float(zipf_s), int(seed), C.byref(out)))
+        self.base_rows = n
+        return out.value
+
+    def bootstrap(self, idx):
+        """active := base[idx] on the device (enstop_.py:87-88); idx=None restores the base."""
+        if idx is None:
+            self._ok(self._L.plsa_bootstrap(self._h, None, 0))
+        else:
+            idx = np.ascontiguousarray(idx, dtype=np.int64)
+            self._ok(self._L.plsa_bootstrap(self._h, idx.ctypes.data, idx.shape[0]))
+        return self
+
+    @property
+    def shape(self):
+        n, m, nnz = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._ok(self._L.plsa_active_shape(self._h, C.byref(n), C.byref(m), C.byref(nnz)))
+        return n.value, m.value, nnz.value
+
+    def download_active_csr(self):
+        import scipy.sparse as sp
+        n, m, nnz = self.shape
+        indptr = np.empty(n + 1, np.int32)
+        indices = np.empty(max(nnz, 1), np.int32)
+        data = np.empty(max(nnz, 1), np.float32)
+        self._ok(self._L.plsa_download_active_csr(self._h, indptr, indices, data))
+        return sp.csr_matrix((data[:nnz], indices[:nnz], indptr), shape=(n, m))
+
+    # -- factors ---------------------------------------------------------------------------------
+    def set_factors(self, p_z_given_d, p_w_given_z=None):
+        U = _f32(p_z_given_d)
+        n, k = U.shape
+        _, m, _ = self.shape
+        V = None
+        if p_w_given_z is not None:
+            V = _f32(p_w_given_z)
+            if V.shape != (k, m):
+                raise ValueError("p_w_given_z has shape %s, expected %s" % (V.shape, (k, m)))
+        self._ok(self._L.plsa_set_factors(self._h, ptr(U), ptr(V), n, m, k))
+        self.k = k
+        return self
+
+    def get_factors(self, want_u=True, want_v=True):
+        n, m, _ = self.shape
+        U = np.empty((n, self.k), np.float32) if want_u else None
+        V = np.empty((self.k, m), np.float32) if want_v else None
+        self._ok(self._L.plsa_get_factors(self._h, ptr(U), ptr(V)))
+        return U, V
+
+    def copy_components_to_device(self, device_ptr):
+        self._ok(self._L.plsa_copy_components_to_device(self._h, int(device_ptr)))
+
+    # -- kernel-level operators --------------------------------------------------------------------
+    def e_step(self, thresh=1e-32, out=None, want_host_copy=True):
+        _, _, nnz = self.shape
+        if want_host_copy and out is None:
+            out = np.empty((nnz, self.k), np.float32)
+        self._ok(self._L.plsa_e_step(self._h, np.float32(thresh), ptr(out) if want_host_copy else None))
+        return out
+
+    def set_p(self, P):
+        self._ok(self._L.plsa_set_p(self._h, _f32(P)))
+
+    def m_step(self, sample_weight=None, update_v=True, deterministic=False):
+        n, _, _ = self.shape
+        sw = None if sample_weight is None else _f32(sample_weight)
+        npwz = np.zeros(self.k, np.float32)
+        npdz = np.zeros(n, np.float32)
+        self._ok(self._L.plsa_m_step(self._h, ptr(sw), int(update_v), int(deterministic), ptr(npwz), ptr(npdz)))
+        return npwz, npdz
+
+    def log_likelihood(self, sample_weight=None):
+        sw = None if sample_weight is None else _f32(sample_weight)
+        out = C.c_double(0.0)
+        self._ok(self._L.plsa_log_likelihood(self._h, ptr(sw), C.byref(out)))
+        return out.value
+
+    # -- EM drivers --------------------------------------------------------------------------------
+    def _drive(self, fn, sample_weight, n_iter, n_iter_per_test, tolerance, thresh, flags, trace):
+        sw = None if sample_weight is None else _f32(sample_weight)
+        ll = np.zeros(n_iter + 2, np.float32)
+        iters, nll = C.c_int32(0), C.c_int32(0)
+        if trace:
+            flags |= PLSA_TRACE_LL
+        self._ok(fn(self._h, ptr(sw), int(n_iter), int(n_iter_per_test), float(tolerance),
+                    np.float32(thresh), int(flags), C.byref(iters), ll.ctypes.data, C.byref(nll)))
+        return iters.value, ll[: nll.value].copy()
+
+    def fit(self, sample_weight=None, n_iter=100, n_iter_per_test=10, tolerance=0.001,
+            e_step_thresh=1e-32, flags=None, trace=False):
+        flags = default_flags() if flags is None else flags
+        return self._drive(self._L.plsa_fit, sample_weight, n_iter, n_iter_per_test, tolerance,
+                           e_step_thresh, flags, trace)
+
+    def refit(self, sample_weight=None, n_iter=50, n_iter_per_test=10, tolerance=0.005,
+              e_step_thresh=1e-32, flags=None, trace=False):
+        flags = default_flags() if flags is None else flags
+        return self._drive(self._L.plsa_refit, sample_weight, n_iter, n_iter_per_test, tolerance,
+                           e_step_thresh, flags, trace)
+
+    # -- measurement ---------------------------------------------------------------------------------
+    def timing(self, on=True):
+        self._ok(self._L.plsa_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        self._ok(self._L.plsa_timing_reset(self._h))
+
+    def timing_get(self, prefix):
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        self._ok(self._L.plsa_timing_get(self._h, prefix.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def timing_report(self):
+        buf = C.create_string_buffer(8192)
+        self._ok(self._L.plsa_timing_report(self._h, buf, 8192))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.rsplit(" ", 2)
+            out[name] = (int(cnt), float(ms))
+        return out
+
+
+_engines = {}
+
+
+def get_engine(device=None):
+    """Process-wide Engine per device (buffers are reused across fits)."""
+    dev = default_device() if device is None else int(device)
+    eng = _engines.get(dev)
+    if eng is None:
+        eng = _engines[dev] = Engine(dev)
+    return eng
+
+
+def host_normalize_rows(a):
+    """enstop/utils.py:8-41 normalize(a, axis=1), in place on a C-contiguous float64 array."""
+    L = _lib.load()
+    assert a.dtype == np.float64 and a.flags.c_contiguous and a.ndim == 2
+    L.plsa_host_normalize_rows(a, a.shape[0], a.shape[1])
+    return a

@@ -1,0 +1,97 @@
+"""Ensemble of bootstrapped pLSA fits on MI355X behind the reference's interface
+(enstop/enstop_.py:56-115 plsa_topics, :164-231 ensemble_of_topics).
+
+The reference fans the members out over dask/joblib *threads* of one process.  Here a member is one
+fit on one GPU: within a process the members assigned to it run back to back on its device (the
+corpus is uploaded once, each bootstrap resample is a device-side row gather); across GPUs the
+launcher starts one process per device (torchrun) and the topic matrices are all-gathered over RCCL
+(`distributed.gather_topics`).  Members are dealt round-robin, run r -> rank r mod world_size, and
+each member draws from its own RandomState stream so the stack does not depend on the device count.
+"""
+import numpy as np
+from scipy.sparse import issparse, csr_matrix
+from sklearn.utils import check_random_state
+
+from .engine import get_engine
+from .plsa import _fit_on_engine
+
+
+def _member_on_engine(eng, k, bootstrap=True, random_state=None, init="random", n_iter=100,
+                      n_iter_per_test=10, tolerance=0.001, e_step_thresh=1e-16, flags=None):
+    """One ensemble member on a corpus already uploaded to `eng`; returns P(w|z) [k, m]."""
+    n_base = eng.base_rows
+    if bootstrap:
+        rng = check_random_state(random_state)                       # enstop_.py:86
+        idx = rng.randint(0, n_base, size=n_base)                    # enstop_.py:87
+        eng.bootstrap(idx)                                           # enstop_.py:88 (on device)
+    else:
+        eng.bootstrap(None)
+    # sample_weight is all ones (enstop_.py:91); random_state is passed on unchanged, so a
+    # RandomState instance continues its stream into the factor initialisation while an int
+    # re-seeds it (enstop_.py:101,113 + plsa.py:707)
+    _fit_on_engine(eng, k, None, init, n_iter, n_iter_per_test, tolerance, e_step_thresh,
+                   random_state, flags)
+    _, V = eng.get_factors(want_u=False)
+    return V
+
+
+def plsa_topics(X, k, **kwargs):
+    """Bootstrap-resample the documents of X and fit pLSA; returns the (k, n_words) topic matrix.
+    Keyword arguments as the reference: bootstrap, random_state, init, n_iter, n_iter_per_test,
+    tolerance, e_step_thresh (default 1e-16 here, enstop_.py:99,111); plus device, flags."""
+    A = X.tocsr() if issparse(X) else csr_matrix(X)
+    eng = get_engine(kwargs.get("device", None))
+    eng.upload_csr(A)
+    return _member_on_engine(
+        eng, k, bootstrap=kwargs.get("bootstrap", True), random_state=kwargs.get("random_state", None),
+        init=kwargs.get("init", "random"), n_iter=kwargs.get("n_iter", 100),
+        n_iter_per_test=kwargs.get("n_iter_per_test", 10), tolerance=kwargs.get("tolerance", 0.001),
+        e_step_thresh=kwargs.get("e_step_thresh", 1e-16), flags=kwargs.get("flags", None))
+
+
+def ensemble_of_topics(X, k, model="plsa", n_jobs=4, n_runs=16, parallelism="dask", **kwargs):
+    """All topics of `n_runs` bootstrapped fits stacked to (n_runs * k, n_words), enstop_.py:164-231.
+
+    `parallelism`:
+      "none"            members run serially on this process' GPU sharing `random_state` exactly
+                        like the reference's serial branch (enstop_.py:220-223).
+      "dask" / "joblib" accepted for drop-in compatibility; the thread fan-out they name is
+                        replaced by the one-GPU-per-process model: with torch.distributed
+                        initialised (torchrun) run r executes on rank r % world_size and the stack
+                        is all-gathered over RCCL; in a single process it degenerates to a serial
+                        loop on one GPU.  `n_jobs` is ignored (a GPU runs one fit at a time).
+    Per-run streams: with an int (or None) `random_state` run r uses seed `random_state + r`
+    (reference: every thread re-seeds with the same int, producing identical members,
+    enstop_.py:86 -- a documented defect, not reproduced).
+    """
+    if model != "plsa":
+        raise ValueError('Only model="plsa" is implemented on this engine')
+    if parallelism not in ("dask", "joblib", "none"):
+        raise ValueError("Unrecognized parallelism {}; should be one of {}".format(
+            parallelism, ("dask", "joblib", "none")))
+    A = X.tocsr() if issparse(X) else csr_matrix(X)
+    eng = get_engine(kwargs.get("device", None))
+    eng.upload_csr(A)
+    member_kw = dict(bootstrap=kwargs.get("bootstrap", True), init=kwargs.get("init", "random"),
+                     n_iter=kwargs.get("n_iter", 100), n_iter_per_test=kwargs.get("n_iter_per_test", 10),
+                     tolerance=kwargs.get("tolerance", 0.001),
+                     e_step_thresh=kwargs.get("e_step_thresh", 1e-16), flags=kwargs.get("flags", None))
+    random_state = kwargs.get("random_state", None)
+
+    if parallelism == "none":
+        topics = [_member_on_engine(eng, k, random_state=random_state, **member_kw) for _ in range(n_runs)]
+        return np.vstack(topics)
+
+    from . import distributed
+    rank, world = distributed.rank_world()
+    if isinstance(random_state, np.random.RandomState):
+        # one shared stream cannot be split deterministically across processes: derive per-run seeds
+        base_seed = int(random_state.randint(0, 2 ** 31 - 1))
+    elif random_state is None:
+        base_seed = int(np.random.randint(0, 2 ** 31 - 1)) if world == 1 else distributed.broadcast_seed()
+    else:
+        base_seed = int(random_state)
+    mine = {}
+    for r in range(rank, n_runs, world):
+        mine[r] = _member_on_engine(eng, k, random_state=np.random.RandomState(base_seed + r), **member_kw)
+    return distributed.gather_topics(mine, n_runs, k, A.shape[1], eng)

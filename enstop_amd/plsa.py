@@ -1,0 +1,315 @@
+"""pLSA on MI355X behind the reference's own interface (enstop/plsa.py).
+
+Same function names, argument order, defaults and return conventions as the reference module, so
+existing callers switch by changing the import.  All numerical work runs in hand-written HIP
+kernels through the C ABI (include/plsa_hip.h); there is no CPU code path -- importing works
+anywhere, calling anything needs libplsa_hip.so and a gfx950 device.
+
+  reference function (enstop/plsa.py)        here
+  plsa_e_step                  :39          plsa_e_step            -> plsa_e_step (C ABI)
+  plsa_m_step                  :124         plsa_m_step            -> plsa_m_step(sw=NULL)
+  plsa_m_step_w_sample_weight  :221         plsa_m_step_w_sample_weight -> plsa_m_step(sw)
+  log_likelihood               :329         log_likelihood         -> plsa_log_likelihood
+  plsa_init                    :412         plsa_init (host NumPy, like the reference)
+  plsa_fit_inner / plsa_fit    :517 / :643  plsa_fit_inner / plsa_fit -> plsa_fit (C ABI)
+  plsa_refit_m_step            :746         plsa_refit_m_step      -> plsa_m_step(update_v=0)
+  plsa_refit_inner / plsa_refit :820 / :923 plsa_refit_inner / plsa_refit -> plsa_refit (C ABI)
+  PLSA                         :1000        PLSA
+"""
+import numpy as np
+from scipy.sparse import coo_matrix, csr_matrix, issparse
+from sklearn.base import BaseEstimator, TransformerMixin
+from sklearn.utils import check_array, check_random_state
+
+from .engine import Engine, get_engine
+from .utils import _check_sample_weight, normalize, standardize_input
+
+
+# ------------------------------------------------------------------------------------------------
+# COO triplets (the reference kernels' argument form) -> CSR on the device
+# ------------------------------------------------------------------------------------------------
+def _coo_to_csr(X_rows, X_cols, X_vals, n, m):
+    """Returns (csr, order): `order` is None when the triplets are already row-major sorted (what
+    X.tocoo() of a canonical CSR gives, plsa.py:714), else the stable permutation applied."""
+    rows = np.asarray(X_rows)
+    order = None
+    if rows.size > 1 and np.any(rows[1:] < rows[:-1]):
+        order = np.argsort(rows, kind="stable")
+        rows = rows[order]
+        X_cols = np.asarray(X_cols)[order]
+        X_vals = np.asarray(X_vals)[order]
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(indptr, rows.astype(np.int64) + 1, 1)
+    indptr = np.cumsum(indptr).astype(np.int32)
+    csr = csr_matrix((np.asarray(X_vals, np.float32), np.asarray(X_cols, np.int32), indptr), shape=(n, m))
+    return csr, order
+
+
+def _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device=None):
+    k, m = p_w_given_z.shape
+    n = p_z_given_d.shape[0]
+    csr, order = _coo_to_csr(X_rows, X_cols, X_vals, n, m)
+    eng = get_engine(device)
+    eng.upload_csr(csr)
+    eng.set_factors(p_z_given_d, p_w_given_z)
+    return eng, order
+
+
+def plsa_e_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd,
+                probability_threshold=1e-32, device=None):
+    """P(z|w,d) for every stored (d, w); fills and returns `p_z_given_wd` [nnz, k]."""
+    eng, order = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device)
+    P = eng.e_step(probability_threshold)
+    if order is None:
+        p_z_given_wd[...] = P
+    else:
+        p_z_given_wd[order] = P
+    return p_z_given_wd
+
+
+def _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, sample_weight,
+            norm_pwz, norm_pdz, update_v, device, deterministic):
+    eng, order = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device)
+    P = np.asarray(p_z_given_wd, np.float32)
+    eng.set_p(P if order is None else P[order])
+    npwz, npdz = eng.m_step(sample_weight, update_v=update_v, deterministic=deterministic)
+    U, V = eng.get_factors(want_v=update_v)
+    p_z_given_d[...] = U
+    if update_v:
+        p_w_given_z[...] = V
+        if norm_pwz is not None:
+            norm_pwz[...] = npwz
+    if norm_pdz is not None:
+        norm_pdz[...] = npdz
+    return p_w_given_z, p_z_given_d
+
+
+def plsa_m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, norm_pwz, norm_pdz,
+                device=None, deterministic=False):
+    """New P(w|z), P(z|d) from P(z|w,d); overwrites both factor arrays in place and returns them."""
+    return _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, None, norm_pwz,
+                   norm_pdz, True, device, deterministic)
+
+
+def plsa_m_step_w_sample_weight(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd,
+                                sample_weight, norm_pwz, norm_pdz, device=None, deterministic=False):
+    """As plsa_m_step with per-document weights entering P(w|z) only (plsa.py:293-300)."""
+    return _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, sample_weight,
+                   norm_pwz, norm_pdz, True, device, deterministic)
+
+
+def plsa_refit_m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, sample_weight,
+                      norm_pdz, device=None):
+    """M-step for P(z|d) only, topics frozen; `sample_weight` is accepted and unused exactly like
+    the reference (plsa.py:801-814)."""
+    return _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, None, None,
+                   norm_pdz, False, device, False)
+
+
+def log_likelihood(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, sample_weight, device=None):
+    """sum x * log(sum_z P(w|z) P(z|d)) * sample_weight[d], returned as float32 like the reference."""
+    eng, _ = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device)
+    return np.float32(eng.log_likelihood(sample_weight))
+
+
+# ------------------------------------------------------------------------------------------------
+# initialisation (host side, as in the reference)
+# ------------------------------------------------------------------------------------------------
+def plsa_init(X, k, init="random", rng=np.random):
+    """Initial (P(z|d), P(w|z)) as float64, rows L1-normalised (plsa.py:412-513).
+
+    "random" draws `rng.rand(k, m)` first and `rng.rand(n, k)` second -- the order matters for
+    seed-for-seed agreement with the reference (plsa.py:455-456)."""
+    n, m = X.shape
+    if isinstance(init, str) and init == "random":
+        p_w_given_z = rng.rand(k, m)
+        p_z_given_d = rng.rand(n, k)
+    elif isinstance(init, str) and init == "nndsvd":
+        from sklearn.decomposition._nmf import _initialize_nmf
+        W, H = _initialize_nmf(X, k, init="nndsvd")
+        p_z_given_d, p_w_given_z = np.array(W, np.float64, order="C"), np.array(H, np.float64, order="C")
+    elif isinstance(init, str) and init == "nmf":
+        from sklearn.decomposition import non_negative_factorization
+        W, H, _ = non_negative_factorization(X, n_components=k, init="nndsvd", solver="cd",
+                                             beta_loss=2, tol=1e-2, max_iter=100)
+        p_z_given_d, p_w_given_z = np.array(W, np.float64, order="C"), np.array(H, np.float64, order="C")
+    elif isinstance(init, (tuple, list)):
+        p_z_given_d, p_w_given_z = init
+        p_z_given_d = np.array(p_z_given_d, dtype=np.float64, order="C")
+        p_w_given_z = np.array(p_w_given_z, dtype=np.float64, order="C")
+        if p_z_given_d.shape != (n, k) or p_w_given_z.shape != (k, m):
+            raise ValueError("init factors have shapes {} and {}, expected {} and {}".format(
+                p_z_given_d.shape, p_w_given_z.shape, (n, k), (k, m)))
+    else:
+        raise ValueError("Unrecognized init {}".format(init))
+    normalize(p_w_given_z, axis=1)
+    normalize(p_z_given_d, axis=1)
+    return p_z_given_d, p_w_given_z
+
+
+# ------------------------------------------------------------------------------------------------
+# EM drivers
+# ------------------------------------------------------------------------------------------------
+def plsa_fit_inner(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, sample_weight, n_iter=100,
+                   n_iter_per_test=10, tolerance=0.001, e_step_thresh=1e-32,
+                   use_sample_weights=False, device=None, flags=None):
+    """EM loop on COO triplets; factor arrays are updated in place and returned (plsa.py:517-640)."""
+    eng, _ = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device)
+    sw = np.asarray(sample_weight, np.float32)
+    # the weighted M-step only when requested; the log-likelihood always sees the weights
+    if not use_sample_weights and np.any(sw != 1.0):
+        raise ValueError("non-unit sample_weight with use_sample_weights=False is not supported")
+    eng.fit(sw if use_sample_weights else None, n_iter, n_iter_per_test, tolerance, e_step_thresh, flags)
+    U, V = eng.get_factors()
+    p_z_given_d[...] = U
+    p_w_given_z[...] = V
+    return p_z_given_d, p_w_given_z
+
+
+def _fit_on_engine(eng, k, sample_weight, init, n_iter, n_iter_per_test, tolerance, e_step_thresh,
+                   random_state, flags=None, trace=False, shape=None, X_for_init=None):
+    """plsa_fit's body for a corpus already resident on `eng` (shared with the ensemble member)."""
+    n, m, _ = eng.shape
+    rng = check_random_state(random_state)
+
+    class _Shape:                      # plsa_init only needs .shape for "random" / tuple inits
+        pass
+    Xs = X_for_init
+    if Xs is None:
+        Xs = _Shape()
+        Xs.shape = (n, m)
+    p_z_given_d, p_w_given_z = plsa_init(Xs, k, init=init, rng=rng)
+    p_z_given_d = p_z_given_d.astype(np.float32, order="C")
+    p_w_given_z = p_w_given_z.astype(np.float32, order="C")
+    sw = None
+    if sample_weight is not None and np.any(np.asarray(sample_weight) != 1.0):   # plsa.py:712
+        sw = np.asarray(sample_weight, np.float32)
+    eng.set_factors(p_z_given_d, p_w_given_z)
+    iters, ll = eng.fit(sw, n_iter, n_iter_per_test, tolerance, e_step_thresh, flags, trace=trace)
+    return iters, ll
+
+
+def plsa_fit(X, k, sample_weight, init="random", n_iter=100, n_iter_per_test=10, tolerance=0.001,
+             e_step_thresh=1e-32, random_state=None, device=None, flags=None, return_info=False):
+    """Fit pLSA with k topics to the sparse doc-term matrix X; returns (P(z|d) [n,k], P(w|z) [k,m]),
+    both float32 (plsa.py:643-730).  Extra keyword arguments select the device and the kernel
+    schedule (fused / materialised / deterministic); positional compatibility is unchanged."""
+    if not issparse(X):
+        X = csr_matrix(X)
+    eng = get_engine(device)
+    eng.upload_csr(X)
+    iters, ll = _fit_on_engine(eng, k, sample_weight, init, n_iter, n_iter_per_test, tolerance,
+                               e_step_thresh, random_state, flags, trace=return_info, X_for_init=X)
+    p_z_given_d, p_w_given_z = eng.get_factors()
+    if return_info:
+        return p_z_given_d, p_w_given_z, dict(n_iter=iters, log_likelihood_trace=ll)
+    return p_z_given_d, p_w_given_z
+
+
+def plsa_refit_inner(X_rows, X_cols, X_vals, topics, p_z_given_d, sample_weight, n_iter=50,
+                     n_iter_per_test=10, tolerance=0.005, e_step_thresh=1e-32, device=None, flags=None):
+    """EM on P(z|d) with the topics frozen (plsa.py:820-920); returns P(z|d)."""
+    eng, _ = _stage(X_rows, X_cols, X_vals, topics, p_z_given_d, device)
+    sw = np.asarray(sample_weight, np.float32)
+    eng.refit(None if not np.any(sw != 1.0) else sw, n_iter, n_iter_per_test, tolerance, e_step_thresh, flags)
+    U, _ = eng.get_factors(want_v=False)
+    p_z_given_d[...] = U
+    return p_z_given_d
+
+
+def plsa_refit(X, topics, sample_weight, n_iter=50, n_iter_per_test=10, tolerance=0.005,
+               e_step_thresh=1e-32, random_state=None, device=None, flags=None, return_info=False):
+    """Document vectors P(z|d) for X against fixed `topics` (plsa.py:923-997)."""
+    if not issparse(X):
+        X = csr_matrix(X)
+    topics = np.asarray(topics)
+    k = topics.shape[0]
+    rng = check_random_state(random_state)
+    p_z_given_d = rng.rand(X.shape[0], k)                    # plsa.py:979
+    normalize(p_z_given_d, axis=1)
+    p_z_given_d = p_z_given_d.astype(np.float32)
+    eng = get_engine(device)
+    eng.upload_csr(X)
+    eng.set_factors(p_z_given_d, topics.astype(np.float32))
+    sw = None
+    if sample_weight is not None and np.any(np.asarray(sample_weight) != 1.0):
+        sw = np.asarray(sample_weight, np.float32)
+    iters, ll = eng.refit(sw, n_iter, n_iter_per_test, tolerance, e_step_thresh, flags, trace=return_info)
+    U, _ = eng.get_factors(want_v=False)
+    if return_info:
+        return U, dict(n_iter=iters, log_likelihood_trace=ll)
+    return U
+
+
+# ------------------------------------------------------------------------------------------------
+# estimator
+# ------------------------------------------------------------------------------------------------
+class PLSA(BaseEstimator, TransformerMixin):
+    """Probabilistic Latent Semantic Analysis with the reference estimator's constructor, methods
+    and fitted attributes (enstop/plsa.py:1000-1285): `components_` = P(w|z) [k, m],
+    `embedding_` = P(z|d) [n, k], `training_data_`.  Additive: `n_iter_` (EM iterations run),
+    and the `device` / `deterministic` constructor keywords at the end of the signature.
+
+    Conscious deviations from reference defects: float input detection works on
+    current NumPy (the reference's `np.float` raises); `sample_weight` is restricted to the
+    non-empty rows together with the data (the reference leaves it misaligned, plsa.py:1144-1164).
+    """
+
+    def __init__(self, n_components=10, init="random", n_iter=100, n_iter_per_test=10,
+                 tolerance=0.001, e_step_thresh=1e-32, transform_random_seed=42, random_state=None,
+                 device=None, deterministic=False):
+        self.n_components = n_components
+        self.init = init
+        self.n_iter = n_iter
+        self.n_iter_per_test = n_iter_per_test
+        self.tolerance = tolerance
+        self.e_step_thresh = e_step_thresh
+        self.transform_random_seed = transform_random_seed
+        self.random_state = random_state
+        self.device = device
+        self.deterministic = deterministic
+
+    def _flags(self):
+        from .engine import PLSA_DETERMINISTIC, default_flags
+        return default_flags() | (PLSA_DETERMINISTIC if self.deterministic else 0)
+
+    def fit(self, X, y=None, sample_weight=None):
+        self.fit_transform(X, sample_weight=sample_weight)
+        return self
+
+    def fit_transform(self, X, y=None, sample_weight=None):
+        X = check_array(X, accept_sparse="csr")
+        X = standardize_input(X)
+        if not issparse(X):
+            X = csr_matrix(X)
+        sample_weight = _check_sample_weight(sample_weight, X, dtype=np.float32)
+        if np.any(X.data < 0):
+            raise ValueError("PLSA is only valid for matrices with non-negative entries")
+        row_sums = np.asarray(X.sum(axis=1)).ravel()
+        good_rows = row_sums != 0
+        all_good = bool(np.all(good_rows))
+        data_for_fitting = X if all_good else X[good_rows]
+        weights = sample_weight if all_good else sample_weight[good_rows]
+        U, V, info = plsa_fit(data_for_fitting, self.n_components, weights, self.init, self.n_iter,
+                              self.n_iter_per_test, self.tolerance, self.e_step_thresh,
+                              self.random_state, device=self.device, flags=self._flags(),
+                              return_info=True)
+        if all_good:
+            self.embedding_ = U
+        else:                                    # float64 zeros, like plsa.py:1174
+            self.embedding_ = np.zeros((X.shape[0], self.n_components))
+            self.embedding_[good_rows] = U
+        self.components_ = V
+        self.training_data_ = X
+        self.n_iter_ = info["n_iter"]
+        return self.embedding_
+
+    def transform(self, X, y=None):
+        X = check_array(X, accept_sparse="csr")
+        random_state = check_random_state(self.transform_random_seed)
+        sample_weight = _check_sample_weight(None, X, dtype=np.float32)
+        X = coo_matrix(X) if not issparse(X) else X.tocoo()
+        # plsa.py:1210-1218: fixed n_iter=50, n_iter_per_test=5, tolerance=0.001
+        return plsa_refit(X, self.components_, sample_weight, n_iter=50, n_iter_per_test=5,
+                          tolerance=0.001, random_state=random_state, device=self.device,
+                          flags=self._flags())

@@ -1,0 +1,133 @@
+/*
+ * plsa_hip.h -- C ABI of the MI355X-native pLSA EM engine (libplsa_hip.so).
+ *
+ * This is the drop-in boundary for the reference's pLSA hot path.  The reference (lmcinnes/enstop,
+ * pure Python + numba) has no FFI of its own; its operator boundary is the set of Python functions
+ * below, and its own accelerator plug point is the `plsa_fit` swap at enstop/enstop_.py:52-53,92-114.
+ * Each entry point names the reference interface it replaces (paths relative to the reference root).
+ * enstop_amd/_lib.py is the ctypes binding; INTEGRATION.md shows the stub a maintainer would add.
+ *
+ * Conventions
+ *   - Every function returns 0 on success and a non-zero status on failure; the message is available
+ *     from plsa_last_error().  No exception crosses this boundary.
+ *   - Host arrays are borrowed for the duration of the call only, C-contiguous, in the reference's
+ *     layouts: U = P(z|d) float32 [n,k]; V = P(w|z) float32 [k,m]; P = P(z|w,d) float32 [nnz,k];
+ *     CSR int32 indptr[n+1] / int32 indices[nnz] / float32 data[nnz].
+ *   - Device buffers are owned by the opaque context.  Internally V is held word-major ([m,kp],
+ *     kp = k rounded up to 4) so that one non-zero touches one contiguous k-vector of each factor.
+ *   - One context = one device + one HIP stream.  A context is not thread-safe; distinct contexts
+ *     are independent (one host thread or process per GPU, like the reference's nogil thread pool,
+ *     enstop/enstop_.py:209-217).
+ */
+#ifndef PLSA_HIP_H
+#define PLSA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plsa_ctx plsa_ctx;
+
+/* plsa_fit()/plsa_refit() `flags` */
+enum {
+    PLSA_FUSED         = 1, /* never materialise P(z|w,d) (idea of enstop/streamed_plsa.py:341-375) */
+    PLSA_DETERMINISTIC = 2, /* P(w|z) update by column ownership over a CSC copy: no float atomics,
+                               bit-reproducible run to run and across devices                      */
+    PLSA_TRACE_LL      = 4  /* also evaluate the log-likelihood test of the last iteration when it
+                               cannot change the result (only to fill ll_trace like plsa.py:631)    */
+};
+
+/* ---- lifetime / errors ----------------------------------------------------------------------- */
+int plsa_device_count(int *count);
+int plsa_create(int device, plsa_ctx **out);
+void plsa_destroy(plsa_ctx *ctx);
+/* ctx may be NULL: returns the last error of a failed plsa_create()/plsa_device_count(). */
+const char *plsa_last_error(const plsa_ctx *ctx);
+int plsa_synchronize(plsa_ctx *ctx);
+/* 64-char device name ("AMD Instinct MI355X"), gcnArchName, CU count and HBM bytes. */
+int plsa_device_info(plsa_ctx *ctx, char *name64, char *arch64, int *cus, int64_t *hbm_bytes);
+
+/* ---- corpus ------------------------------------------------------------------------------------
+ * plsa_upload_csr: the doc-term matrix X, replaces `A = X.tocoo().astype(np.float32)`
+ *   (enstop/plsa.py:714, 975).  The uploaded matrix becomes both the *base* corpus and the *active*
+ *   matrix the EM kernels iterate over.  indices must be < m, indptr non-decreasing.
+ * plsa_bootstrap: active := base[idx, :] gathered on the device; replaces
+ *   `B = A[bootstrap_sample_indices]` (enstop/enstop_.py:87-88).  idx == NULL restores active := base.
+ * plsa_active_shape / plsa_download_active_csr: read back the active matrix (tests).           */
+int plsa_upload_csr(plsa_ctx *ctx, const int32_t *indptr, const int32_t *indices, const float *data,
+                    int64_t n, int64_t m, int64_t nnz);
+int plsa_bootstrap(plsa_ctx *ctx, const int64_t *idx, int64_t n_out);
+int plsa_active_shape(plsa_ctx *ctx, int64_t *n, int64_t *m, int64_t *nnz);
+int plsa_download_active_csr(plsa_ctx *ctx, int32_t *indptr, int32_t *indices, float *data);
+
+/* ---- factors -----------------------------------------------------------------------------------
+ * plsa_set_factors: current estimates (p_z_given_d [n,k], p_w_given_z [k,m]) as produced by
+ *   plsa_init + the float32 casts (enstop/plsa.py:708-710) or a warm start.  n must equal the active
+ *   matrix' row count.  V may be NULL to keep the current topics (refit of new documents).
+ * plsa_get_factors: copy back in the reference's layouts; either pointer may be NULL.
+ * plsa_copy_components_to_device: D2D copy of P(w|z) as [k,m] float32 into caller-owned device
+ *   memory (e.g. a buffer handed to an RCCL all-gather: the np.vstack of enstop/enstop_.py:231).  */
+int plsa_set_factors(plsa_ctx *ctx, const float *U, const float *V, int64_t n, int64_t m, int32_t k);
+int plsa_get_factors(plsa_ctx *ctx, float *U, float *V);
+int plsa_copy_components_to_device(plsa_ctx *ctx, void *dst_device_km);
+
+/* ---- kernel-level operators ---------------------------------------------------------------------
+ * plsa_e_step           <- plsa_e_step                  enstop/plsa.py:39-107 (signature :26)
+ *   materialises P(z|w,d) [nnz,k] in HBM; P_out (nullable) receives a host copy.
+ * plsa_set_p            uploads a host P [nnz,k] (lets plsa_m_step be tested in isolation).
+ * plsa_m_step           <- plsa_m_step                  enstop/plsa.py:124-204 (sw == NULL)
+ *                       <- plsa_m_step_w_sample_weight  enstop/plsa.py:221-310 (sw != NULL)
+ *                       <- plsa_refit_m_step            enstop/plsa.py:746-816 (update_v == 0)
+ *   consumes the device-resident P; overwrites the factors; norms (nullable) receive norm_pwz[k]
+ *   and norm_pdz[n].  deterministic != 0 selects the column-owned (atomic-free) P(w|z) update.
+ * plsa_log_likelihood   <- log_likelihood               enstop/plsa.py:329-386
+ *   sw == NULL means all-ones.  Accumulated in float64 on the device; the reference returns float32
+ *   (callers cast).                                                                               */
+int plsa_e_step(plsa_ctx *ctx, float thresh, float *P_out);
+int plsa_set_p(plsa_ctx *ctx, const float *P);
+int plsa_m_step(plsa_ctx *ctx, const float *sw, int32_t update_v, int32_t deterministic,
+                float *norm_pwz, float *norm_pdz);
+int plsa_log_likelihood(plsa_ctx *ctx, const float *sw, double *ll);
+
+/* ---- EM drivers ---------------------------------------------------------------------------------
+ * plsa_fit   <- plsa_fit_inner   enstop/plsa.py:517-640   (and the cuda seam enstop/cuda_plsa.py:157)
+ * plsa_refit <- plsa_refit_inner enstop/plsa.py:820-920   (topics frozen, stop test as plsa.py:913)
+ *   sw: sample weights [n] or NULL (== all ones; the weighted M-step is used iff sw != NULL, the
+ *       caller applies `np.any(sample_weight != 1.0)`, enstop/plsa.py:712).
+ *   tolerance is float64, thresh float32, exactly as the reference's argument types.
+ *   iters_done  <- number of EM iterations the reference would have executed.
+ *   ll_trace    (nullable, capacity >= n_iter + 2) every log-likelihood evaluated, float32;
+ *   n_ll        (nullable) how many were written.                                                 */
+int plsa_fit(plsa_ctx *ctx, const float *sw, int32_t n_iter, int32_t n_iter_per_test,
+             double tolerance, float thresh, int32_t flags, int32_t *iters_done, float *ll_trace,
+             int32_t *n_ll);
+int plsa_refit(plsa_ctx *ctx, const float *sw, int32_t n_iter, int32_t n_iter_per_test,
+               double tolerance, float thresh, int32_t flags, int32_t *iters_done, float *ll_trace,
+               int32_t *n_ll);
+
+/* ---- measurement --------------------------------------------------------------------------------
+ * HIP events on the context's own stream around every kernel launch (bench.py roofline figures).  */
+int plsa_timing_enable(plsa_ctx *ctx, int32_t on);
+int plsa_timing_reset(plsa_ctx *ctx);
+/* total milliseconds and launch count of kernels whose name starts with `prefix`. */
+int plsa_timing_get(plsa_ctx *ctx, const char *prefix, double *total_ms, int64_t *launches);
+/* newline-separated "name launches total_ms" report into buf. */
+int plsa_timing_report(plsa_ctx *ctx, char *buf, int64_t cap);
+
+/* ---- host helper ---------------------------------------------------------------------------------
+ * plsa_host_normalize_rows <- enstop/utils.py:8-41 normalize(ndarray, axis=1): float64, in place,
+ *   sequential marginal, used by the factor initialisation (enstop/plsa.py:510-511, 980).          */
+void plsa_host_normalize_rows(double *a, int64_t rows, int64_t cols);
+
+/* synthetic bag-of-words CSR generated on the device (bench.py / large-size tests; not part of the
+ * reference): lognormal document lengths, Zipf(s) word ids, counts 1 + Poisson(0.5).  The result
+ * becomes base + active matrix.  nnz_target is approximate; the exact nnz is returned.            */
+int plsa_generate_synthetic(plsa_ctx *ctx, int64_t n, int64_t m, int64_t nnz_target, double zipf_s,
+                            uint64_t seed, int64_t *nnz_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLSA_HIP_H */

@@ -1,0 +1,130 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/plsa_hip.h declares, and the host-side logic (initialisation, COO->CSR staging, estimator
+validation, ensemble seeding) behaves like the reference.  No device computation here."""
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import ROOT, load_golden, golden_csr
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "plsa_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(plsa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from enstop_amd import _lib
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 24
+    for name in declared:
+        assert hasattr(lib, name), "libplsa_hip.so does not export %s" % name
+        assert name in _lib.SIGNATURES, "ctypes binding lacks %s" % name
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_library_has_gfx950_code_object():
+    data = open(os.path.join(ROOT, "enstop_amd", "libplsa_hip.so"), "rb").read()
+    assert b"gfx950" in data and b"k_e_step" in data and b"k_row_pass" in data
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a GPU the product must fail loudly, not compute on the host."""
+    from enstop_amd import _lib, plsa_fit
+    from enstop_amd.engine import DeviceError
+    import ctypes as C
+    cnt = C.c_int(0)
+    _lib.load().plsa_device_count(C.byref(cnt))
+    if cnt.value > 0:
+        pytest.skip("a HIP device is present")
+    X = sp.random(20, 30, density=0.2, format="csr", random_state=0)
+    with pytest.raises(DeviceError):
+        plsa_fit(X, 4, np.ones(20, np.float32), n_iter=2, random_state=0)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "enstop_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.lower(), "%s mentions the oracle" % f
+
+
+@pytest.mark.parametrize("case", ["fit_k8_tol0", "fit_k6_tupleinit", "fit_k20_50it"])
+def test_plsa_init_matches_reference(case):
+    """plsa_init + float32 casts (plsa.py:707-710) reproduce the reference's initial factors."""
+    from enstop_amd import plsa_init
+    g = load_golden(case)
+    X = golden_csr(g)
+    if "U_init" in g:
+        U, V = plsa_init(X, int(g["k"]), init=(g["U_init"], g["V_init"]))
+    else:
+        U, V = plsa_init(X, int(g["k"]), init="random", rng=np.random.RandomState(int(g["fit_seed"])))
+    assert U.dtype == np.float64 and V.dtype == np.float64
+    np.testing.assert_array_equal(U.astype(np.float32), g["U0"])
+    np.testing.assert_array_equal(V.astype(np.float32), g["V0"])
+
+
+def test_plsa_init_errors():
+    from enstop_amd import plsa_init
+    X = sp.random(5, 7, density=0.5, format="csr", random_state=0)
+    with pytest.raises(ValueError, match="Unrecognized init"):
+        plsa_init(X, 3, init="bogus")
+    with pytest.raises(ValueError):
+        plsa_init(X, 3, init=(np.ones((4, 3)), np.ones((3, 7))))
+
+
+def test_normalize_matches_oracle(oracle):
+    from enstop_amd.utils import normalize
+    rs = np.random.RandomState(3)
+    a = rs.rand(37, 53)
+    a[5] = 0.0
+    b = a.copy()
+    normalize(a, axis=1)
+    oracle.normalize(b, axis=1)
+    np.testing.assert_array_equal(a, b)
+    c = rs.rand(11, 9)
+    d = c.copy()
+    normalize(c, axis=0)
+    np.testing.assert_allclose(c.sum(axis=0), 1.0, rtol=1e-12)
+    np.testing.assert_allclose(c, d / d.sum(axis=0), rtol=1e-12)
+
+
+def test_coo_staging_sorted_and_unsorted():
+    from enstop_amd.plsa import _coo_to_csr
+    X = sp.random(30, 40, density=0.2, format="csr", random_state=1)
+    A = X.tocoo()
+    csr, order = _coo_to_csr(A.row, A.col, A.data, 30, 40)
+    assert order is None
+    assert (csr != X.astype(np.float32)).nnz == 0
+    perm = np.random.RandomState(0).permutation(A.nnz)
+    csr2, order2 = _coo_to_csr(A.row[perm], A.col[perm], A.data[perm], 30, 40)
+    assert order2 is not None
+    assert (csr2 != X.astype(np.float32)).nnz == 0
+    np.testing.assert_array_equal(A.row[perm][order2], np.sort(A.row))
+
+
+def test_estimator_validation_like_reference():
+    from enstop_amd import PLSA
+    X = np.abs(np.random.RandomState(0).randn(6, 5))
+    X[2, 3] = -1.0
+    with pytest.raises(ValueError, match="non-negative"):
+        PLSA(n_components=2).fit(sp.csr_matrix(X.astype(np.int64) * 0 + np.where(X < 0, -1, 1)))
+    params = PLSA().get_params()
+    for key, val in dict(n_components=10, init="random", n_iter=100, n_iter_per_test=10, tolerance=0.001,
+                         e_step_thresh=1e-32, transform_random_seed=42, random_state=None).items():
+        assert params[key] == val
+
+
+def test_standardize_input():
+    from enstop_amd.utils import standardize_input
+    Xi = sp.csr_matrix(np.arange(12).reshape(3, 4))
+    assert standardize_input(Xi) is Xi
+    Xf = sp.csr_matrix(np.arange(12, dtype=np.float64).reshape(3, 4) + 1)
+    np.testing.assert_allclose(np.asarray(standardize_input(Xf).sum(axis=1)).ravel(), 1.0)

@@ -1,0 +1,318 @@
+"""Parity of the HIP path (through the C ABI / the reference-shaped Python interface) against
+(1) the golden vectors produced by the reference itself and (2) the pinned CPU oracle on seeded
+inputs.  Needs a real MI355X: run with  pytest -m gpu.
+
+Tolerances (BASELINE.json north_star): 1e-5 relative on the log-likelihood, 1e-4 on the factor
+matrices (measured relative to the largest entry of the matrix, the scale at which a probability
+table is meaningful).  Kernel-level single steps are held to much tighter bounds.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import load_golden, golden_csr, coo_arrays
+
+pytestmark = pytest.mark.gpu
+
+FUSED, DET = 1, 2
+MODES = {"materialised": 0, "materialised+det": DET, "fused": FUSED, "fused+det": FUSED | DET}
+KERNEL_CASES = ["kernels_k6", "kernels_k8_thresh", "kernels_k20", "kernels_k33"]
+FIT_CASES = ["fit_k8_tol0", "fit_k5_earlystop", "fit_k4_weighted", "fit_k8_thresh",
+             "fit_k6_tupleinit", "fit_k16_mid", "fit_k20_50it"]
+
+
+def close_factors(a, b, tol=1e-4):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b).max() / scale
+    assert err <= tol, "factor mismatch %.3e (scale %.3e)" % (err, scale)
+
+
+def close_ll(a, b, rtol=1e-5):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape
+    fin = np.isfinite(b)
+    np.testing.assert_array_equal(np.isfinite(a), fin)
+    np.testing.assert_array_equal(a[~fin], b[~fin])
+    np.testing.assert_allclose(a[fin], b[fin], rtol=rtol)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import enstop_amd
+    return enstop_amd
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel level vs the reference's own outputs
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", KERNEL_CASES)
+def test_e_step_vs_reference(amd, case):
+    g = load_golden(case)
+    r, c, v = coo_arrays(golden_csr(g))
+    P = np.full_like(g["P"], -7.0)
+    out = amd.plsa_e_step(r, c, v, g["V"].copy(), g["U"].copy(), P, g["thresh"])
+    assert out is P
+    np.testing.assert_array_equal(P == 0.0, g["P"] == 0.0)          # threshold pattern is exact
+    np.testing.assert_allclose(P, g["P"], rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+@pytest.mark.parametrize("case", KERNEL_CASES)
+def test_m_steps_vs_reference(amd, case, deterministic):
+    g = load_golden(case)
+    r, c, v = coo_arrays(golden_csr(g))
+    n, k = g["U"].shape
+    V, U = g["V"].copy(), g["U"].copy()
+    a, b = np.zeros(k, np.float32), np.zeros(n, np.float32)
+    amd.plsa_m_step(r, c, v, V, U, g["P"], a, b, deterministic=deterministic)
+    np.testing.assert_allclose(V, g["V_m"], rtol=3e-6, atol=1e-9)
+    np.testing.assert_allclose(U, g["U_m"], rtol=3e-6, atol=1e-9)
+    np.testing.assert_allclose(a, g["norm_pwz"], rtol=3e-6)
+    np.testing.assert_allclose(b, g["norm_pdz"], rtol=3e-6)
+
+    V, U = g["V"].copy(), g["U"].copy()
+    amd.plsa_m_step_w_sample_weight(r, c, v, V, U, g["P"], g["sw"], a, b, deterministic=deterministic)
+    np.testing.assert_allclose(V, g["V_mw"], rtol=3e-6, atol=1e-9)
+    np.testing.assert_allclose(U, g["U_mw"], rtol=3e-6, atol=1e-9)
+    np.testing.assert_allclose(a, g["norm_pwz_w"], rtol=3e-6)
+    np.testing.assert_allclose(b, g["norm_pdz_w"], rtol=3e-6)
+
+    U = g["U"].copy()
+    Vfixed = g["V"].copy()
+    amd.plsa_refit_m_step(r, c, v, Vfixed, U, g["P"], np.ones(n, np.float32), b)
+    np.testing.assert_allclose(U, g["U_refit"], rtol=3e-6, atol=1e-9)
+    np.testing.assert_array_equal(Vfixed, g["V"])
+    np.testing.assert_allclose(b, g["norm_pdz_refit"], rtol=3e-6)
+
+
+@pytest.mark.parametrize("case", KERNEL_CASES)
+def test_log_likelihood_vs_reference(amd, case):
+    g = load_golden(case)
+    r, c, v = coo_arrays(golden_csr(g))
+    ones = np.ones(g["U"].shape[0], np.float32)
+    for sw, key, VV, UU in ((ones, "ll_ones", g["V"], g["U"]), (g["sw"], "ll_sw", g["V"], g["U"]),
+                            (ones, "ll_after_m", g["V_m"], g["U_m"])):
+        got = amd.log_likelihood(r, c, v, VV, UU, sw)
+        assert got.dtype == np.float32
+        close_ll(np.array([got]), np.array([g[key]]), rtol=3e-6)
+
+
+def test_unsorted_coo_input(amd):
+    """Kernel-level functions accept COO triplets in any order, like the reference."""
+    g = load_golden("kernels_k6")
+    r, c, v = coo_arrays(golden_csr(g))
+    perm = np.random.RandomState(0).permutation(r.shape[0])
+    P = np.zeros_like(g["P"])
+    amd.plsa_e_step(r[perm], c[perm], v[perm], g["V"], g["U"], P, g["thresh"])
+    np.testing.assert_allclose(P, g["P"][perm], rtol=2e-6, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+# drivers vs the reference's own outputs
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("case", FIT_CASES)
+def test_fit_vs_reference(amd, case, mode):
+    g = load_golden(case)
+    X = golden_csr(g)
+    init = (g["U_init"], g["V_init"]) if "U_init" in g else "random"
+    U, V, info = amd.plsa_fit(X, int(g["k"]), g["sw"], init=init, n_iter=int(g["n_iter"]),
+                              n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+                              e_step_thresh=float(g["thresh"]), random_state=int(g["fit_seed"]),
+                              flags=MODES[mode], return_info=True)
+    assert U.dtype == np.float32 and V.dtype == np.float32
+    assert info["n_iter"] == int(g["iters"])
+    close_ll(info["log_likelihood_trace"], g["ll_trace"])
+    close_factors(U, g["U"])
+    close_factors(V, g["V"])
+
+
+@pytest.mark.parametrize("mode", ["materialised", "fused"])
+@pytest.mark.parametrize("case", ["refit_k6", "refit_k8_weighted"])
+def test_refit_vs_reference(amd, case, mode):
+    g = load_golden(case)
+    X = golden_csr(g)
+    U, info = amd.plsa_refit(X, g["topics"], g["sw"], n_iter=int(g["n_iter"]),
+                             n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+                             random_state=np.random.RandomState(42), flags=MODES[mode], return_info=True)
+    assert info["n_iter"] == int(g["iters"])
+    close_ll(info["log_likelihood_trace"], g["ll_trace"])
+    close_factors(U, g["U"])
+
+
+@pytest.mark.parametrize("case", ["estimator_int", "estimator_float", "estimator_int_emptyrows"])
+def test_estimator_vs_reference(amd, case):
+    g = load_golden(case)
+    shape = tuple(int(s) for s in g["shape"])
+    X = sp.csr_matrix((g["data"], g["indices"], g["indptr"]), shape=shape)
+    model = amd.PLSA(n_components=int(g["k"]), n_iter=30, n_iter_per_test=10, tolerance=0.0, random_state=11)
+    emb = model.fit_transform(X)
+    assert str(np.asarray(emb).dtype) == str(g["embedding_dtype"])
+    close_factors(emb, g["embedding"])
+    close_factors(model.components_, g["components"])
+    assert model.embedding_ is emb and model.training_data_.shape == shape
+    if case.endswith("emptyrows"):
+        assert np.all(emb[[0, 17, 47]] == 0.0)
+    Xt = sp.csr_matrix((g["t_data"], g["t_indices"], g["t_indptr"]), shape=tuple(int(s) for s in g["t_shape"]))
+    close_factors(model.transform(Xt), g["transformed"])
+    assert model.fit(X) is model
+
+
+def test_ensemble_member_vs_reference(amd):
+    g = load_golden("member_k6")
+    X = golden_csr(g)
+    k = int(g["k"])
+    kw = dict(n_iter=int(g["n_iter"]), n_iter_per_test=10, tolerance=0.0, e_step_thresh=float(g["thresh"]))
+    close_factors(amd.plsa_topics(X, k, random_state=np.random.RandomState(5), **kw), g["V_rs5"])
+    close_factors(amd.plsa_topics(X, k, random_state=9, **kw), g["V_int9"])
+    close_factors(amd.plsa_topics(X, k, random_state=9, bootstrap=False, **kw), g["V_nobootstrap"])
+    stack = amd.ensemble_of_topics(X, k, n_runs=3, parallelism="none",
+                                   random_state=np.random.RandomState(21), **kw)
+    assert stack.shape == g["V_stack_rs21"].shape
+    close_factors(stack, g["V_stack_rs21"])
+
+
+def test_bootstrap_gather_bit_exact(amd):
+    """Device row gather == scipy's A[idx] (what enstop_.py:88 does), bit for bit."""
+    rs = np.random.RandomState(7)
+    X = sp.random(500, 300, density=0.05, format="csr", random_state=rs, dtype=np.float32)
+    X.data = np.ceil(X.data * 9).astype(np.float32)
+    idx = rs.randint(0, 500, size=500)
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        eng.bootstrap(idx)
+        B = eng.download_active_csr()
+        ref = X[idx]
+        np.testing.assert_array_equal(B.indptr, ref.indptr)
+        np.testing.assert_array_equal(B.indices, ref.indices)
+        np.testing.assert_array_equal(B.data, ref.data)
+        eng.bootstrap(None)
+        B = eng.download_active_csr()
+        np.testing.assert_array_equal(B.indptr, X.indptr)
+        np.testing.assert_array_equal(B.indices, X.indices)
+        with pytest.raises(amd.DeviceError):
+            eng.bootstrap(np.array([0, 500], np.int64))
+
+
+# ------------------------------------------------------------------------------------------------
+# HIP vs the pinned oracle on seeded inputs the reference would take minutes for
+# ------------------------------------------------------------------------------------------------
+def _corpus(n, m, density, seed, empty_rows=0):
+    rs = np.random.RandomState(seed)
+    X = sp.random(n, m, density=density, format="csr", random_state=rs, dtype=np.float64)
+    X.data = np.ceil(X.data * 7)
+    if empty_rows:
+        X = X.tolil()
+        for r in rs.choice(n, empty_rows, replace=False):
+            X[r] = 0
+        X = X.tocsr()
+    X.eliminate_zeros()
+    X.sort_indices()
+    return X.astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("k", [3, 20, 32, 64, 128, 200, 300])
+def test_fit_vs_oracle(amd, oracle, k, mode):
+    n, m = (600, 900) if k <= 128 else (150, 260)
+    X = _corpus(n, m, 0.04, seed=k, empty_rows=3)
+    rs = np.random.RandomState(k + 1)
+    sw = (0.5 + rs.rand(n)).astype(np.float32) if k in (20, 200) else np.ones(n, np.float32)
+    kw = dict(n_iter=12, n_iter_per_test=5, tolerance=0.0, e_step_thresh=1e-16, random_state=k)
+    Uo, Vo, trace, iters = oracle.plsa_fit(X, k, sw, return_trace=True, **kw)
+    U, V, info = amd.plsa_fit(X, k, sw, flags=MODES[mode], return_info=True, **kw)
+    assert info["n_iter"] == iters
+    close_ll(info["log_likelihood_trace"], trace)
+    close_factors(U, Uo)
+    close_factors(V, Vo)
+    # rows of an empty document stay exactly zero (plsa.py:200-202 guard)
+    empty = np.diff(X.indptr) == 0
+    assert empty.sum() == 3 and np.all(U[empty] == 0.0)
+
+
+@pytest.mark.parametrize("k", [20, 64])
+def test_kernels_vs_oracle_midsize(amd, oracle, k):
+    n, m = 3000, 4000
+    X = _corpus(n, m, 0.01, seed=100 + k)
+    r, c, v = coo_arrays(X)
+    rs = np.random.RandomState(5)
+    V = rs.rand(k, m); V /= V.sum(1, keepdims=True)
+    U = rs.rand(n, k); U /= U.sum(1, keepdims=True)
+    V = V.astype(np.float32); U = U.astype(np.float32)
+    U[7] = 0.0                                             # a document with an all-zero row: norm == 0
+    Po = oracle.plsa_e_step(r, c, v, V, U, np.zeros((r.shape[0], k), np.float32), 1e-7)
+    P = amd.plsa_e_step(r, c, v, V, U, np.zeros((r.shape[0], k), np.float32), 1e-7)
+    np.testing.assert_array_equal(P == 0.0, Po == 0.0)
+    np.testing.assert_allclose(P, Po, rtol=3e-6, atol=1e-10)
+    ones = np.ones(n, np.float32)
+    Vo, Uo = V.copy(), U.copy()
+    oracle.plsa_m_step(r, c, v, Vo, Uo, Po, np.zeros(k, np.float32), np.zeros(n, np.float32))
+    for det in (False, True):
+        Vh, Uh = V.copy(), U.copy()
+        amd.plsa_m_step(r, c, v, Vh, Uh, Po, np.zeros(k, np.float32), np.zeros(n, np.float32), deterministic=det)
+        np.testing.assert_allclose(Uh, Uo, rtol=2e-5, atol=1e-9)
+        np.testing.assert_allclose(Vh, Vo, rtol=2e-5, atol=1e-9)
+    close_ll(np.array([amd.log_likelihood(r, c, v, Vo, Uo, ones)]),
+             np.array([oracle.log_likelihood(r, c, v, Vo, Uo, ones)]))
+
+
+# ------------------------------------------------------------------------------------------------
+# size-independent properties at sizes the oracle cannot reach in seconds
+# ------------------------------------------------------------------------------------------------
+def test_properties_large_synthetic(amd):
+    n, m, nnz_t, k = 200_000, 50_000, 20_000_000, 64
+    with amd.Engine() as eng:
+        nnz = eng.generate_synthetic(n, m, nnz_t, seed=3)
+        assert abs(nnz - nnz_t) / nnz_t < 0.01
+        rs = np.random.RandomState(0)
+        V = rs.rand(k, m); V /= V.sum(1, keepdims=True)
+        U = rs.rand(n, k); U /= U.sum(1, keepdims=True)
+        results = {}
+        for name, flags in MODES.items():
+            eng.set_factors(U.astype(np.float32), V.astype(np.float32))
+            iters, ll = eng.fit(None, n_iter=6, n_iter_per_test=1, tolerance=0.0, e_step_thresh=1e-32,
+                                flags=flags, trace=True)
+            assert iters == 6 and ll.shape == (7,)
+            assert np.all(np.diff(ll.astype(np.float64)) >= -1e-6 * np.abs(ll[0])), "EM must not decrease LL"
+            Uf, Vf = eng.get_factors()
+            np.testing.assert_allclose(Uf.sum(1, dtype=np.float64), 1.0, atol=2e-5)
+            np.testing.assert_allclose(Vf.sum(1, dtype=np.float64), 1.0, atol=2e-4)
+            assert Uf.min() >= 0.0 and Vf.min() >= 0.0
+            results[name] = (Uf, Vf, ll)
+        base = results["materialised+det"]
+        for name, (Uf, Vf, ll) in results.items():
+            close_ll(ll, base[2])
+            close_factors(Uf, base[0])
+            close_factors(Vf, base[1])
+        # the atomic-free schedule is bit-reproducible
+        eng.set_factors(U.astype(np.float32), V.astype(np.float32))
+        eng.fit(None, n_iter=6, n_iter_per_test=1, tolerance=0.0, flags=FUSED | DET, trace=True)
+        U2, V2 = eng.get_factors()
+        np.testing.assert_array_equal(U2, results["fused+det"][0])
+        np.testing.assert_array_equal(V2, results["fused+det"][1])
+
+
+def test_synthetic_generator_is_canonical_and_deterministic(amd):
+    with amd.Engine() as eng:
+        nnz = eng.generate_synthetic(5000, 2000, 300_000, seed=11)
+        A = eng.download_active_csr()
+        assert A.nnz == nnz and abs(nnz - 300_000) / 300_000 < 0.01
+        assert np.all(np.diff(A.indptr) >= 1)                       # no empty documents
+        assert A.has_sorted_indices and A.indices.max() < 2000 and A.indices.min() >= 0
+        B = A.copy(); B.sum_duplicates()
+        assert B.nnz == A.nnz                                        # no duplicate (doc, word)
+        assert A.data.min() >= 1.0 and np.all(A.data == np.round(A.data))
+        nnz2 = eng.generate_synthetic(5000, 2000, 300_000, seed=11)
+        A2 = eng.download_active_csr()
+        assert nnz2 == nnz
+        np.testing.assert_array_equal(A.indptr, A2.indptr)
+        np.testing.assert_array_equal(A.indices, A2.indices)
+        np.testing.assert_array_equal(A.data, A2.data)
+        eng.generate_synthetic(5000, 2000, 300_000, seed=12)
+        A3 = eng.download_active_csr()
+        assert not np.array_equal(A.indices[:1000], A3.indices[:1000])
+        # Zipf head: the most frequent word appears in far more documents than the median word
+        df = np.bincount(A.indices, minlength=2000)
+        assert df.max() > 20 * max(np.median(df), 1)
