@@ -9,9 +9,9 @@ from .plsa import (PLSA, log_likelihood, plsa_e_step, plsa_fit, plsa_fit_inner, 
                    plsa_m_step, plsa_m_step_w_sample_weight, plsa_refit, plsa_refit_inner,
                    plsa_refit_m_step)
 from .enstop_ import ensemble_of_topics, plsa_topics
-from .engine import Engine, DeviceError, PLSA_FUSED, PLSA_DETERMINISTIC
+from .engine import Engine, DeviceError, PLSA_FUSED
 
 __all__ = ["PLSA", "plsa_fit", "plsa_refit", "plsa_fit_inner", "plsa_refit_inner", "plsa_init",
            "plsa_e_step", "plsa_m_step", "plsa_m_step_w_sample_weight", "plsa_refit_m_step",
            "log_likelihood", "plsa_topics", "ensemble_of_topics", "Engine", "DeviceError",
-           "PLSA_FUSED", "PLSA_DETERMINISTIC"]
+           "PLSA_FUSED"]

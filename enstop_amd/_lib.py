@@ -10,10 +10,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplsa_hip.so")
+LIB_PATH = os.environ.get("ENSTOP_AMD_LIB", os.path.join(_HERE, "libplsa_hip.so"))   # override: A/B builds
 
 PLSA_FUSED = 1
-PLSA_DETERMINISTIC = 2
 PLSA_TRACE_LL = 4
 
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -42,7 +41,7 @@ SIGNATURES = {
     "plsa_copy_components_to_device": (C.c_int, [_ctx, _vp]),
     "plsa_e_step": (C.c_int, [_ctx, C.c_float, _vp]),
     "plsa_set_p": (C.c_int, [_ctx, _f32p]),
-    "plsa_m_step": (C.c_int, [_ctx, _vp, _i32, _i32, _vp, _vp]),
+    "plsa_m_step": (C.c_int, [_ctx, _vp, _i32, _vp, _vp]),
     "plsa_log_likelihood": (C.c_int, [_ctx, _vp, C.POINTER(C.c_double)]),
     "plsa_fit": (C.c_int, [_ctx, _vp, _i32, _i32, C.c_double, C.c_float, _i32, C.POINTER(_i32), _vp,
                            C.POINTER(_i32)]),
@@ -52,6 +51,7 @@ SIGNATURES = {
     "plsa_timing_reset": (C.c_int, [_ctx]),
     "plsa_timing_get": (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "plsa_timing_report": (C.c_int, [_ctx, C.c_char_p, _i64]),
+    "plsa_measure_stream_bandwidth": (C.c_int, [_ctx, _i64, _i32, _i32, C.POINTER(C.c_double)]),
     "plsa_host_normalize_rows": (None, [_f64p, _i64, _i64]),
     "plsa_generate_synthetic": (C.c_int, [_ctx, _i64, _i64, _i64, C.c_double, C.c_uint64,
                                           C.POINTER(_i64)]),

@@ -6,7 +6,7 @@
 //   active CSR   same arrays for the matrix the EM runs on (== base, or a bootstrap resample)
 //   rowidx       i32[nnz]   COO row ids of the active matrix (nnz-parallel E-step)
 //   CSC copy     colptr i32[m+1], csc_row/csc_pos i32[nnz], csc_val f32[nnz], column items
-//                (built lazily, only for PLSA_DETERMINISTIC)
+//                (built lazily; not needed with PLSA_ATOMIC_V)
 //   U[2]         f32[n,kp]  P(z|d), double-buffered (a rejected iteration is simply not swapped in)
 //   Vt[2], Vacc  f32[m,kp]  P(w|z) word-major, double-buffered, + the un-normalised accumulator
 //   P            f32[nnz,kp] materialised responsibilities (only when not PLSA_FUSED)
@@ -64,16 +64,21 @@ struct plsa_ctx {
 
     // CSC copy + column items
     bool csc_valid = false;
-    int seg = 128;
+    int seg = 256;
     i64 n_items = 0;
-    DevBuf colptr, csc_row, csc_val, csc_pos, item_first, item_col, item_start, partial;
+    DevBuf colptr, csc_row, csc_val, csc_pos, item_first, item_col, item_start, item_order, partial, heavy_cols;
+    bool use_item_order = true;
+    int heavy_items = 32, n_heavy = 0;
+
+    // rows in descending-length order (row-owned kernels: groups of a wave finish together)
+    bool sort_rows = true, roworder_valid = false;
+    DevBuf row_order;
 
     // factors
     int k = 0, kp = 0, lpn = 1, ch = 1;
     DevBuf U[2], Vt[2], Vacc;
     int cu = 0, cv = 0;
     i64 fac_n = 0, fac_m = 0;
-    bool vacc_zero = false;
     DevBuf P;
     bool p_valid = false;
 
@@ -185,9 +190,10 @@ struct Scope {  // brackets one kernel launch with events when timing is on
 
 template <class Fn>
 int dispatch_shape(plsa_ctx *c, Fn &&fn) {
+    const bool full = c->kp == 4 * c->lpn * c->ch;
 #define PLSA_SHAPE(L, H)                                                                           \
     if (c->lpn == L && c->ch == H) {                                                               \
-        fn(std::integral_constant<int, L>{}, std::integral_constant<int, H>{});                    \
+        if (full) fn(plsa::Shape<L, H, true>{}); else fn(plsa::Shape<L, H, false>{});              \
         return 0;                                                                                  \
     }
     PLSA_SHAPE(1, 1) PLSA_SHAPE(2, 1) PLSA_SHAPE(4, 1) PLSA_SHAPE(8, 1) PLSA_SHAPE(16, 1)
@@ -220,6 +226,7 @@ void set_active_pointers(plsa_ctx *c) {
     }
     c->rowidx_valid = false;
     c->csc_valid = false;
+    c->roworder_valid = false;
     c->p_valid = false;
 }
 
@@ -233,6 +240,31 @@ int ensure_rowidx(plsa_ctx *c) {
     }
     CHK(launch_check(c, "k_expand_rows"));
     c->rowidx_valid = true;
+    return 0;
+}
+
+// row ids sorted by descending row length (stable), or nullptr when sorting is disabled
+int ensure_roworder(plsa_ctx *c, const int **out) {
+    *out = nullptr;
+    if (!c->sort_rows) return 0;
+    if (!c->roworder_valid) {
+        const i64 n = c->n;
+        CHK(ensure(c, c->row_order, sizeof(int) * (size_t)n));
+        CHK(ensure(c, c->tmp0, sizeof(int) * (size_t)n * 2));
+        CHK(ensure(c, c->tmp1, sizeof(int) * (size_t)n));
+        int *len = c->tmp0.as<int>(), *len_sorted = c->tmp0.as<int>() + n, *ids = c->tmp1.as<int>();
+        hipLaunchKernelGGL(plsa::k_row_lengths, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           c->indptr, (int)n, len, ids);
+        CHK(launch_check(c, "k_row_lengths"));
+        size_t bytes = 0;
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, len, len_sorted, ids,
+                                                               c->row_order.as<int>(), (int)n, 0, 32, c->stream));
+        CHK(ensure(c, c->cubtmp, bytes));
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairsDescending(c->cubtmp.p, bytes, len, len_sorted, ids,
+                                                               c->row_order.as<int>(), (int)n, 0, 32, c->stream));
+        c->roworder_valid = true;
+    }
+    *out = c->row_order.as<int>();
     return 0;
 }
 
@@ -293,10 +325,32 @@ int ensure_csc(plsa_ctx *c) {
     c->n_items = n_items;
     CHK(ensure(c, c->item_col, sizeof(int) * (size_t)n_items));
     CHK(ensure(c, c->item_start, sizeof(int) * (size_t)n_items));
+    CHK(ensure(c, c->item_order, sizeof(int) * (size_t)n_items));
+    CHK(ensure(c, c->tmp0, sizeof(int) * (size_t)std::max<i64>(n_items, 1) * 2));   // doc0, doc0 sorted
+    CHK(ensure(c, c->tmp1, sizeof(int) * (size_t)std::max<i64>(n_items, 1)));       // item ids
     hipLaunchKernelGGL(plsa::k_item_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                       c->colptr.as<int>(), c->item_first.as<int>(), (int)m, c->seg,
-                       c->item_col.as<int>(), c->item_start.as<int>());
+                       c->colptr.as<int>(), c->item_first.as<int>(), (int)m, c->seg, c->csc_row.as<int>(),
+                       c->item_col.as<int>(), c->item_start.as<int>(), c->tmp0.as<int>(), c->tmp1.as<int>());
     CHK(launch_check(c, "k_item_fill"));
+    if (n_items > 0) {   // visiting order: ascending first document (stable) -> doc-band-major
+        int dbits = 1;
+        while (((i64)1 << dbits) < c->n) ++dbits;
+        size_t bytes = 0;
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, c->tmp0.as<int>(), c->tmp0.as<int>() + n_items,
+                                                     c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, dbits, c->stream));
+        CHK(ensure(c, c->cubtmp, bytes));
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, bytes, c->tmp0.as<int>(), c->tmp0.as<int>() + n_items,
+                                                     c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, dbits, c->stream));
+    }
+    // columns whose item count makes a single group's serial reduction a tail (Zipf head words)
+    CHK(ensure(c, c->heavy_cols, sizeof(int) * (size_t)(m + 1)));
+    HIPCHK(c, hipMemsetAsync(c->heavy_cols.as<int>() + m, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(plsa::k_heavy_list, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                       c->item_first.as<int>(), (int)m, c->heavy_items, c->heavy_cols.as<int>(),
+                       c->heavy_cols.as<int>() + m);
+    CHK(launch_check(c, "k_heavy_list"));
+    HIPCHK(c, hipMemcpyAsync(&c->n_heavy, c->heavy_cols.as<int>() + m, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->csc_valid = true;
     return 0;
 }
@@ -325,64 +379,49 @@ int need_factors(plsa_ctx *c) {
 // ---------------------------------------------------------------------------------------------
 int run_e_step(plsa_ctx *c, float thresh) {
     CHK(ensure_rowidx(c));
-    CHK(ensure(c, c->P, sizeof(float) * (size_t)c->nnz * (size_t)c->kp));
+    // one tile (64 rows) of slack: the last tile is stored without a predicate
+    CHK(ensure(c, c->P, sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp));
     const i64 tiles = (c->nnz + 63) / 64;
     const int grid = grid_for(c, tiles, 4);
-    CHK(dispatch_shape(c, [&](auto L, auto H) {
+    CHK(dispatch_shape(c, [&](auto S) {
         Scope s(c, "k_e_step");
-        hipLaunchKernelGGL((plsa::k_e_step<decltype(L)::value, decltype(H)::value>), dim3(grid),
-                           dim3(256), 0, c->stream, c->rowidx.as<int>(), c->col, c->nnz,
-                           c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(), c->P.as<float>(), c->kp,
-                           thresh);
+        hipLaunchKernelGGL((plsa::k_e_step<decltype(S)>), dim3(grid), dim3(256), 0, c->stream,
+                           c->rowidx.as<int>(), c->col, c->nnz, c->U[c->cu].as<float>(),
+                           c->Vt[c->cv].as<float>(), c->P.as<float>(), c->kp, thresh);
     }));
     CHK(launch_check(c, "k_e_step"));
     c->p_valid = true;
     return 0;
 }
 
-int ensure_vacc_zero(plsa_ctx *c) {
-    if (c->vacc_zero) return 0;
-    HIPCHK(c, hipMemsetAsync(c->Vacc.p, 0, sizeof(float) * (size_t)c->m * c->kp, c->stream));
-    c->vacc_zero = true;
-    return 0;
-}
-
-// document-owned pass: writes U[1-cu]; optional atomics into Vacc; optional LL partials
-int run_row_pass(plsa_ctx *c, bool from_p, bool atomic_v, bool want_ll, const float *d_sw,
-                 float thresh, float *d_norm_pdz, int *ll_blocks) {
+// document-owned pass: writes U[1-cu]; optional LL partials of the current factors
+int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, float thresh,
+                 float *d_norm_pdz, int *ll_blocks) {
     const int grid = grid_for(c, c->n, 256 / c->lpn);
-    if (atomic_v) CHK(ensure_vacc_zero(c));
+    const int *order = nullptr;
+    CHK(ensure_roworder(c, &order));
     if (want_ll) CHK(ensure(c, c->ll_partials, sizeof(double) * (size_t)grid));
-    CHK(dispatch_shape(c, [&](auto L, auto H) {
-        constexpr int LPN = decltype(L)::value, CHn = decltype(H)::value;
+    CHK(dispatch_shape(c, [&](auto S) {
+        using Sh = decltype(S);
         const int *ip = c->indptr, *cl = c->col;
         const float *vl = c->val, *U = c->U[c->cu].as<float>(), *Vt = c->Vt[c->cv].as<float>();
         const float *P = c->P.as<float>();
-        float *Un = c->U[1 - c->cu].as<float>(), *Va = c->Vacc.as<float>();
+        float *Un = c->U[1 - c->cu].as<float>();
         double *llp = c->ll_partials.as<double>();
         const int n = (int)c->n, kp = c->kp;
-        auto go = [&](auto FP, auto AV, auto LL, const char *name) {
+        auto go = [&](auto FP, auto LL, const char *name) {
             Scope s(c, name);
-            hipLaunchKernelGGL((plsa::k_row_pass<LPN, CHn, decltype(FP)::value, decltype(AV)::value,
-                                                 decltype(LL)::value>),
-                               dim3(grid), dim3(256), 0, c->stream, ip, cl, vl, n, U, Vt, P, Un, Va,
+            hipLaunchKernelGGL((plsa::k_row_pass<Sh, decltype(FP)::value, decltype(LL)::value>),
+                               dim3(grid), dim3(256), 0, c->stream, ip, cl, vl, n, order, U, Vt, P, Un,
                                d_sw, d_norm_pdz, kp, thresh, llp);
         };
         using T = std::true_type;
         using F = std::false_type;
-        if (from_p) {
-            if (atomic_v) go(T{}, T{}, F{}, "k_row_pass<P,atomicV>");
-            else go(T{}, F{}, F{}, "k_row_pass<P>");
-        } else if (atomic_v) {
-            if (want_ll) go(F{}, T{}, T{}, "k_row_pass<fused,atomicV,LL>");
-            else go(F{}, T{}, F{}, "k_row_pass<fused,atomicV>");
-        } else {
-            if (want_ll) go(F{}, F{}, T{}, "k_row_pass<fused,LL>");
-            else go(F{}, F{}, F{}, "k_row_pass<fused>");
-        }
+        if (from_p) go(T{}, F{}, "k_row_pass<P>");
+        else if (want_ll) go(F{}, T{}, "k_row_pass<fused,LL>");
+        else go(F{}, F{}, "k_row_pass<fused>");
     }));
     CHK(launch_check(c, "k_row_pass"));
-    if (atomic_v) c->vacc_zero = false;
     if (ll_blocks) *ll_blocks = grid;
     return 0;
 }
@@ -391,43 +430,48 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool atomic_v, bool want_ll, const fl
 int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh) {
     CHK(ensure_csc(c));
     CHK(ensure(c, c->partial, sizeof(float) * (size_t)std::max<i64>(c->n_items, 1) * c->kp));
-    CHK(dispatch_shape(c, [&](auto L, auto H) {
-        constexpr int LPN = decltype(L)::value, CHn = decltype(H)::value;
+    CHK(dispatch_shape(c, [&](auto S) {
+        using Sh = decltype(S);
+        constexpr int LPN = Sh::LPN;
         const int grid = grid_for(c, c->n_items, 256 / LPN);
         const int grid2 = grid_for(c, c->m, 256 / LPN);
+        const int *order = c->use_item_order ? c->item_order.as<int>() : nullptr;
         if (c->n_items > 0) {
             if (from_p) {
                 Scope s(c, "k_col_pass<P>");
-                hipLaunchKernelGGL((plsa::k_col_pass<LPN, CHn, true>), dim3(grid), dim3(256), 0,
-                                   c->stream, c->item_col.as<int>(), c->item_start.as<int>(),
-                                   c->colptr.as<int>(), c->n_items, c->seg, c->csc_row.as<int>(),
-                                   c->csc_val.as<float>(), c->csc_pos.as<int>(),
-                                   c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
+                hipLaunchKernelGGL((plsa::k_col_pass<Sh, true>), dim3(grid), dim3(256), 0, c->stream, order,
+                                   c->item_col.as<int>(), c->item_start.as<int>(), c->colptr.as<int>(),
+                                   c->n_items, c->seg, c->csc_row.as<int>(), c->csc_val.as<float>(),
+                                   c->csc_pos.as<int>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
                                    c->P.as<float>(), d_sw, c->partial.as<float>(), c->kp, thresh);
             } else {
                 Scope s(c, "k_col_pass<fused>");
-                hipLaunchKernelGGL((plsa::k_col_pass<LPN, CHn, false>), dim3(grid), dim3(256), 0,
-                                   c->stream, c->item_col.as<int>(), c->item_start.as<int>(),
-                                   c->colptr.as<int>(), c->n_items, c->seg, c->csc_row.as<int>(),
-                                   c->csc_val.as<float>(), c->csc_pos.as<int>(),
-                                   c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
+                hipLaunchKernelGGL((plsa::k_col_pass<Sh, false>), dim3(grid), dim3(256), 0, c->stream, order,
+                                   c->item_col.as<int>(), c->item_start.as<int>(), c->colptr.as<int>(),
+                                   c->n_items, c->seg, c->csc_row.as<int>(), c->csc_val.as<float>(),
+                                   c->csc_pos.as<int>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
                                    c->P.as<float>(), d_sw, c->partial.as<float>(), c->kp, thresh);
             }
         }
         {
             Scope s(c, "k_col_reduce");
-            hipLaunchKernelGGL((plsa::k_col_reduce<LPN, CHn>), dim3(grid2), dim3(256), 0, c->stream,
-                               c->item_first.as<int>(), (int)c->m, c->partial.as<float>(),
-                               c->Vacc.as<float>(), c->kp);
+            hipLaunchKernelGGL((plsa::k_col_reduce<Sh>), dim3(grid2), dim3(256), 0, c->stream,
+                               c->item_first.as<int>(), (int)c->m, c->heavy_items,
+                               c->partial.as<float>(), c->Vacc.as<float>(), c->kp);
+        }
+        if (c->n_heavy > 0) {
+            Scope s(c, "k_col_reduce_heavy");
+            hipLaunchKernelGGL((plsa::k_col_reduce_heavy<Sh>), dim3(c->n_heavy), dim3(256),
+                               (256 / LPN) * c->kp * sizeof(float), c->stream, c->heavy_cols.as<int>(),
+                               c->item_first.as<int>(), c->partial.as<float>(), c->Vacc.as<float>(), c->kp);
         }
     }));
     CHK(launch_check(c, "k_col_pass"));
-    c->vacc_zero = false;
     return 0;
 }
 
 // Vacc -> normalised topics in Vt[1-cv]  (plsa.py:196-199)
-int run_v_normalise(plsa_ctx *c, bool rezero, float *d_norm_pwz) {
+int run_v_normalise(plsa_ctx *c, float *d_norm_pwz) {
     const int nb = (int)std::min<i64>(plsa::NORM_BLOCKS, std::max<i64>(1, c->m));
     CHK(ensure(c, c->colsum_partials, sizeof(double) * (size_t)nb * c->kp));
     {
@@ -438,13 +482,12 @@ int run_v_normalise(plsa_ctx *c, bool rezero, float *d_norm_pwz) {
     {
         Scope s(c, "k_v_normalise");
         const i64 total4 = c->m * c->kp / 4;
-        hipLaunchKernelGGL(plsa::k_v_normalise, dim3(grid_for(c, total4, 256)), dim3(256),
+        hipLaunchKernelGGL(plsa::k_v_normalise, dim3(std::min(grid_for(c, total4, 256), 8 * c->prop.multiProcessorCount)), dim3(256),
                            c->kp * sizeof(float), c->stream, c->Vacc.as<float>(),
                            c->Vt[1 - c->cv].as<float>(), (int)c->m, c->kp,
-                           c->colsum_partials.as<double>(), nb, d_norm_pwz, rezero ? 1 : 0);
+                           c->colsum_partials.as<double>(), nb, d_norm_pwz);
     }
     CHK(launch_check(c, "k_v_normalise"));
-    c->vacc_zero = rezero;
     return 0;
 }
 
@@ -464,12 +507,13 @@ int finish_ll(plsa_ctx *c, int blocks, double *out) {
 
 int run_loglik(plsa_ctx *c, const float *d_sw, double *out) {
     const int grid = grid_for(c, c->n, 256 / c->lpn);
+    const int *order = nullptr;
+    CHK(ensure_roworder(c, &order));
     CHK(ensure(c, c->ll_partials, sizeof(double) * (size_t)grid));
-    CHK(dispatch_shape(c, [&](auto L, auto H) {
-        constexpr int LPN = decltype(L)::value, CHn = decltype(H)::value;
+    CHK(dispatch_shape(c, [&](auto S) {
         Scope s(c, "k_loglik");
-        hipLaunchKernelGGL((plsa::k_loglik<LPN, CHn>), dim3(grid), dim3(256), 0, c->stream, c->indptr,
-                           c->col, c->val, (int)c->n, c->U[c->cu].as<float>(),
+        hipLaunchKernelGGL((plsa::k_loglik<decltype(S)>), dim3(grid), dim3(256), 0, c->stream, c->indptr,
+                           c->col, c->val, (int)c->n, order, c->U[c->cu].as<float>(),
                            c->Vt[c->cv].as<float>(), d_sw, c->kp, c->ll_partials.as<double>());
     }));
     CHK(launch_check(c, "k_loglik"));
@@ -477,18 +521,12 @@ int run_loglik(plsa_ctx *c, const float *d_sw, double *out) {
 }
 
 // one M-step from the materialised P: U[1-cu], and (update_v) Vt[1-cv]; swaps the buffers in
-int run_m_step_from_p(plsa_ctx *c, const float *d_sw, bool update_v, bool deterministic,
-                      float *d_norm_pwz, float *d_norm_pdz) {
+int run_m_step_from_p(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_pwz, float *d_norm_pdz) {
     if (!c->p_valid) return fail(c, "plsa_m_step: no P(z|w,d) on the device (run plsa_e_step or plsa_set_p)");
-    if (update_v && deterministic) {
-        CHK(run_row_pass(c, true, false, false, d_sw, 0.f, d_norm_pdz, nullptr));
+    CHK(run_row_pass(c, true, false, nullptr, 0.f, d_norm_pdz, nullptr));
+    if (update_v) {
         CHK(run_col_pass(c, true, d_sw, 0.f));
-        CHK(run_v_normalise(c, false, d_norm_pwz));
-    } else if (update_v) {
-        CHK(run_row_pass(c, true, true, false, d_sw, 0.f, d_norm_pdz, nullptr));
-        CHK(run_v_normalise(c, true, d_norm_pwz));
-    } else {
-        CHK(run_row_pass(c, true, false, false, nullptr, 0.f, d_norm_pdz, nullptr));
+        CHK(run_v_normalise(c, d_norm_pwz));
     }
     c->cu ^= 1;
     if (update_v) c->cv ^= 1;
@@ -542,10 +580,13 @@ int plsa_create(int device, plsa_ctx **out) {
         delete c;
         return fail(nullptr, "stream / pinned buffer creation failed");
     }
-    int mult = 8;
+    int mult = 64;   // blocks per CU a grid may hold: large grids measured best
     if (const char *s = getenv("PLSA_GRID_MULT")) mult = std::max(1, atoi(s));
     c->grid_cap = c->prop.multiProcessorCount * mult;
     if (const char *s = getenv("PLSA_COL_SEG")) c->seg = std::max(1, atoi(s));
+    if (const char *s = getenv("PLSA_HEAVY_ITEMS")) c->heavy_items = std::max(1, atoi(s));
+    if (const char *s = getenv("PLSA_SORT_ROWS")) c->sort_rows = atoi(s) != 0;
+    if (const char *s = getenv("PLSA_ITEM_ORDER")) c->use_item_order = atoi(s) != 0;
     *out = c;
     return 0;
 }
@@ -556,7 +597,7 @@ void plsa_destroy(plsa_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
-                     &c->item_start, &c->partial, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,
+                     &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,
                      &c->P, &c->sw, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
                      &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp};
     for (DevBuf *b : all) release(*b);
@@ -697,7 +738,6 @@ int plsa_set_factors(plsa_ctx *c, const float *U, const float *V, int64_t n, int
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->U[i], sizeof(float) * (size_t)n * kp));
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->Vt[i], sizeof(float) * (size_t)m * kp));
     CHK(ensure(c, c->Vacc, sizeof(float) * (size_t)m * kp));
-    c->vacc_zero = false;
     c->p_valid = false;
     c->cu = 0;
     if (kp != k) HIPCHK(c, hipMemsetAsync(c->U[0].p, 0, sizeof(float) * (size_t)n * kp, c->stream));
@@ -759,7 +799,7 @@ int plsa_e_step(plsa_ctx *c, float thresh, float *P_out) {
 int plsa_set_p(plsa_ctx *c, const float *P) {
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
-    CHK(ensure(c, c->P, sizeof(float) * (size_t)c->nnz * c->kp));
+    CHK(ensure(c, c->P, sizeof(float) * (size_t)(c->nnz + 64) * c->kp));
     if (c->kp != c->k) HIPCHK(c, hipMemsetAsync(c->P.p, 0, sizeof(float) * (size_t)c->nnz * c->kp, c->stream));
     if (c->nnz)
         HIPCHK(c, hipMemcpy2DAsync(c->P.p, sizeof(float) * c->kp, P, sizeof(float) * c->k,
@@ -769,16 +809,14 @@ int plsa_set_p(plsa_ctx *c, const float *P) {
     return 0;
 }
 
-int plsa_m_step(plsa_ctx *c, const float *sw, int32_t update_v, int32_t deterministic, float *norm_pwz,
-                float *norm_pdz) {
+int plsa_m_step(plsa_ctx *c, const float *sw, int32_t update_v, float *norm_pwz, float *norm_pdz) {
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
     const float *d_sw = nullptr;
     CHK(upload_sw(c, sw, &d_sw));
     CHK(ensure(c, c->norm_pwz, sizeof(float) * (size_t)c->kp));
     CHK(ensure(c, c->norm_pdz, sizeof(float) * (size_t)c->n));
-    CHK(run_m_step_from_p(c, d_sw, update_v != 0, deterministic != 0, c->norm_pwz.as<float>(),
-                          c->norm_pdz.as<float>()));
+    CHK(run_m_step_from_p(c, d_sw, update_v != 0, c->norm_pwz.as<float>(), c->norm_pdz.as<float>()));
     if (norm_pwz && update_v)
         HIPCHK(c, hipMemcpyAsync(norm_pwz, c->norm_pwz.p, sizeof(float) * (size_t)c->k, hipMemcpyDeviceToHost, c->stream));
     if (norm_pdz)
@@ -810,7 +848,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
     if (n_iter < 0 || n_iter_per_test <= 0) return fail(c, "plsa_fit: bad n_iter / n_iter_per_test");
-    const bool fused = flags & PLSA_FUSED, det = flags & PLSA_DETERMINISTIC, trace = flags & PLSA_TRACE_LL;
+    const bool fused = flags & PLSA_FUSED, trace = flags & PLSA_TRACE_LL;
     const float *d_sw = nullptr;
     CHK(upload_sw(c, sw, &d_sw));
     int nll = 0, iters = 0;
@@ -823,7 +861,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
     if (!fused) {
         for (int i = 0; i < n_iter; ++i) {
             CHK(run_e_step(c, thresh));                              // plsa.py:597
-            CHK(run_m_step_from_p(c, d_sw, true, det, nullptr, nullptr));  // plsa.py:606-628
+            CHK(run_m_step_from_p(c, d_sw, true, nullptr, nullptr));       // plsa.py:606-628
             iters++;
             if (i % n_iter_per_test == 0) {                          // plsa.py:630
                 if (i == n_iter - 1 && !trace) break;                // outcome cannot matter any more
@@ -839,9 +877,9 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
         bool stopped = false;
         for (int i = 0; i < n_iter; ++i) {
             int blocks = 0;
-            CHK(run_row_pass(c, false, !det, pending, d_sw, thresh, nullptr, &blocks));
-            if (det) CHK(run_col_pass(c, false, d_sw, thresh));
-            CHK(run_v_normalise(c, !det, nullptr));
+            CHK(run_row_pass(c, false, pending, d_sw, thresh, nullptr, &blocks));
+            CHK(run_col_pass(c, false, d_sw, thresh));
+            CHK(run_v_normalise(c, nullptr));
             if (pending) {
                 CHK(finish_ll(c, blocks, &ll));
                 const float cur = (float)ll;
@@ -892,7 +930,7 @@ int plsa_refit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_
     if (!fused) {
         for (int i = 0; i < n_iter; ++i) {
             CHK(run_e_step(c, thresh));
-            CHK(run_m_step_from_p(c, nullptr, false, false, nullptr, nullptr));
+            CHK(run_m_step_from_p(c, nullptr, false, nullptr, nullptr));
             iters++;
             if (i % n_iter_per_test == 0) {
                 if (i == n_iter - 1 && !trace) break;
@@ -909,7 +947,7 @@ int plsa_refit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_
             int blocks = 0;
             // the refit M-step ignores sample weights for P(z|d) (plsa.py:806-809); they only enter
             // the log-likelihood, which this pass accumulates when a test is pending
-            CHK(run_row_pass(c, false, false, pending, d_sw, thresh, nullptr, &blocks));
+            CHK(run_row_pass(c, false, pending, d_sw, thresh, nullptr, &blocks));
             if (pending) {
                 CHK(finish_ll(c, blocks, &ll));
                 const float cur = (float)ll;
@@ -968,6 +1006,35 @@ int plsa_timing_report(plsa_ctx *c, char *buf, int64_t cap) {
         s += line;
     }
     if (cap > 0) { strncpy(buf, s.c_str(), (size_t)cap - 1); buf[cap - 1] = 0; }
+    return 0;
+}
+
+int plsa_measure_stream_bandwidth(plsa_ctx *c, int64_t bytes, int32_t kind, int32_t reps, double *gbps) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (bytes < (1 << 20) || reps < 1 || kind < 0 || kind > 2) return fail(c, "plsa_measure_stream_bandwidth: bad arguments");
+    DevBuf a, b;
+    const i64 n4 = bytes / 16;
+    int rc = ensure(c, a, (size_t)n4 * 16);
+    if (!rc && kind == 2) rc = ensure(c, b, (size_t)n4 * 16);
+    if (rc) { release(a); release(b); return rc; }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int grid = grid_for(c, n4, 256);
+    for (int r = -1; r < reps; ++r) {          // r == -1: untimed warm-up (page faults, clocks)
+        if (r == 0) (void)hipEventRecord(e0, c->stream);
+        if (kind == 0) hipLaunchKernelGGL((plsa::k_probe_fill<true>), dim3(grid), dim3(256), 0, c->stream, a.as<float>(), n4);
+        else if (kind == 1) hipLaunchKernelGGL((plsa::k_probe_fill<false>), dim3(grid), dim3(256), 0, c->stream, a.as<float>(), n4);
+        else hipLaunchKernelGGL(plsa::k_probe_copy, dim3(grid), dim3(256), 0, c->stream, a.as<float>(), b.as<float>(), n4);
+    }
+    (void)hipEventRecord(e1, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    release(a); release(b);
+    if (e != hipSuccess) return fail(c, "stream probe failed: %s", hipGetErrorString(e));
+    const double moved = (double)n4 * 16.0 * (kind == 2 ? 2.0 : 1.0) * reps;
+    *gbps = moved / 1e9 / (ms / 1e3);
     return 0;
 }
 

@@ -1,12 +1,17 @@
 // plsa_kernels.hpp -- gfx950 (CDNA4, wave64) device kernels of the pLSA EM engine.
 //
 // Work decomposition shared by every kernel: a "group" of LPN adjacent lanes (LPN = 1..64, power
-// of two) handles one non-zero (or one document row / one vocabulary column); each lane owns CH
-// float4 chunks of the k-vector, chunk c = lane_in_group + LPN*j.  k is padded to kp = 4*ceil(k/4)
-// in every device layout (U [n,kp], Vt [m,kp] word-major, P [nnz,kp]); pad entries are zero and can
-// never pass the `> thresh` test, so they do not perturb norms.  For k = 64: LPN = 16, CH = 1 -> a
-// wave covers 4 non-zeros per step and every gather / store is one 16-byte access per lane, 256
-// contiguous bytes per non-zero.
+// of two) handles one non-zero (or one document row / one vocabulary column item); each lane owns
+// CH float4 chunks of the k-vector, chunk c = lane_in_group + LPN*j.  k is padded to
+// kp = 4*ceil(k/4) in every device layout (U [n,kp], Vt [m,kp] word-major, P [nnz,kp]); pad entries
+// are zero and can never pass the `> thresh` test, so they do not perturb norms.  For k = 64:
+// LPN = 16, CH = 1 -> a wave covers 4 non-zeros per step and every gather / store is one 16-byte
+// access per lane, 256 contiguous bytes per non-zero.  FULL (kp == 4*LPN*CH, i.e. k = 4,8,..,256
+// and 512, 1024) makes kp a compile-time constant and removes every lane predicate.
+//
+// Latency hiding: each wave keeps UNR non-zeros' factor rows in flight (all gathers of a batch are
+// issued before the first use) and prefetches the next batch of (index, count) pairs; with 8 waves
+// per SIMD this is what lets the gathers run at L2 rate instead of one L2 round trip per non-zero.
 //
 // Reference statements implemented here (paths relative to the reference root):
 //   E-step            enstop/plsa.py:91-105      M-step scatter    enstop/plsa.py:182-194, 287-300
@@ -15,6 +20,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#ifndef PLSA_UNR
+#define PLSA_UNR 4      // non-zeros whose gathers are in flight together, per group
+#endif
+#ifndef PLSA_UNR_COL
+#define PLSA_UNR_COL 8  // same for the column pass (its U gathers miss L2 more often: measured best)
+#endif
 
 namespace plsa {
 
@@ -41,6 +53,7 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 __device__ __forceinline__ float hsum(const float4 &a) { return (a.x + a.y) + (a.z + a.w); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
@@ -50,9 +63,35 @@ __device__ __forceinline__ void st4_nt(float *p, const float4 &v) {
     __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));  // global_store_dwordx4 ... nt
 }
 
+// Shape of the lane decomposition.  When FULL, kp is the compile-time constant 4*LPN*CH.
+template <int LPN_, int CH_, bool FULL_>
+struct Shape {
+    static constexpr int LPN = LPN_, CH = CH_;
+    static constexpr bool FULL = FULL_;
+    static constexpr int UNR = (LPN_ < PLSA_UNR) ? LPN_ : PLSA_UNR;
+    static constexpr int UNR_COL = (LPN_ < PLSA_UNR_COL) ? LPN_ : PLSA_UNR_COL;
+    __device__ static __forceinline__ int kp(int kp_rt) { return FULL_ ? 4 * LPN_ * CH_ : kp_rt; }
+    // offset of chunk j for lane li, and whether it lies inside the row
+    __device__ static __forceinline__ int c4(int li, int j) { return 4 * (li + LPN_ * j); }
+    __device__ static __forceinline__ bool ok(int li, int j, int kp) { return FULL_ || c4(li, j) < kp; }
+};
+
+// gather the lane's chunks of one factor row WITHOUT a branch: out-of-row chunks read offset 0
+// (a valid address) -- ZERO_INVALID then forces them to zero (needed for one operand only:
+// the product with a zeroed chunk is 0 and fails the threshold test).
+template <class S, bool ZERO_INVALID>
+__device__ __forceinline__ void load_row(const float *row, int li, int kp, float4 (&out)[S::CH]) {
+#pragma unroll
+    for (int j = 0; j < S::CH; ++j) {
+        const bool ok = S::ok(li, j, kp);
+        const float4 v = ld4(row + (ok ? S::c4(li, j) : 0));
+        out[j] = (ZERO_INVALID && !ok) ? zero4() : v;
+    }
+}
+
 // responsibilities of one non-zero for this lane's chunks.
 //   keep[j] = (Vt*U > thresh) ? Vt*U : 0        (plsa.py:97-102)
-//   returns the lane-partial of the thresholded norm; *unth gets the un-thresholded partial
+//   returns the lane-partial of the thresholded norm; unth gets the un-thresholded partial
 template <int CH, bool WANT_UNTH>
 __device__ __forceinline__ float products(const float4 (&u)[CH], const float4 (&vt)[CH],
                                           float thresh, float4 (&keep)[CH], float &unth) {
@@ -72,30 +111,35 @@ __device__ __forceinline__ float products(const float4 (&u)[CH], const float4 (&
     return part;
 }
 
-template <int LPN, int CH>
-__device__ __forceinline__ void load_chunks(const float *row, int li, int kp, float4 (&out)[CH]) {
+// 1/norm when norm > 0 else 0 (plsa.py:103-105: rows with a zero norm stay all-zero); v_rcp_f32
+__device__ __forceinline__ float inv_norm(float norm) {
+    return norm > 0.f ? __builtin_amdgcn_rcpf(norm) : 0.f;
+}
+
+template <int CH>
+__device__ __forceinline__ void scale(float4 (&a)[CH], float s) {
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-        const int c4 = 4 * (li + LPN * j);
-        out[j] = (c4 < kp) ? ld4(row + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int j = 0; j < CH; ++j) { a[j].x *= s; a[j].y *= s; a[j].z *= s; a[j].w *= s; }
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_e_step: the materialising E-step, plsa.py:91-105.  nnz-parallel: a wave takes a tile of 64
 // consecutive non-zeros, loads their (doc, word) ids with one coalesced access each, then walks the
-// tile 64/LPN non-zeros at a time.  Per non-zero: gather U[d,:] and Vt[w,:] (kp floats each),
-// multiply, threshold, group-sum, scale, stream the kp responsibilities out (non-temporal: P is
-// written once and not re-read by this kernel, it must not evict the factor rows from L2).
+// tile 64/LPN non-zeros per step, UNR steps per batch: all 2*UNR row gathers of a batch are issued
+// back to back, then the batch is reduced and streamed out.  P is written with non-temporal
+// 16-byte stores (written once, never re-read here: it must not evict the factor rows from L2);
+// the buffer carries one tile of slack so the last tile needs no store predicate.
 // Algorithmic bytes: 4(n+1) + 4 nnz + 4k nnz + 4k(n+m)   (SURVEY.md section 8d).
 // ------------------------------------------------------------------------------------------------
-template <int LPN, int CH>
+template <class S>
 __global__ __launch_bounds__(256) void k_e_step(const int *__restrict__ rowidx,
                                                 const int *__restrict__ colidx, i64 nnz,
                                                 const float *__restrict__ U,
                                                 const float *__restrict__ Vt, float *__restrict__ P,
-                                                int kp, float thresh) {
-    constexpr int GPW = 64 / LPN;  // groups (= non-zeros in flight) per wave
+                                                int kp_rt, float thresh) {
+    constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR;
+    constexpr int GPW = 64 / LPN;  // groups (= non-zeros per step) per wave
+    const int kp = S::kp(kp_rt);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane / LPN, li = lane % LPN;
@@ -105,29 +149,30 @@ __global__ __launch_bounds__(256) void k_e_step(const int *__restrict__ rowidx,
         const i64 mine = base + lane;
         const int d_l = mine < nnz ? __builtin_nontemporal_load(rowidx + mine) : 0;
         const int w_l = mine < nnz ? __builtin_nontemporal_load(colidx + mine) : 0;
-#pragma unroll 4
-        for (int s = 0; s < LPN; ++s) {
-            const int src = s * GPW + g;
-            const int d = __shfl(d_l, src, 64);
-            const int w = __shfl(w_l, src, 64);
-            const i64 nz = base + src;
-            float4 u[CH], vt[CH], keep[CH];
-            load_chunks<LPN, CH>(U + (i64)d * kp, li, kp, u);
-            load_chunks<LPN, CH>(Vt + (i64)w * kp, li, kp, vt);
-            float unth;
-            const float norm = group_sum<LPN>(products<CH, false>(u, vt, thresh, keep, unth));
-            // plsa.py:103-105: divide only when norm > 0 (otherwise the row is all zeros already)
-            const float inv = norm > 0.f ? 1.0f / norm : 0.f;
-            if (nz < nnz) {
-                float *prow = P + nz * kp;
+#pragma unroll
+        for (int s0 = 0; s0 < LPN; s0 += UNR) {
+            float4 u[UNR][CH], vt[UNR][CH];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                const int src = (s0 + q) * GPW + g;
+                const int d = __shfl(d_l, src, 64);
+                const int w = __shfl(w_l, src, 64);
+                load_row<S, true>(U + (i64)d * kp, li, kp, u[q]);
+                load_row<S, false>(Vt + (i64)w * kp, li, kp, vt[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                float4 keep[CH];
+                float unth;
+                const float inv = inv_norm(group_sum<LPN>(products<CH, false>(u[q], vt[q], thresh, keep, unth)));
+                float *prow = P + (base + (s0 + q) * GPW + g) * kp;
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
-                    const int c4 = 4 * (li + LPN * j);
-                    if (c4 < kp) {
+                    if (S::ok(li, j, kp)) {
                         float4 p;
                         p.x = keep[j].x * inv; p.y = keep[j].y * inv;
                         p.z = keep[j].z * inv; p.w = keep[j].w * inv;
-                        st4_nt(prow + c4, p);
+                        st4_nt(prow + S::c4(li, j), p);
                     }
                 }
             }
@@ -138,85 +183,79 @@ __global__ __launch_bounds__(256) void k_e_step(const int *__restrict__ rowidx,
 // ------------------------------------------------------------------------------------------------
 // k_row_pass: document-owned half of the M-step (plsa.py:182-194 restricted to P(z|d), then the
 // P(z|d) part of 196-202), optionally fused with the E-step (FROM_P = false: responsibilities are
-// recomputed in registers and never touch HBM), with the log-likelihood of the CURRENT factors
-// (WANT_LL, plsa.py:375-384) and, when ATOMIC_V, with the P(w|z) scatter as float atomics into the
-// zero-initialised word-major accumulator Vt_new.
+// recomputed in registers and never touch HBM) and with the log-likelihood of the CURRENT factors
+// (WANT_LL, plsa.py:375-384).
 // A group owns one row: no atomics on U, the row norm is a group sum, the normalised row is written
-// once.  Groups walk rows in a grid-stride loop.
+// once.  Rows are visited through `row_order` (descending length) so the groups of a wave finish
+// together; entries beyond the row end are padded with (word 0, count 0) and add exact zeros.
 // ------------------------------------------------------------------------------------------------
-template <int LPN, int CH, bool FROM_P, bool ATOMIC_V, bool WANT_LL>
+template <class S, bool FROM_P, bool WANT_LL>
 __global__ __launch_bounds__(256) void k_row_pass(const int *__restrict__ indptr,
                                                   const int *__restrict__ colidx,
                                                   const float *__restrict__ vals, int n,
+                                                  const int *__restrict__ row_order,
                                                   const float *__restrict__ U,
                                                   const float *__restrict__ Vt,
                                                   const float *__restrict__ P,
                                                   float *__restrict__ U_new,
-                                                  float *__restrict__ Vt_new,
                                                   const float *__restrict__ sw,
-                                                  float *__restrict__ norm_pdz_out, int kp,
+                                                  float *__restrict__ norm_pdz_out, int kp_rt,
                                                   float thresh, double *__restrict__ ll_partials) {
+    constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR;
     constexpr int GPB = 256 / LPN;  // groups per block
+    const int kp = S::kp(kp_rt);
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
     double ll = 0.0;
     for (i64 r = (i64)blockIdx.x * GPB + gid; r < n; r += (i64)gridDim.x * GPB) {
-        const int d = (int)r;
+        const int d = row_order ? row_order[r] : (int)r;
         const int j0 = indptr[d], j1 = indptr[d + 1];
         float4 u[CH], acc[CH];
-        if (!FROM_P || WANT_LL) load_chunks<LPN, CH>(U + (i64)d * kp, li, kp, u);
+        load_row<S, true>(U + (i64)d * kp, li, kp, u);
 #pragma unroll
-        for (int j = 0; j < CH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float swd = sw ? sw[d] : 1.0f;  // x1.0f is exact: one path for plsa.py:188 and :293
+        for (int j = 0; j < CH; ++j) acc[j] = zero4();
+        const float swd = (WANT_LL && sw) ? sw[d] : 1.0f;
+        // software-pipelined index stream: the next LPN (word, count) pairs are in flight while the
+        // current ones are consumed
+        int w_n = (j0 + li < j1) ? colidx[j0 + li] : 0;
+        float x_n = (j0 + li < j1) ? vals[j0 + li] : 0.f;
         for (int jb = j0; jb < j1; jb += LPN) {
-            // one coalesced load of up to LPN (word, count) pairs of this row, then broadcast
-            const int jm = jb + li;
-            const int w_l = jm < j1 ? colidx[jm] : 0;
-            const float x_l = jm < j1 ? vals[jm] : 0.f;
+            const int w_l = w_n;
+            const float x_l = x_n;
+            const int jn = jb + LPN + li;
+            w_n = jn < j1 ? colidx[jn] : 0;
+            x_n = jn < j1 ? vals[jn] : 0.f;
             const int cnt = min(LPN, j1 - jb);
-            for (int s = 0; s < cnt; ++s) {
-                const int w = __shfl(w_l, s, LPN);
-                const float x = __shfl(x_l, s, LPN);
-                float4 pz[CH];
-                float dot = 0.f;
-                if (FROM_P) {
-                    load_chunks<LPN, CH>(P + (i64)(jb + s) * kp, li, kp, pz);
-                    if (WANT_LL) {
-                        float4 vt[CH], keep[CH];
-                        float unth;
-                        load_chunks<LPN, CH>(Vt + (i64)w * kp, li, kp, vt);
-                        products<CH, true>(u, vt, thresh, keep, unth);
-                        dot = group_sum<LPN>(unth);
-                    }
-                } else {
-                    float4 vt[CH];
-                    float unth;
-                    load_chunks<LPN, CH>(Vt + (i64)w * kp, li, kp, vt);
-                    const float part = products<CH, WANT_LL>(u, vt, thresh, pz, unth);
-                    const float norm = group_sum<LPN>(part);
-                    if (WANT_LL) dot = group_sum<LPN>(unth);
-                    const float inv = norm > 0.f ? 1.0f / norm : 0.f;
+            for (int s0 = 0; s0 < cnt; s0 += UNR) {
+                float4 a[UNR][CH];   // Vt rows (fused) or P rows (FROM_P)
+                float x[UNR];
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        pz[j].x *= inv; pz[j].y *= inv; pz[j].z *= inv; pz[j].w *= inv;
-                    }
+                for (int q = 0; q < UNR; ++q) {
+                    const int w = __shfl(w_l, s0 + q, LPN);
+                    x[q] = __shfl(x_l, s0 + q, LPN);
+                    if (FROM_P) load_row<S, false>(P + (i64)min(jb + s0 + q, j1 - 1) * kp, li, kp, a[q]);
+                    else load_row<S, false>(Vt + (i64)w * kp, li, kp, a[q]);
                 }
-                if (WANT_LL && li == 0) ll += (double)(x * logf(dot) * swd);
 #pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    float4 sv;  // s = x * P(z|w,d)        plsa.py:188
-                    sv.x = x * pz[j].x; sv.y = x * pz[j].y; sv.z = x * pz[j].z; sv.w = x * pz[j].w;
-                    acc[j].x += sv.x; acc[j].y += sv.y; acc[j].z += sv.z; acc[j].w += sv.w;
-                    if (ATOMIC_V) {
-                        const int c4 = 4 * (li + LPN * j);
-                        if (c4 < kp) {
-                            float *dst = Vt_new + (i64)w * kp + c4;
-                            sv.x *= swd; sv.y *= swd; sv.z *= swd; sv.w *= swd;  // plsa.py:294
-                            atomicAdd(dst + 0, sv.x);
-                            atomicAdd(dst + 1, sv.y);
-                            atomicAdd(dst + 2, sv.z);
-                            atomicAdd(dst + 3, sv.w);
+                for (int q = 0; q < UNR; ++q) {
+                    float4 pz[CH];
+                    if (FROM_P) {
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) pz[j] = S::ok(li, j, kp) ? a[q][j] : zero4();
+                    } else {
+                        float unth;
+                        const float part = products<CH, WANT_LL>(u, a[q], thresh, pz, unth);
+                        const float norm = group_sum<LPN>(part);
+                        if (WANT_LL) {
+                            const float dot = group_sum<LPN>(unth);
+                            if (li == 0 && s0 + q < cnt) ll += (double)(x[q] * logf(dot) * swd);
                         }
+                        scale<CH>(pz, inv_norm(norm));
+                    }
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {   // s = x * P(z|w,d); U[d,z] += s   plsa.py:188-191
+                        acc[j].x += x[q] * pz[j].x; acc[j].y += x[q] * pz[j].y;
+                        acc[j].z += x[q] * pz[j].z; acc[j].w += x[q] * pz[j].w;
                     }
                 }
             }
@@ -229,11 +268,10 @@ __global__ __launch_bounds__(256) void k_row_pass(const int *__restrict__ indptr
         if (norm_pdz_out && li == 0) norm_pdz_out[d] = rown;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const int c4 = 4 * (li + LPN * j);
-            if (c4 < kp) {
+            if (S::ok(li, j, kp)) {
                 float4 o = acc[j];
                 if (rown > 0.f) { o.x /= rown; o.y /= rown; o.z /= rown; o.w /= rown; }
-                st4(U_new + (i64)d * kp + c4, o);
+                st4(U_new + (i64)d * kp + S::c4(li, j), o);
             }
         }
     }
@@ -251,15 +289,18 @@ __global__ __launch_bounds__(256) void k_row_pass(const int *__restrict__ indptr
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_col_pass: vocabulary-owned half of the M-step without atomics (PLSA_DETERMINISTIC).  The
+// k_col_pass: vocabulary-owned half of the M-step (plsa.py:190/296, 193/299) without atomics.  The
 // active matrix is also held column-major (CSC: colptr, csc_row, csc_val, csc_pos = position of the
 // entry in CSR order).  Long columns (Zipf head words) are cut into items of at most SEG entries;
 // a group owns one item, accumulates x * P(z|w,d) [* sample_weight] in registers and writes one
-// partial k-vector; k_col_reduce adds the partials of a column in item order.
-// FROM_P = false recomputes the responsibilities from U (gather) and Vt (registers).
+// partial k-vector; k_col_reduce* add the partials of a column in item order (bit-reproducible).
+// Items are visited through `item_order` (ascending first document) so that the groups running
+// concurrently gather from the same band of U rows.  FROM_P = false recomputes the
+// responsibilities from U (gather) and Vt (registers).
 // ------------------------------------------------------------------------------------------------
-template <int LPN, int CH, bool FROM_P>
-__global__ __launch_bounds__(256) void k_col_pass(const int *__restrict__ item_col,
+template <class S, bool FROM_P>
+__global__ __launch_bounds__(256) void k_col_pass(const int *__restrict__ item_order,
+                                                  const int *__restrict__ item_col,
                                                   const int *__restrict__ item_start,
                                                   const int *__restrict__ colptr, i64 n_items,
                                                   int seg, const int *__restrict__ csc_row,
@@ -269,102 +310,159 @@ __global__ __launch_bounds__(256) void k_col_pass(const int *__restrict__ item_c
                                                   const float *__restrict__ Vt,
                                                   const float *__restrict__ P,
                                                   const float *__restrict__ sw,
-                                                  float *__restrict__ partial, int kp, float thresh) {
+                                                  float *__restrict__ partial, int kp_rt, float thresh) {
+    constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR_COL;
     constexpr int GPB = 256 / LPN;
+    const int kp = S::kp(kp_rt);
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
-    for (i64 it = (i64)blockIdx.x * GPB + gid; it < n_items; it += (i64)gridDim.x * GPB) {
+    for (i64 io = (i64)blockIdx.x * GPB + gid; io < n_items; io += (i64)gridDim.x * GPB) {
+        const int it = item_order ? item_order[io] : (int)io;
         const int w = item_col[it];
         const int j0 = item_start[it];
         const int j1 = min(j0 + seg, colptr[w + 1]);
         float4 vt[CH], acc[CH];
-        if (!FROM_P) load_chunks<LPN, CH>(Vt + (i64)w * kp, li, kp, vt);
+        load_row<S, true>(Vt + (i64)w * kp, li, kp, vt);
 #pragma unroll
-        for (int j = 0; j < CH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < CH; ++j) acc[j] = zero4();
+        int d_n = (j0 + li < j1) ? csc_row[j0 + li] : 0;
+        float x_n = (j0 + li < j1) ? csc_val[j0 + li] : 0.f;
+        int p_n = (FROM_P && j0 + li < j1) ? csc_pos[j0 + li] : 0;
         for (int jb = j0; jb < j1; jb += LPN) {
-            const int jm = jb + li;
-            const int d_l = jm < j1 ? csc_row[jm] : 0;
-            const float x_l = jm < j1 ? csc_val[jm] : 0.f;
-            const int p_l = (FROM_P && jm < j1) ? csc_pos[jm] : 0;
+            const int d_l = d_n, p_l = p_n;
+            float x_l = x_n;
+            const int jn = jb + LPN + li;
+            d_n = jn < j1 ? csc_row[jn] : 0;
+            x_n = jn < j1 ? csc_val[jn] : 0.f;
+            if (FROM_P) p_n = jn < j1 ? csc_pos[jn] : 0;
+            if (sw) x_l *= sw[d_l];  // t = s * sample_weight[d]  (plsa.py:294), folded into the count
             const int cnt = min(LPN, j1 - jb);
-            for (int s = 0; s < cnt; ++s) {
-                const int d = __shfl(d_l, s, LPN);
-                float x = __shfl(x_l, s, LPN);
-                float4 pz[CH];
-                if (FROM_P) {
-                    const int pos = __shfl(p_l, s, LPN);
-                    load_chunks<LPN, CH>(P + (i64)pos * kp, li, kp, pz);
-                } else {
-                    float4 u[CH];
-                    float unth;
-                    load_chunks<LPN, CH>(U + (i64)d * kp, li, kp, u);
-                    const float norm = group_sum<LPN>(products<CH, false>(u, vt, thresh, pz, unth));
-                    const float inv = norm > 0.f ? 1.0f / norm : 0.f;
+            for (int s0 = 0; s0 < cnt; s0 += UNR) {
+                float4 a[UNR][CH];   // U rows (fused) or P rows (FROM_P)
+                float x[UNR];
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        pz[j].x *= inv; pz[j].y *= inv; pz[j].z *= inv; pz[j].w *= inv;
+                for (int q = 0; q < UNR; ++q) {
+                    x[q] = __shfl(x_l, s0 + q, LPN);
+                    if (FROM_P) {
+                        const int pos = __shfl(p_l, s0 + q, LPN);
+                        load_row<S, false>(P + (i64)pos * kp, li, kp, a[q]);
+                    } else {
+                        const int d = __shfl(d_l, s0 + q, LPN);
+                        load_row<S, false>(U + (i64)d * kp, li, kp, a[q]);
                     }
                 }
-                const float swd = sw ? sw[d] : 1.0f;  // x1.0f is exact: one path for plsa.py:188 and :293
 #pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    float4 sv;
-                    sv.x = x * pz[j].x; sv.y = x * pz[j].y; sv.z = x * pz[j].z; sv.w = x * pz[j].w;
-                    sv.x *= swd; sv.y *= swd; sv.z *= swd; sv.w *= swd;
-                    acc[j].x += sv.x; acc[j].y += sv.y; acc[j].z += sv.z; acc[j].w += sv.w;
+                for (int q = 0; q < UNR; ++q) {
+                    float4 pz[CH];
+                    if (FROM_P) {
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) pz[j] = S::ok(li, j, kp) ? a[q][j] : zero4();
+                    } else {
+                        float unth;
+                        const float norm = group_sum<LPN>(products<CH, false>(a[q], vt, thresh, pz, unth));
+                        scale<CH>(pz, inv_norm(norm));
+                    }
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        acc[j].x += x[q] * pz[j].x; acc[j].y += x[q] * pz[j].y;
+                        acc[j].z += x[q] * pz[j].z; acc[j].w += x[q] * pz[j].w;
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int c4 = 4 * (li + LPN * j);
-            if (c4 < kp) st4(partial + it * kp + c4, acc[j]);
-        }
+        for (int j = 0; j < CH; ++j)
+            if (S::ok(li, j, kp)) st4(partial + (i64)it * kp + S::c4(li, j), acc[j]);
     }
 }
 
-// adds the item partials of each column (fixed order) into the un-normalised Vt_new.
-template <int LPN, int CH>
+// adds the item partials of each column (fixed order) into the un-normalised Vt_new.  Columns with
+// more than `heavy_items` items (the Zipf head) are left to k_col_reduce_heavy.
+template <class S>
 __global__ __launch_bounds__(256) void k_col_reduce(const int *__restrict__ item_first, int m,
+                                                    int heavy_items,
                                                     const float *__restrict__ partial,
-                                                    float *__restrict__ Vt_new, int kp) {
+                                                    float *__restrict__ Vt_new, int kp_rt) {
+    constexpr int LPN = S::LPN, CH = S::CH;
     constexpr int GPB = 256 / LPN;
+    const int kp = S::kp(kp_rt);
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
     for (i64 c = (i64)blockIdx.x * GPB + gid; c < m; c += (i64)gridDim.x * GPB) {
         const int i0 = item_first[c], i1 = item_first[c + 1];
+        if (i1 - i0 > heavy_items) continue;
         float4 acc[CH];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < CH; ++j) acc[j] = zero4();
         for (int it = i0; it < i1; ++it) {
             float4 p[CH];
-            load_chunks<LPN, CH>(partial + (i64)it * kp, li, kp, p);
+            load_row<S, true>(partial + (i64)it * kp, li, kp, p);
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 acc[j].x += p[j].x; acc[j].y += p[j].y; acc[j].z += p[j].z; acc[j].w += p[j].w;
             }
         }
 #pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (S::ok(li, j, kp)) st4(Vt_new + c * kp + S::c4(li, j), acc[j]);
+    }
+}
+
+// one block per heavy column: the block's groups stride over the column's items (fixed assignment),
+// then their sums are added in group order through LDS -> bit-reproducible.
+template <class S>
+__global__ __launch_bounds__(256) void k_col_reduce_heavy(const int *__restrict__ heavy_cols,
+                                                          const int *__restrict__ item_first,
+                                                          const float *__restrict__ partial,
+                                                          float *__restrict__ Vt_new, int kp_rt) {
+    constexpr int LPN = S::LPN, CH = S::CH;
+    constexpr int GPB = 256 / LPN;
+    extern __shared__ float sacc[];  // [GPB][kp]
+    const int kp = S::kp(kp_rt);
+    const int li = threadIdx.x % LPN;
+    const int gid = threadIdx.x / LPN;
+    const int c = heavy_cols[blockIdx.x];
+    const int i0 = item_first[c], i1 = item_first[c + 1];
+    float4 acc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] = zero4();
+    for (int it = i0 + gid; it < i1; it += GPB) {
+        float4 p[CH];
+        load_row<S, true>(partial + (i64)it * kp, li, kp, p);
+#pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const int c4 = 4 * (li + LPN * j);
-            if (c4 < kp) st4(Vt_new + c * kp + c4, acc[j]);
+            acc[j].x += p[j].x; acc[j].y += p[j].y; acc[j].z += p[j].z; acc[j].w += p[j].w;
         }
     }
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+        if (S::ok(li, j, kp)) st4(sacc + gid * kp + S::c4(li, j), acc[j]);
+    __syncthreads();
+    for (int z = threadIdx.x; z < kp; z += 256) {
+        float t = 0.f;
+        for (int g = 0; g < GPB; ++g) t += sacc[g * kp + z];
+        Vt_new[(i64)c * kp + z] = t;
+    }
+}
+
+__global__ void k_heavy_list(const int *__restrict__ item_first, int m, int heavy_items,
+                             int *__restrict__ heavy_cols, int *__restrict__ n_heavy) {
+    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m && item_first[c + 1] - item_first[c] > heavy_items)
+        heavy_cols[atomicAdd(n_heavy, 1)] = (int)c;
 }
 
 // ------------------------------------------------------------------------------------------------
 // P(w|z) normalisation, plsa.py:196-199: norm_pwz[z] = sum_w Vt_new[w,z], then divide.
 //   k_colsum_partial : NORM_BLOCKS blocks, each sums a contiguous slab of words -> partials (f64)
 //   k_v_normalise    : every block re-adds the NORM_BLOCKS partials (fixed order) into LDS, divides
-//                      its slab, writes the normalised topics into Vt and (optionally) re-zeroes
-//                      the accumulator for the next atomic pass.
+//                      its slab and writes the normalised topics into Vt.
 // ------------------------------------------------------------------------------------------------
 constexpr int NORM_BLOCKS = 256;
 
 __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ Vt_new, int m,
                                                         int kp, double *__restrict__ partials) {
-    // thread t owns column z = t % kp for rows t / kp, t / kp + rows_per_pass, ...  (kp <= 256)
-    // for kp > 256 the thread loops over z as well.
+    // thread t owns column z = t % span for rows t / span, t / span + rows_per_pass, ...
     extern __shared__ double sred[];  // [256]
     const i64 per = ((i64)m + gridDim.x - 1) / gridDim.x;
     const i64 w0 = (i64)blockIdx.x * per, w1 = min((i64)m, w0 + per);
@@ -387,11 +485,10 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_v_normalise(float *__restrict__ Vt_new,
+__global__ __launch_bounds__(256) void k_v_normalise(const float *__restrict__ Vt_new,
                                                      float *__restrict__ Vt, int m, int kp,
                                                      const double *__restrict__ partials,
-                                                     int n_partials, float *__restrict__ norm_pwz,
-                                                     int rezero) {
+                                                     int n_partials, float *__restrict__ norm_pwz) {
     extern __shared__ float snorm[];  // [kp]
     for (int z = threadIdx.x; z < kp; z += 256) {
         double tot = 0.0;
@@ -411,7 +508,6 @@ __global__ __launch_bounds__(256) void k_v_normalise(float *__restrict__ Vt_new,
         if (n2 > 0.f) v.z /= n2;
         if (n3 > 0.f) v.w /= n3;
         st4(Vt + i * 4, v);
-        if (rezero) st4(Vt_new + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
     }
 }
 
@@ -430,41 +526,54 @@ __global__ void k_ll_final(const double *__restrict__ partials, int nb, double *
 }
 
 // standalone log-likelihood, plsa.py:375-384 (row-owned; same traversal as k_row_pass)
-template <int LPN, int CH>
+template <class S>
 __global__ __launch_bounds__(256) void k_loglik(const int *__restrict__ indptr,
                                                 const int *__restrict__ colidx,
                                                 const float *__restrict__ vals, int n,
+                                                const int *__restrict__ row_order,
                                                 const float *__restrict__ U,
                                                 const float *__restrict__ Vt,
-                                                const float *__restrict__ sw, int kp,
+                                                const float *__restrict__ sw, int kp_rt,
                                                 double *__restrict__ ll_partials) {
+    constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR;
     constexpr int GPB = 256 / LPN;
+    const int kp = S::kp(kp_rt);
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
     double ll = 0.0;
     for (i64 r = (i64)blockIdx.x * GPB + gid; r < n; r += (i64)gridDim.x * GPB) {
-        const int d = (int)r;
+        const int d = row_order ? row_order[r] : (int)r;
         const int j0 = indptr[d], j1 = indptr[d + 1];
         float4 u[CH];
-        load_chunks<LPN, CH>(U + (i64)d * kp, li, kp, u);
-        const float swd = sw ? sw[d] : 1.0f;  // x1.0f is exact: one path for plsa.py:188 and :293
+        load_row<S, true>(U + (i64)d * kp, li, kp, u);
+        const float swd = sw ? sw[d] : 1.0f;
+        int w_n = (j0 + li < j1) ? colidx[j0 + li] : 0;
+        float x_n = (j0 + li < j1) ? vals[j0 + li] : 0.f;
         for (int jb = j0; jb < j1; jb += LPN) {
-            const int jm = jb + li;
-            const int w_l = jm < j1 ? colidx[jm] : 0;
-            const float x_l = jm < j1 ? vals[jm] : 0.f;
+            const int w_l = w_n;
+            const float x_l = x_n;
+            const int jn = jb + LPN + li;
+            w_n = jn < j1 ? colidx[jn] : 0;
+            x_n = jn < j1 ? vals[jn] : 0.f;
             const int cnt = min(LPN, j1 - jb);
-            for (int s = 0; s < cnt; ++s) {
-                const int w = __shfl(w_l, s, LPN);
-                const float x = __shfl(x_l, s, LPN);
-                float4 vt[CH];
-                load_chunks<LPN, CH>(Vt + (i64)w * kp, li, kp, vt);
-                float part = 0.f;
+            for (int s0 = 0; s0 < cnt; s0 += UNR) {
+                float4 vt[UNR][CH];
+                float x[UNR];
 #pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    part += (vt[j].x * u[j].x + vt[j].y * u[j].y) + (vt[j].z * u[j].z + vt[j].w * u[j].w);
+                for (int q = 0; q < UNR; ++q) {
+                    const int w = __shfl(w_l, s0 + q, LPN);
+                    x[q] = __shfl(x_l, s0 + q, LPN);
+                    load_row<S, false>(Vt + (i64)w * kp, li, kp, vt[q]);
                 }
-                const float dot = group_sum<LPN>(part);
-                if (li == 0) ll += (double)(x * logf(dot) * swd);
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) {
+                    float part = 0.f;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+                        part += (vt[q][j].x * u[j].x + vt[q][j].y * u[j].y) + (vt[q][j].z * u[j].z + vt[q][j].w * u[j].w);
+                    const float dot = group_sum<LPN>(part);
+                    if (li == 0 && s0 + q < cnt) ll += (double)(x[q] * logf(dot) * swd);
+                }
             }
         }
     }
@@ -490,6 +599,12 @@ __global__ void k_expand_rows(const int *__restrict__ indptr, int n, int *__rest
         const int j0 = indptr[d], j1 = indptr[d + 1];
         for (int j = j0 + lane; j < j1; j += 64) rowidx[j] = (int)d;
     }
+}
+
+__global__ void k_row_lengths(const int *__restrict__ indptr, int n, int *__restrict__ len,
+                              int *__restrict__ ids) {
+    const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) { len[r] = indptr[r + 1] - indptr[r]; ids[r] = (int)r; }
 }
 
 // V [k,m] (reference layout) -> Vt [m,kp] (device layout), 32x32 tiles through LDS
@@ -577,21 +692,35 @@ __global__ void k_item_counts(const int *__restrict__ colptr, int m, int seg, in
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m) cnt[c] = (colptr[c + 1] - colptr[c] + seg - 1) / seg;
 }
+// item arrays + the first document of every item (sort key of the doc-band-major visiting order)
 __global__ void k_item_fill(const int *__restrict__ colptr, const int *__restrict__ item_first, int m,
-                            int seg, int *__restrict__ item_col, int *__restrict__ item_start) {
+                            int seg, const int *__restrict__ csc_row, int *__restrict__ item_col,
+                            int *__restrict__ item_start, int *__restrict__ item_doc0,
+                            int *__restrict__ item_id) {
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m) {
         const int i0 = item_first[c], i1 = item_first[c + 1];
         for (int i = i0; i < i1; ++i) {
+            const int st = colptr[c] + (i - i0) * seg;
             item_col[i] = (int)c;
-            item_start[i] = colptr[c] + (i - i0) * seg;
+            item_start[i] = st;
+            item_doc0[i] = csc_row[st];
+            item_id[i] = i;
         }
     }
 }
 
-__global__ void k_fill_zero4(float *__restrict__ p, i64 n4) {
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (i64)gridDim.x * blockDim.x)
-        st4(p + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+// streaming-bandwidth probes (measurement only): fill with plain / non-temporal stores, copy
+template <bool NT>
+__global__ __launch_bounds__(256) void k_probe_fill(float *__restrict__ p, i64 n4) {
+    const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n4; i += (i64)gridDim.x * 256) {
+        if (NT) st4_nt(p + i * 4, v); else st4(p + i * 4, v);
+    }
+}
+__global__ __launch_bounds__(256) void k_probe_copy(const float *__restrict__ a, float *__restrict__ b, i64 n4) {
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n4; i += (i64)gridDim.x * 256)
+        st4(b + i * 4, ld4(a + i * 4));
 }
 
 }  // namespace plsa

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import PLSA_DETERMINISTIC, PLSA_FUSED, PLSA_TRACE_LL, ptr
+from ._lib import PLSA_FUSED, PLSA_TRACE_LL, ptr
 
 
 class DeviceError(RuntimeError):
@@ -23,12 +23,9 @@ def default_device():
 
 
 def default_flags():
-    """Fit schedule: fused (no nnz x k materialisation) unless ENSTOP_AMD_MATERIALISE=1;
-    atomic-free column-owned P(w|z) update when ENSTOP_AMD_DETERMINISTIC=1."""
-    flags = 0 if os.environ.get("ENSTOP_AMD_MATERIALISE", "0") == "1" else PLSA_FUSED
-    if os.environ.get("ENSTOP_AMD_DETERMINISTIC", "0") == "1":
-        flags |= PLSA_DETERMINISTIC
-    return flags
+    """Fit schedule: fused (P(z|w,d) never touches HBM) unless ENSTOP_AMD_MATERIALISE=1, which
+    follows the reference's E-step -> M-step kernel sequence through a materialised nnz x k array."""
+    return 0 if os.environ.get("ENSTOP_AMD_MATERIALISE", "0") == "1" else PLSA_FUSED
 
 
 def _f32(a):
@@ -156,12 +153,12 @@ class Engine:
     def set_p(self, P):
         self._ok(self._L.plsa_set_p(self._h, _f32(P)))
 
-    def m_step(self, sample_weight=None, update_v=True, deterministic=False):
+    def m_step(self, sample_weight=None, update_v=True):
         n, _, _ = self.shape
         sw = None if sample_weight is None else _f32(sample_weight)
         npwz = np.zeros(self.k, np.float32)
         npdz = np.zeros(n, np.float32)
-        self._ok(self._L.plsa_m_step(self._h, ptr(sw), int(update_v), int(deterministic), ptr(npwz), ptr(npdz)))
+        self._ok(self._L.plsa_m_step(self._h, ptr(sw), int(update_v), ptr(npwz), ptr(npdz)))
         return npwz, npdz
 
     def log_likelihood(self, sample_weight=None):
@@ -204,6 +201,12 @@ class Engine:
         ms, n = C.c_double(0.0), C.c_int64(0)
         self._ok(self._L.plsa_timing_get(self._h, prefix.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def stream_bandwidth(self, nbytes=1 << 32, kind=0, reps=5):
+        """GB/s of a fill (kind 0 non-temporal, 1 plain) or copy (2) over `nbytes` of scratch HBM."""
+        out = C.c_double(0.0)
+        self._ok(self._L.plsa_measure_stream_bandwidth(self._h, int(nbytes), int(kind), int(reps), C.byref(out)))
+        return out.value
 
     def timing_report(self):
         buf = C.create_string_buffer(8192)

@@ -68,11 +68,11 @@ def plsa_e_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd,
 
 
 def _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, sample_weight,
-            norm_pwz, norm_pdz, update_v, device, deterministic):
+            norm_pwz, norm_pdz, update_v, device):
     eng, order = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device)
     P = np.asarray(p_z_given_wd, np.float32)
     eng.set_p(P if order is None else P[order])
-    npwz, npdz = eng.m_step(sample_weight, update_v=update_v, deterministic=deterministic)
+    npwz, npdz = eng.m_step(sample_weight, update_v=update_v)
     U, V = eng.get_factors(want_v=update_v)
     p_z_given_d[...] = U
     if update_v:
@@ -85,17 +85,17 @@ def _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, samp
 
 
 def plsa_m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, norm_pwz, norm_pdz,
-                device=None, deterministic=False):
+                device=None):
     """New P(w|z), P(z|d) from P(z|w,d); overwrites both factor arrays in place and returns them."""
     return _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, None, norm_pwz,
-                   norm_pdz, True, device, deterministic)
+                   norm_pdz, True, device)
 
 
 def plsa_m_step_w_sample_weight(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd,
-                                sample_weight, norm_pwz, norm_pdz, device=None, deterministic=False):
+                                sample_weight, norm_pwz, norm_pdz, device=None):
     """As plsa_m_step with per-document weights entering P(w|z) only (plsa.py:293-300)."""
     return _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, sample_weight,
-                   norm_pwz, norm_pdz, True, device, deterministic)
+                   norm_pwz, norm_pdz, True, device)
 
 
 def plsa_refit_m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, sample_weight,
@@ -103,7 +103,7 @@ def plsa_refit_m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_give
     """M-step for P(z|d) only, topics frozen; `sample_weight` is accepted and unused exactly like
     the reference (plsa.py:801-814)."""
     return _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, None, None,
-                   norm_pdz, False, device, False)
+                   norm_pdz, False, device)
 
 
 def log_likelihood(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, sample_weight, device=None):
@@ -193,7 +193,7 @@ def plsa_fit(X, k, sample_weight, init="random", n_iter=100, n_iter_per_test=10,
              e_step_thresh=1e-32, random_state=None, device=None, flags=None, return_info=False):
     """Fit pLSA with k topics to the sparse doc-term matrix X; returns (P(z|d) [n,k], P(w|z) [k,m]),
     both float32 (plsa.py:643-730).  Extra keyword arguments select the device and the kernel
-    schedule (fused / materialised / deterministic); positional compatibility is unchanged."""
+    schedule (fused / materialised); positional compatibility is unchanged."""
     if not issparse(X):
         X = csr_matrix(X)
     eng = get_engine(device)
@@ -248,7 +248,7 @@ class PLSA(BaseEstimator, TransformerMixin):
     """Probabilistic Latent Semantic Analysis with the reference estimator's constructor, methods
     and fitted attributes (enstop/plsa.py:1000-1285): `components_` = P(w|z) [k, m],
     `embedding_` = P(z|d) [n, k], `training_data_`.  Additive: `n_iter_` (EM iterations run),
-    and the `device` / `deterministic` constructor keywords at the end of the signature.
+    and the `device` constructor keyword at the end of the signature.
 
     Conscious deviations from reference defects: float input detection works on
     current NumPy (the reference's `np.float` raises); `sample_weight` is restricted to the
@@ -257,7 +257,7 @@ class PLSA(BaseEstimator, TransformerMixin):
 
     def __init__(self, n_components=10, init="random", n_iter=100, n_iter_per_test=10,
                  tolerance=0.001, e_step_thresh=1e-32, transform_random_seed=42, random_state=None,
-                 device=None, deterministic=False):
+                 device=None):
         self.n_components = n_components
         self.init = init
         self.n_iter = n_iter
@@ -267,11 +267,10 @@ class PLSA(BaseEstimator, TransformerMixin):
         self.transform_random_seed = transform_random_seed
         self.random_state = random_state
         self.device = device
-        self.deterministic = deterministic
 
     def _flags(self):
-        from .engine import PLSA_DETERMINISTIC, default_flags
-        return default_flags() | (PLSA_DETERMINISTIC if self.deterministic else 0)
+        from .engine import default_flags
+        return default_flags()
 
     def fit(self, X, y=None, sample_weight=None):
         self.fit_transform(X, sample_weight=sample_weight)

@@ -32,11 +32,9 @@ typedef struct plsa_ctx plsa_ctx;
 
 /* plsa_fit()/plsa_refit() `flags` */
 enum {
-    PLSA_FUSED         = 1, /* never materialise P(z|w,d) (idea of enstop/streamed_plsa.py:341-375) */
-    PLSA_DETERMINISTIC = 2, /* P(w|z) update by column ownership over a CSC copy: no float atomics,
-                               bit-reproducible run to run and across devices                      */
-    PLSA_TRACE_LL      = 4  /* also evaluate the log-likelihood test of the last iteration when it
-                               cannot change the result (only to fill ll_trace like plsa.py:631)    */
+    PLSA_FUSED     = 1, /* never materialise P(z|w,d) (idea of enstop/streamed_plsa.py:341-375)     */
+    PLSA_TRACE_LL  = 4  /* also evaluate the log-likelihood test of the last iteration when it
+                           cannot change the result (only to fill ll_trace like plsa.py:631)        */
 };
 
 /* ---- lifetime / errors ----------------------------------------------------------------------- */
@@ -81,14 +79,14 @@ int plsa_copy_components_to_device(plsa_ctx *ctx, void *dst_device_km);
  *                       <- plsa_m_step_w_sample_weight  enstop/plsa.py:221-310 (sw != NULL)
  *                       <- plsa_refit_m_step            enstop/plsa.py:746-816 (update_v == 0)
  *   consumes the device-resident P; overwrites the factors; norms (nullable) receive norm_pwz[k]
- *   and norm_pdz[n].  deterministic != 0 selects the column-owned (atomic-free) P(w|z) update.
+ *   and norm_pdz[n].  P(w|z) is updated by column ownership over a CSC copy of X (no atomics,
+ *   bit-reproducible); a float-atomic scatter was measured 17x slower on MI355X.
  * plsa_log_likelihood   <- log_likelihood               enstop/plsa.py:329-386
  *   sw == NULL means all-ones.  Accumulated in float64 on the device; the reference returns float32
  *   (callers cast).                                                                               */
 int plsa_e_step(plsa_ctx *ctx, float thresh, float *P_out);
 int plsa_set_p(plsa_ctx *ctx, const float *P);
-int plsa_m_step(plsa_ctx *ctx, const float *sw, int32_t update_v, int32_t deterministic,
-                float *norm_pwz, float *norm_pdz);
+int plsa_m_step(plsa_ctx *ctx, const float *sw, int32_t update_v, float *norm_pwz, float *norm_pdz);
 int plsa_log_likelihood(plsa_ctx *ctx, const float *sw, double *ll);
 
 /* ---- EM drivers ---------------------------------------------------------------------------------
@@ -115,6 +113,10 @@ int plsa_timing_reset(plsa_ctx *ctx);
 int plsa_timing_get(plsa_ctx *ctx, const char *prefix, double *total_ms, int64_t *launches);
 /* newline-separated "name launches total_ms" report into buf. */
 int plsa_timing_report(plsa_ctx *ctx, char *buf, int64_t cap);
+/* achievable streaming bandwidth of this device, GB/s, over `bytes` of scratch HBM:
+ * kind 0 = fill with non-temporal stores, 1 = fill with plain stores, 2 = copy (bytes read + bytes
+ * written counted).  The practical ceiling the E-step's P write is compared with.   */
+int plsa_measure_stream_bandwidth(plsa_ctx *ctx, int64_t bytes, int32_t kind, int32_t reps, double *gbps);
 
 /* ---- host helper ---------------------------------------------------------------------------------
  * plsa_host_normalize_rows <- enstop/utils.py:8-41 normalize(ndarray, axis=1): float64, in place,

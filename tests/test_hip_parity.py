@@ -14,8 +14,8 @@ from conftest import load_golden, golden_csr, coo_arrays
 
 pytestmark = pytest.mark.gpu
 
-FUSED, DET = 1, 2
-MODES = {"materialised": 0, "materialised+det": DET, "fused": FUSED, "fused+det": FUSED | DET}
+FUSED = 1
+MODES = {"materialised": 0, "fused": FUSED}
 KERNEL_CASES = ["kernels_k6", "kernels_k8_thresh", "kernels_k20", "kernels_k33"]
 FIT_CASES = ["fit_k8_tol0", "fit_k5_earlystop", "fit_k4_weighted", "fit_k8_thresh",
              "fit_k6_tupleinit", "fit_k16_mid", "fit_k20_50it"]
@@ -58,22 +58,21 @@ def test_e_step_vs_reference(amd, case):
     np.testing.assert_allclose(P, g["P"], rtol=2e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize("deterministic", [False, True])
 @pytest.mark.parametrize("case", KERNEL_CASES)
-def test_m_steps_vs_reference(amd, case, deterministic):
+def test_m_steps_vs_reference(amd, case):
     g = load_golden(case)
     r, c, v = coo_arrays(golden_csr(g))
     n, k = g["U"].shape
     V, U = g["V"].copy(), g["U"].copy()
     a, b = np.zeros(k, np.float32), np.zeros(n, np.float32)
-    amd.plsa_m_step(r, c, v, V, U, g["P"], a, b, deterministic=deterministic)
+    amd.plsa_m_step(r, c, v, V, U, g["P"], a, b)
     np.testing.assert_allclose(V, g["V_m"], rtol=3e-6, atol=1e-9)
     np.testing.assert_allclose(U, g["U_m"], rtol=3e-6, atol=1e-9)
     np.testing.assert_allclose(a, g["norm_pwz"], rtol=3e-6)
     np.testing.assert_allclose(b, g["norm_pdz"], rtol=3e-6)
 
     V, U = g["V"].copy(), g["U"].copy()
-    amd.plsa_m_step_w_sample_weight(r, c, v, V, U, g["P"], g["sw"], a, b, deterministic=deterministic)
+    amd.plsa_m_step_w_sample_weight(r, c, v, V, U, g["P"], g["sw"], a, b)
     np.testing.assert_allclose(V, g["V_mw"], rtol=3e-6, atol=1e-9)
     np.testing.assert_allclose(U, g["U_mw"], rtol=3e-6, atol=1e-9)
     np.testing.assert_allclose(a, g["norm_pwz_w"], rtol=3e-6)
@@ -249,11 +248,10 @@ def test_kernels_vs_oracle_midsize(amd, oracle, k):
     ones = np.ones(n, np.float32)
     Vo, Uo = V.copy(), U.copy()
     oracle.plsa_m_step(r, c, v, Vo, Uo, Po, np.zeros(k, np.float32), np.zeros(n, np.float32))
-    for det in (False, True):
-        Vh, Uh = V.copy(), U.copy()
-        amd.plsa_m_step(r, c, v, Vh, Uh, Po, np.zeros(k, np.float32), np.zeros(n, np.float32), deterministic=det)
-        np.testing.assert_allclose(Uh, Uo, rtol=2e-5, atol=1e-9)
-        np.testing.assert_allclose(Vh, Vo, rtol=2e-5, atol=1e-9)
+    Vh, Uh = V.copy(), U.copy()
+    amd.plsa_m_step(r, c, v, Vh, Uh, Po, np.zeros(k, np.float32), np.zeros(n, np.float32))
+    np.testing.assert_allclose(Uh, Uo, rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(Vh, Vo, rtol=2e-5, atol=1e-9)
     close_ll(np.array([amd.log_likelihood(r, c, v, Vo, Uo, ones)]),
              np.array([oracle.log_likelihood(r, c, v, Vo, Uo, ones)]))
 
@@ -281,17 +279,18 @@ def test_properties_large_synthetic(amd):
             np.testing.assert_allclose(Vf.sum(1, dtype=np.float64), 1.0, atol=2e-4)
             assert Uf.min() >= 0.0 and Vf.min() >= 0.0
             results[name] = (Uf, Vf, ll)
-        base = results["materialised+det"]
+        base = results["materialised"]
         for name, (Uf, Vf, ll) in results.items():
             close_ll(ll, base[2])
             close_factors(Uf, base[0])
             close_factors(Vf, base[1])
-        # the atomic-free schedule is bit-reproducible
-        eng.set_factors(U.astype(np.float32), V.astype(np.float32))
-        eng.fit(None, n_iter=6, n_iter_per_test=1, tolerance=0.0, flags=FUSED | DET, trace=True)
-        U2, V2 = eng.get_factors()
-        np.testing.assert_array_equal(U2, results["fused+det"][0])
-        np.testing.assert_array_equal(V2, results["fused+det"][1])
+        # no float atomics anywhere: both schedules are bit-reproducible run to run
+        for name, flags in MODES.items():
+            eng.set_factors(U.astype(np.float32), V.astype(np.float32))
+            eng.fit(None, n_iter=6, n_iter_per_test=1, tolerance=0.0, flags=flags, trace=True)
+            U2, V2 = eng.get_factors()
+            np.testing.assert_array_equal(U2, results[name][0])
+            np.testing.assert_array_equal(V2, results[name][1])
 
 
 def test_synthetic_generator_is_canonical_and_deterministic(amd):
