@@ -119,15 +119,26 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
+    # Only the JSON line may reach stdout: route file descriptor 1 to stderr for the whole run (RCCL and
+    # the HIP runtime print banners from C) and write the result to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    force_dist = os.environ.get("PLSA_BENCH_FORCE_DIST", "0") == "1"   # exercise the RCCL path with 1 rank
+    if world > 1 or force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # torch first: its HIP runtime / RCCL are then the ones libplsa_hip.so binds to
         import torch
         import torch.distributed as dist
+        if local_rank >= torch.cuda.device_count():      # launcher restricted the visible devices
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -145,7 +156,7 @@ def main():
     info = eng.device_info()
     t_gen = time.perf_counter()
     nnz = eng.generate_synthetic(n, m, cfg["nnz"], zipf_s=1.07, seed=args.seed)
-    if world > 1:       # ensemble member `rank`: bootstrap rows on the device (enstop_.py:87-88)
+    if dist is not None:  # ensemble member `rank`: bootstrap rows on the device (enstop_.py:87-88)
         idx = np.random.RandomState(args.seed + 1000 + rank).randint(0, n, size=n)
         eng.bootstrap(idx)
     n_act, m_act, nnz_act = eng.shape
@@ -287,11 +298,14 @@ def main():
             except Exception as e:       # the baseline must never cost the GPU measurement
                 out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

@@ -5,13 +5,13 @@
 Importing is possible anywhere; any numerical call needs libplsa_hip.so (python -m
 enstop_amd.build) and a gfx950 device -- there is no CPU code path in this package.
 """
-from .plsa import (PLSA, log_likelihood, plsa_e_step, plsa_fit, plsa_fit_inner, plsa_init,
+from .plsa import (PLSA, StreamedPLSA, BlockParallelPLSA, log_likelihood, plsa_e_step, plsa_fit, plsa_fit_inner, plsa_init,
                    plsa_m_step, plsa_m_step_w_sample_weight, plsa_refit, plsa_refit_inner,
                    plsa_refit_m_step)
 from .enstop_ import ensemble_of_topics, plsa_topics
 from .engine import Engine, DeviceError, PLSA_FUSED
 
-__all__ = ["PLSA", "plsa_fit", "plsa_refit", "plsa_fit_inner", "plsa_refit_inner", "plsa_init",
+__all__ = ["PLSA", "StreamedPLSA", "BlockParallelPLSA", "plsa_fit", "plsa_refit", "plsa_fit_inner", "plsa_refit_inner", "plsa_init",
            "plsa_e_step", "plsa_m_step", "plsa_m_step_w_sample_weight", "plsa_refit_m_step",
            "log_likelihood", "plsa_topics", "ensemble_of_topics", "Engine", "DeviceError",
            "PLSA_FUSED"]

@@ -67,7 +67,8 @@ struct plsa_ctx {
     int seg = 256;
     i64 n_items = 0;
     DevBuf colptr, csc_row, csc_val, csc_pos, item_first, item_col, item_start, item_order, partial, heavy_cols;
-    bool use_item_order = true;
+    bool use_item_order = true, xcd_split = true;
+    int chunks_per_lane = 2;
     int heavy_items = 32, n_heavy = 0;
 
     // rows in descending-length order (row-owned kernels: groups of a wave finish together)
@@ -198,6 +199,7 @@ int dispatch_shape(plsa_ctx *c, Fn &&fn) {
     }
     PLSA_SHAPE(1, 1) PLSA_SHAPE(2, 1) PLSA_SHAPE(4, 1) PLSA_SHAPE(8, 1) PLSA_SHAPE(16, 1)
     PLSA_SHAPE(32, 1) PLSA_SHAPE(64, 1) PLSA_SHAPE(64, 2) PLSA_SHAPE(64, 4)
+    PLSA_SHAPE(16, 2) PLSA_SHAPE(32, 2)
 #undef PLSA_SHAPE
     return fail(c, "unsupported topic count k=%d (max 1024)", c->k);
 }
@@ -436,6 +438,7 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh) {
         const int grid = grid_for(c, c->n_items, 256 / LPN);
         const int grid2 = grid_for(c, c->m, 256 / LPN);
         const int *order = c->use_item_order ? c->item_order.as<int>() : nullptr;
+        const int xcd_split = (c->xcd_split && grid >= 64) ? 1 : 0;
         if (c->n_items > 0) {
             if (from_p) {
                 Scope s(c, "k_col_pass<P>");
@@ -443,14 +446,14 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh) {
                                    c->item_col.as<int>(), c->item_start.as<int>(), c->colptr.as<int>(),
                                    c->n_items, c->seg, c->csc_row.as<int>(), c->csc_val.as<float>(),
                                    c->csc_pos.as<int>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
-                                   c->P.as<float>(), d_sw, c->partial.as<float>(), c->kp, thresh);
+                                   c->P.as<float>(), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split);
             } else {
                 Scope s(c, "k_col_pass<fused>");
                 hipLaunchKernelGGL((plsa::k_col_pass<Sh, false>), dim3(grid), dim3(256), 0, c->stream, order,
                                    c->item_col.as<int>(), c->item_start.as<int>(), c->colptr.as<int>(),
                                    c->n_items, c->seg, c->csc_row.as<int>(), c->csc_val.as<float>(),
                                    c->csc_pos.as<int>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
-                                   c->P.as<float>(), d_sw, c->partial.as<float>(), c->kp, thresh);
+                                   c->P.as<float>(), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split);
             }
         }
         {
@@ -471,7 +474,7 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh) {
 }
 
 // Vacc -> normalised topics in Vt[1-cv]  (plsa.py:196-199)
-int run_v_normalise(plsa_ctx *c, float *d_norm_pwz) {
+int run_v_normalise(plsa_ctx *c) {
     const int nb = (int)std::min<i64>(plsa::NORM_BLOCKS, std::max<i64>(1, c->m));
     CHK(ensure(c, c->colsum_partials, sizeof(double) * (size_t)nb * c->kp));
     {
@@ -479,13 +482,18 @@ int run_v_normalise(plsa_ctx *c, float *d_norm_pwz) {
         hipLaunchKernelGGL(plsa::k_colsum_partial, dim3(nb), dim3(256), 256 * sizeof(double), c->stream,
                            c->Vacc.as<float>(), (int)c->m, c->kp, c->colsum_partials.as<double>());
     }
+    CHK(ensure(c, c->norm_pwz, sizeof(float) * (size_t)c->kp));
+    {
+        Scope s(c, "k_colsum_final");
+        hipLaunchKernelGGL(plsa::k_colsum_final, dim3(1), dim3(256), 0, c->stream,
+                           c->colsum_partials.as<double>(), nb, c->kp, c->norm_pwz.as<float>());
+    }
     {
         Scope s(c, "k_v_normalise");
         const i64 total4 = c->m * c->kp / 4;
-        hipLaunchKernelGGL(plsa::k_v_normalise, dim3(std::min(grid_for(c, total4, 256), 8 * c->prop.multiProcessorCount)), dim3(256),
+        hipLaunchKernelGGL(plsa::k_v_normalise, dim3(grid_for(c, total4, 256)), dim3(256),
                            c->kp * sizeof(float), c->stream, c->Vacc.as<float>(),
-                           c->Vt[1 - c->cv].as<float>(), (int)c->m, c->kp,
-                           c->colsum_partials.as<double>(), nb, d_norm_pwz);
+                           c->Vt[1 - c->cv].as<float>(), (int)c->m, c->kp, c->norm_pwz.as<float>());
     }
     CHK(launch_check(c, "k_v_normalise"));
     return 0;
@@ -521,12 +529,12 @@ int run_loglik(plsa_ctx *c, const float *d_sw, double *out) {
 }
 
 // one M-step from the materialised P: U[1-cu], and (update_v) Vt[1-cv]; swaps the buffers in
-int run_m_step_from_p(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_pwz, float *d_norm_pdz) {
+int run_m_step_from_p(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_pdz) {
     if (!c->p_valid) return fail(c, "plsa_m_step: no P(z|w,d) on the device (run plsa_e_step or plsa_set_p)");
     CHK(run_row_pass(c, true, false, nullptr, 0.f, d_norm_pdz, nullptr));
     if (update_v) {
         CHK(run_col_pass(c, true, d_sw, 0.f));
-        CHK(run_v_normalise(c, d_norm_pwz));
+        CHK(run_v_normalise(c));
     }
     c->cu ^= 1;
     if (update_v) c->cv ^= 1;
@@ -587,6 +595,8 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_HEAVY_ITEMS")) c->heavy_items = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_SORT_ROWS")) c->sort_rows = atoi(s) != 0;
     if (const char *s = getenv("PLSA_ITEM_ORDER")) c->use_item_order = atoi(s) != 0;
+    if (const char *s = getenv("PLSA_XCD_SPLIT")) c->xcd_split = atoi(s) != 0;
+    if (const char *s = getenv("PLSA_CHUNKS_PER_LANE")) c->chunks_per_lane = atoi(s);
     *out = c;
     return 0;
 }
@@ -732,6 +742,9 @@ int plsa_set_factors(plsa_ctx *c, const float *U, const float *V, int64_t n, int
     c->fac_n = n; c->fac_m = m;
     int lpn = 1;
     while (lpn < kp / 4 && lpn < 64) lpn *= 2;
+    // k >= 128: 8 floats per lane (two float4 chunks) -- fewer reduction/shuffle instructions per
+    // cell, each access still covers whole 128-B lines (measured: config 5 document pass -15 %)
+    if (lpn >= 32 && lpn * 4 >= kp && c->chunks_per_lane == 2) lpn /= 2;
     c->lpn = lpn;
     c->ch = (kp / 4 + lpn - 1) / lpn;
     if (c->ch == 3) c->ch = 4;
@@ -814,9 +827,8 @@ int plsa_m_step(plsa_ctx *c, const float *sw, int32_t update_v, float *norm_pwz,
     CHK(need_factors(c));
     const float *d_sw = nullptr;
     CHK(upload_sw(c, sw, &d_sw));
-    CHK(ensure(c, c->norm_pwz, sizeof(float) * (size_t)c->kp));
     CHK(ensure(c, c->norm_pdz, sizeof(float) * (size_t)c->n));
-    CHK(run_m_step_from_p(c, d_sw, update_v != 0, c->norm_pwz.as<float>(), c->norm_pdz.as<float>()));
+    CHK(run_m_step_from_p(c, d_sw, update_v != 0, c->norm_pdz.as<float>()));
     if (norm_pwz && update_v)
         HIPCHK(c, hipMemcpyAsync(norm_pwz, c->norm_pwz.p, sizeof(float) * (size_t)c->k, hipMemcpyDeviceToHost, c->stream));
     if (norm_pdz)
@@ -861,7 +873,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
     if (!fused) {
         for (int i = 0; i < n_iter; ++i) {
             CHK(run_e_step(c, thresh));                              // plsa.py:597
-            CHK(run_m_step_from_p(c, d_sw, true, nullptr, nullptr));       // plsa.py:606-628
+            CHK(run_m_step_from_p(c, d_sw, true, nullptr));       // plsa.py:606-628
             iters++;
             if (i % n_iter_per_test == 0) {                          // plsa.py:630
                 if (i == n_iter - 1 && !trace) break;                // outcome cannot matter any more
@@ -879,7 +891,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
             int blocks = 0;
             CHK(run_row_pass(c, false, pending, d_sw, thresh, nullptr, &blocks));
             CHK(run_col_pass(c, false, d_sw, thresh));
-            CHK(run_v_normalise(c, nullptr));
+            CHK(run_v_normalise(c));
             if (pending) {
                 CHK(finish_ll(c, blocks, &ll));
                 const float cur = (float)ll;
@@ -930,7 +942,7 @@ int plsa_refit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_
     if (!fused) {
         for (int i = 0; i < n_iter; ++i) {
             CHK(run_e_step(c, thresh));
-            CHK(run_m_step_from_p(c, nullptr, false, nullptr, nullptr));
+            CHK(run_m_step_from_p(c, nullptr, false, nullptr));
             iters++;
             if (i % n_iter_per_test == 0) {
                 if (i == n_iter - 1 && !trace) break;

@@ -24,6 +24,10 @@
 #ifndef PLSA_UNR
 #define PLSA_UNR 4      // non-zeros whose gathers are in flight together, per group
 #endif
+#ifndef PLSA_NT_STREAMS
+#define PLSA_NT_STREAMS 0   // non-temporal loads for read-once streams: measured neutral on the fused
+                            // passes and -14 % on the E-step (U rows are re-used from L1 by ~100 nnz)
+#endif
 #ifndef PLSA_UNR_COL
 #define PLSA_UNR_COL 8  // same for the column pass (its U gathers miss L2 more often: measured best)
 #endif
@@ -63,6 +67,14 @@ __device__ __forceinline__ void st4_nt(float *p, const float4 &v) {
     __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));  // global_store_dwordx4 ... nt
 }
 
+__device__ __forceinline__ float4 ld4_nt(const float *p) {
+    const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));   // global_load_dwordx4 ... nt
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
+__device__ __forceinline__ int ldi(const int *p) { return PLSA_NT_STREAMS ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ float ldf(const float *p) { return PLSA_NT_STREAMS ? __builtin_nontemporal_load(p) : *p; }
+
 // Shape of the lane decomposition.  When FULL, kp is the compile-time constant 4*LPN*CH.
 template <int LPN_, int CH_, bool FULL_>
 struct Shape {
@@ -79,12 +91,16 @@ struct Shape {
 // gather the lane's chunks of one factor row WITHOUT a branch: out-of-row chunks read offset 0
 // (a valid address) -- ZERO_INVALID then forces them to zero (needed for one operand only:
 // the product with a zeroed chunk is 0 and fails the threshold test).
-template <class S, bool ZERO_INVALID>
+// STREAM marks rows that are read once per launch (the owner's own row, the index streams): they
+// are loaded non-temporally so that the 4 MB per-XCD L2 keeps the rows that ARE re-used (the
+// gathered factor table).
+template <class S, bool ZERO_INVALID, bool STREAM = false>
 __device__ __forceinline__ void load_row(const float *row, int li, int kp, float4 (&out)[S::CH]) {
 #pragma unroll
     for (int j = 0; j < S::CH; ++j) {
         const bool ok = S::ok(li, j, kp);
-        const float4 v = ld4(row + (ok ? S::c4(li, j) : 0));
+        const float *p = row + (ok ? S::c4(li, j) : 0);
+        const float4 v = STREAM ? ld4_nt(p) : ld4(p);
         out[j] = (ZERO_INVALID && !ok) ? zero4() : v;
     }
 }
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(256) void k_e_step(const int *__restrict__ rowidx,
                 const int src = (s0 + q) * GPW + g;
                 const int d = __shfl(d_l, src, 64);
                 const int w = __shfl(w_l, src, 64);
-                load_row<S, true>(U + (i64)d * kp, li, kp, u[q]);
+                load_row<S, true, PLSA_NT_STREAMS>(U + (i64)d * kp, li, kp, u[q]);
                 load_row<S, false>(Vt + (i64)w * kp, li, kp, vt[q]);
             }
 #pragma unroll
@@ -211,20 +227,20 @@ __global__ __launch_bounds__(256) void k_row_pass(const int *__restrict__ indptr
         const int d = row_order ? row_order[r] : (int)r;
         const int j0 = indptr[d], j1 = indptr[d + 1];
         float4 u[CH], acc[CH];
-        load_row<S, true>(U + (i64)d * kp, li, kp, u);
+        load_row<S, true, PLSA_NT_STREAMS>(U + (i64)d * kp, li, kp, u);
 #pragma unroll
         for (int j = 0; j < CH; ++j) acc[j] = zero4();
         const float swd = (WANT_LL && sw) ? sw[d] : 1.0f;
         // software-pipelined index stream: the next LPN (word, count) pairs are in flight while the
         // current ones are consumed
-        int w_n = (j0 + li < j1) ? colidx[j0 + li] : 0;
-        float x_n = (j0 + li < j1) ? vals[j0 + li] : 0.f;
+        int w_n = (j0 + li < j1) ? ldi(colidx + j0 + li) : 0;
+        float x_n = (j0 + li < j1) ? ldf(vals + j0 + li) : 0.f;
         for (int jb = j0; jb < j1; jb += LPN) {
             const int w_l = w_n;
             const float x_l = x_n;
             const int jn = jb + LPN + li;
-            w_n = jn < j1 ? colidx[jn] : 0;
-            x_n = jn < j1 ? vals[jn] : 0.f;
+            w_n = jn < j1 ? ldi(colidx + jn) : 0;
+            x_n = jn < j1 ? ldf(vals + jn) : 0.f;
             const int cnt = min(LPN, j1 - jb);
             for (int s0 = 0; s0 < cnt; s0 += UNR) {
                 float4 a[UNR][CH];   // Vt rows (fused) or P rows (FROM_P)
@@ -250,7 +266,7 @@ __global__ __launch_bounds__(256) void k_row_pass(const int *__restrict__ indptr
                             const float dot = group_sum<LPN>(unth);
                             if (li == 0 && s0 + q < cnt) ll += (double)(x[q] * logf(dot) * swd);
                         }
-                        scale<CH>(pz, inv_norm(norm));
+                        x[q] *= inv_norm(norm);   // s = x * (v / norm) evaluated as v * (x / norm)
                     }
 #pragma unroll
                     for (int j = 0; j < CH; ++j) {   // s = x * P(z|w,d); U[d,z] += s   plsa.py:188-191
@@ -310,31 +326,40 @@ __global__ __launch_bounds__(256) void k_col_pass(const int *__restrict__ item_o
                                                   const float *__restrict__ Vt,
                                                   const float *__restrict__ P,
                                                   const float *__restrict__ sw,
-                                                  float *__restrict__ partial, int kp_rt, float thresh) {
+                                                  float *__restrict__ partial, int kp_rt, float thresh,
+                                                  int xcd_split) {
     constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR_COL;
     constexpr int GPB = 256 / LPN;
     const int kp = S::kp(kp_rt);
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
-    for (i64 io = (i64)blockIdx.x * GPB + gid; io < n_items; io += (i64)gridDim.x * GPB) {
+    // XCD-aware traversal: workgroup b runs on XCD b % 8 (observed dispatch rule; a different
+    // placement only costs speed).  Each XCD walks its own contiguous eighth of the doc-band-major
+    // item list, so all workgroups sharing an L2 gather from the same band of U rows.
+    const int xcd = xcd_split ? (int)(blockIdx.x & 7) : 0;
+    const i64 nq = xcd_split ? (gridDim.x + 7 - xcd) / 8 : gridDim.x;   // workgroups on this XCD
+    const i64 q = xcd_split ? (blockIdx.x >> 3) : blockIdx.x;
+    const i64 per = xcd_split ? (n_items + 7) / 8 : n_items;
+    const i64 lo = xcd * per, hi = min(n_items, lo + per);
+    for (i64 io = lo + q * GPB + gid; io < hi; io += nq * GPB) {
         const int it = item_order ? item_order[io] : (int)io;
         const int w = item_col[it];
         const int j0 = item_start[it];
         const int j1 = min(j0 + seg, colptr[w + 1]);
         float4 vt[CH], acc[CH];
-        load_row<S, true>(Vt + (i64)w * kp, li, kp, vt);
+        load_row<S, true, PLSA_NT_STREAMS>(Vt + (i64)w * kp, li, kp, vt);
 #pragma unroll
         for (int j = 0; j < CH; ++j) acc[j] = zero4();
-        int d_n = (j0 + li < j1) ? csc_row[j0 + li] : 0;
-        float x_n = (j0 + li < j1) ? csc_val[j0 + li] : 0.f;
-        int p_n = (FROM_P && j0 + li < j1) ? csc_pos[j0 + li] : 0;
+        int d_n = (j0 + li < j1) ? ldi(csc_row + j0 + li) : 0;
+        float x_n = (j0 + li < j1) ? ldf(csc_val + j0 + li) : 0.f;
+        int p_n = (FROM_P && j0 + li < j1) ? ldi(csc_pos + j0 + li) : 0;
         for (int jb = j0; jb < j1; jb += LPN) {
             const int d_l = d_n, p_l = p_n;
             float x_l = x_n;
             const int jn = jb + LPN + li;
-            d_n = jn < j1 ? csc_row[jn] : 0;
-            x_n = jn < j1 ? csc_val[jn] : 0.f;
-            if (FROM_P) p_n = jn < j1 ? csc_pos[jn] : 0;
+            d_n = jn < j1 ? ldi(csc_row + jn) : 0;
+            x_n = jn < j1 ? ldf(csc_val + jn) : 0.f;
+            if (FROM_P) p_n = jn < j1 ? ldi(csc_pos + jn) : 0;
             if (sw) x_l *= sw[d_l];  // t = s * sample_weight[d]  (plsa.py:294), folded into the count
             const int cnt = min(LPN, j1 - jb);
             for (int s0 = 0; s0 < cnt; s0 += UNR) {
@@ -360,7 +385,7 @@ __global__ __launch_bounds__(256) void k_col_pass(const int *__restrict__ item_o
                     } else {
                         float unth;
                         const float norm = group_sum<LPN>(products<CH, false>(a[q], vt, thresh, pz, unth));
-                        scale<CH>(pz, inv_norm(norm));
+                        x[q] *= inv_norm(norm);
                     }
 #pragma unroll
                     for (int j = 0; j < CH; ++j) {
@@ -455,8 +480,8 @@ __global__ void k_heavy_list(const int *__restrict__ item_first, int m, int heav
 // ------------------------------------------------------------------------------------------------
 // P(w|z) normalisation, plsa.py:196-199: norm_pwz[z] = sum_w Vt_new[w,z], then divide.
 //   k_colsum_partial : NORM_BLOCKS blocks, each sums a contiguous slab of words -> partials (f64)
-//   k_v_normalise    : every block re-adds the NORM_BLOCKS partials (fixed order) into LDS, divides
-//                      its slab and writes the normalised topics into Vt.
+//   k_colsum_final   : one block adds the NORM_BLOCKS partials in fixed order -> norm_pwz (f32)
+//   k_v_normalise    : divides and writes the normalised topics into Vt.
 // ------------------------------------------------------------------------------------------------
 constexpr int NORM_BLOCKS = 256;
 
@@ -485,17 +510,37 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
     }
 }
 
+// norm_pwz[z] = fixed-order sum of the slab partials (one block; the 256 threads split the
+// partials of each column into 256/span interleaved strands that are then added in strand order)
+__global__ __launch_bounds__(256) void k_colsum_final(const double *__restrict__ partials, int n_partials,
+                                                      int kp, float *__restrict__ norm_pwz) {
+    __shared__ double sred[256];
+    for (int zb = 0; zb < kp; zb += 256) {
+        const int span = min(256, kp - zb);
+        const int rpp = 256 / span;
+        const int z = zb + (int)threadIdx.x % span;
+        const int ro = (int)threadIdx.x / span;
+        double tot = 0.0;
+        if (ro < rpp) {
+#pragma unroll 8
+            for (int b = ro; b < n_partials; b += rpp) tot += partials[(i64)b * kp + z];
+        }
+        sred[threadIdx.x] = tot;
+        __syncthreads();
+        if ((int)threadIdx.x < span) {
+            double t2 = 0.0;
+            for (int r = 0; r < rpp; ++r) t2 += sred[r * span + threadIdx.x];
+            norm_pwz[zb + threadIdx.x] = (float)t2;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_v_normalise(const float *__restrict__ Vt_new,
                                                      float *__restrict__ Vt, int m, int kp,
-                                                     const double *__restrict__ partials,
-                                                     int n_partials, float *__restrict__ norm_pwz) {
+                                                     const float *__restrict__ norm_pwz) {
     extern __shared__ float snorm[];  // [kp]
-    for (int z = threadIdx.x; z < kp; z += 256) {
-        double tot = 0.0;
-        for (int b = 0; b < n_partials; ++b) tot += partials[(i64)b * kp + z];
-        snorm[z] = (float)tot;
-        if (blockIdx.x == 0 && norm_pwz) norm_pwz[z] = (float)tot;
-    }
+    for (int z = threadIdx.x; z < kp; z += 256) snorm[z] = norm_pwz[z];
     __syncthreads();
     const i64 total4 = (i64)m * kp / 4;
     const int kq = kp / 4;
@@ -545,16 +590,16 @@ __global__ __launch_bounds__(256) void k_loglik(const int *__restrict__ indptr,
         const int d = row_order ? row_order[r] : (int)r;
         const int j0 = indptr[d], j1 = indptr[d + 1];
         float4 u[CH];
-        load_row<S, true>(U + (i64)d * kp, li, kp, u);
+        load_row<S, true, PLSA_NT_STREAMS>(U + (i64)d * kp, li, kp, u);
         const float swd = sw ? sw[d] : 1.0f;
-        int w_n = (j0 + li < j1) ? colidx[j0 + li] : 0;
-        float x_n = (j0 + li < j1) ? vals[j0 + li] : 0.f;
+        int w_n = (j0 + li < j1) ? ldi(colidx + j0 + li) : 0;
+        float x_n = (j0 + li < j1) ? ldf(vals + j0 + li) : 0.f;
         for (int jb = j0; jb < j1; jb += LPN) {
             const int w_l = w_n;
             const float x_l = x_n;
             const int jn = jb + LPN + li;
-            w_n = jn < j1 ? colidx[jn] : 0;
-            x_n = jn < j1 ? vals[jn] : 0.f;
+            w_n = jn < j1 ? ldi(colidx + jn) : 0;
+            x_n = jn < j1 ? ldf(vals + jn) : 0.f;
             const int cnt = min(LPN, j1 - jb);
             for (int s0 = 0; s0 < cnt; s0 += UNR) {
                 float4 vt[UNR][CH];

@@ -312,3 +312,43 @@ class PLSA(BaseEstimator, TransformerMixin):
         return plsa_refit(X, self.components_, sample_weight, n_iter=50, n_iter_per_test=5,
                           tolerance=0.001, random_state=random_state, device=self.device,
                           flags=self._flags())
+
+
+class StreamedPLSA(PLSA):
+    """Drop-in name for enstop.streamed_plsa.StreamedPLSA (streamed_plsa.py:1042-1337).  The reference
+    class bounds memory by materialising P(z|w,d) for `block_size` non-zeros at a time
+    (streamed_plsa.py:341-375); the fused HIP schedule never materialises it at all, so `block_size`
+    is accepted for signature compatibility and has no effect.  Results equal `PLSA`'s."""
+
+    def __init__(self, n_components=10, init="random", block_size=65536, n_iter=100, n_iter_per_test=10,
+                 tolerance=0.001, e_step_thresh=1e-32, transform_random_seed=42, random_state=None,
+                 device=None):
+        super().__init__(n_components=n_components, init=init, n_iter=n_iter,
+                         n_iter_per_test=n_iter_per_test, tolerance=tolerance,
+                         e_step_thresh=e_step_thresh, transform_random_seed=transform_random_seed,
+                         random_state=random_state, device=device)
+        self.block_size = block_size
+
+    def _flags(self):
+        from .engine import PLSA_FUSED
+        return PLSA_FUSED
+
+
+class BlockParallelPLSA(PLSA):
+    """Drop-in name for enstop.block_parallel_plsa.BlockParallelPLSA (block_parallel_plsa.py:424-538).
+    The reference tiles X into n_row_blocks x n_col_blocks padded COO tiles for numba threads (and
+    silently wraps tile sizes above 65 535 rows through np.uint16, block_parallel_plsa.py:359-360);
+    on the GPU the work decomposition is per document row / per column item, so the two tiling
+    parameters are accepted as hints and ignored.  Same EM maths, hence the same results as `PLSA`
+    (the reference's blockwise log-likelihood ignores sample weights, block_parallel_plsa.py:205-248;
+    here they are honoured like in plsa.py)."""
+
+    def __init__(self, n_components=10, init="random", n_row_blocks=8, n_col_blocks=8, n_iter=100,
+                 n_iter_per_test=10, tolerance=0.001, e_step_thresh=1e-32, transform_random_seed=42,
+                 random_state=None, device=None):
+        super().__init__(n_components=n_components, init=init, n_iter=n_iter,
+                         n_iter_per_test=n_iter_per_test, tolerance=tolerance,
+                         e_step_thresh=e_step_thresh, transform_random_seed=transform_random_seed,
+                         random_state=random_state, device=device)
+        self.n_row_blocks = n_row_blocks
+        self.n_col_blocks = n_col_blocks

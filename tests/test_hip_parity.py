@@ -315,3 +315,97 @@ def test_synthetic_generator_is_canonical_and_deterministic(amd):
         # Zipf head: the most frequent word appears in far more documents than the median word
         df = np.bincount(A.indices, minlength=2000)
         assert df.max() > 20 * max(np.median(df), 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases: degenerate shapes, duplicate entries, limits, API-compatible class names
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape_k", [((1, 9), 3), ((9, 1), 2), ((7, 5), 1), ((6, 4), 9), ((3, 3), 4)])
+def test_degenerate_shapes_vs_oracle(amd, oracle, shape_k):
+    (n, m), k = shape_k
+    rs = np.random.RandomState(n * 31 + m)
+    D = np.ceil(rs.rand(n, m) * 4) * (rs.rand(n, m) < 0.7)
+    D[0, 0] = 2.0
+    X = sp.csr_matrix(D.astype(np.float32))
+    sw = np.ones(n, np.float32)
+    kw = dict(n_iter=7, n_iter_per_test=3, tolerance=0.0, e_step_thresh=1e-32, random_state=5)
+    Uo, Vo, trace, iters = oracle.plsa_fit(X, k, sw, return_trace=True, **kw)
+    for mode in MODES.values():
+        U, V, info = amd.plsa_fit(X, k, sw, flags=mode, return_info=True, **kw)
+        got = info["log_likelihood_trace"]
+        if n == 1 or m == 1 or k == 1:
+            # a rank-one problem converges in one step; afterwards the reference's `change == 0`
+            # stop arm (plsa.py:635) fires on last-bit noise of whichever float32 sum is used, so
+            # the iteration count is not a well-defined quantity -- the fixed point is
+            assert 1 <= info["n_iter"] <= 7
+            q = min(len(got), len(trace))
+            close_ll(got[:q], trace[:q])
+        else:
+            assert info["n_iter"] == iters
+            close_ll(got, trace)
+        close_factors(U, Uo); close_factors(V, Vo)
+
+
+def test_duplicate_coo_entries_are_separate_nonzeros(amd, oracle):
+    """X.tocoo() of a CSR with repeated (d, w) keeps both entries; the reference treats them as two
+    non-zeros (it never sums duplicates).  Same here, on both the CSR and the CSC side."""
+    rows = np.array([0, 0, 0, 1, 1, 2, 2, 2, 2], np.int32)
+    cols = np.array([1, 1, 3, 0, 3, 2, 2, 2, 0], np.int32)
+    vals = np.array([1, 2, 1, 3, 1, 1, 1, 2, 4], np.float32)
+    n, m, k = 3, 4, 3
+    rs = np.random.RandomState(1)
+    V = rs.rand(k, m).astype(np.float32); V /= V.sum(1, keepdims=True)
+    U = rs.rand(n, k).astype(np.float32); U /= U.sum(1, keepdims=True)
+    Po = oracle.plsa_e_step(rows, cols, vals, V, U, np.zeros((9, k), np.float32), 1e-32)
+    P = amd.plsa_e_step(rows, cols, vals, V, U, np.zeros((9, k), np.float32), 1e-32)
+    np.testing.assert_allclose(P, Po, rtol=3e-6)
+    Vo, Uo = V.copy(), U.copy()
+    oracle.plsa_m_step(rows, cols, vals, Vo, Uo, Po, np.zeros(k, np.float32), np.zeros(n, np.float32))
+    Vh, Uh = V.copy(), U.copy()
+    amd.plsa_m_step(rows, cols, vals, Vh, Uh, Po, np.zeros(k, np.float32), np.zeros(n, np.float32))
+    np.testing.assert_allclose(Vh, Vo, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(Uh, Uo, rtol=1e-5, atol=1e-9)
+
+
+def test_limits_and_errors(amd):
+    X = sp.random(50, 40, density=0.2, format="csr", random_state=0, dtype=np.float32)
+    ones = np.ones(50, np.float32)
+    U, V = amd.plsa_fit(X, 1024, ones, n_iter=2, random_state=0)           # largest supported k
+    assert U.shape == (50, 1024) and np.allclose(U.sum(1), 1.0, atol=1e-4)
+    with pytest.raises(amd.DeviceError, match="outside"):
+        amd.plsa_fit(X, 1025, ones, n_iter=1, random_state=0)
+    with pytest.raises(ValueError, match="Unrecognized init"):
+        amd.plsa_fit(X, 4, ones, init="nope", n_iter=1)
+    with amd.Engine() as eng:
+        with pytest.raises(amd.DeviceError, match="upload a corpus"):
+            eng._ok(eng._L.plsa_set_factors(eng._h, np.ones((5, 2), np.float32).ctypes.data,
+                                            np.ones((2, 3), np.float32).ctypes.data, 5, 3, 2))
+        eng.upload_csr(X)
+        with pytest.raises(amd.DeviceError, match="do not match"):
+            eng._ok(eng._L.plsa_set_factors(eng._h, np.ones((7, 2), np.float32).ctypes.data,
+                                            np.ones((2, 40), np.float32).ctypes.data, 7, 40, 2))
+        with pytest.raises(amd.DeviceError, match="factors not set"):
+            eng.e_step()
+        eng.set_factors(np.full((50, 2), 0.5, np.float32), np.full((2, 40), 1 / 40, np.float32))
+        with pytest.raises(amd.DeviceError, match="no P"):
+            eng.m_step()
+
+
+def test_api_compatible_class_names(amd):
+    g = load_golden("estimator_int")
+    shape = tuple(int(s) for s in g["shape"])
+    X = sp.csr_matrix((g["data"], g["indices"], g["indptr"]), shape=shape)
+    kw = dict(n_components=int(g["k"]), n_iter=30, n_iter_per_test=10, tolerance=0.0, random_state=11)
+    for cls, extra in ((amd.StreamedPLSA, dict(block_size=1024)), (amd.BlockParallelPLSA, dict(n_row_blocks=4, n_col_blocks=2))):
+        model = cls(**kw, **extra).fit(X)
+        close_factors(model.embedding_, g["embedding"])
+        close_factors(model.components_, g["components"])
+        assert set(extra) <= set(model.get_params())
+
+
+def test_init_nndsvd_and_nmf_run(amd):
+    X = _corpus(200, 300, 0.05, seed=9)
+    for init in ("nndsvd", "nmf"):
+        U, V = amd.plsa_fit(X, 5, np.ones(200, np.float32), init=init, n_iter=5, random_state=0)
+        assert np.all(np.isfinite(U)) and np.all(np.isfinite(V))
+        np.testing.assert_allclose(V.sum(1), 1.0, atol=1e-4)
