@@ -130,6 +130,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
+    backend = None
     force_dist = os.environ.get("PLSA_BENCH_FORCE_DIST", "0") == "1"   # exercise the RCCL path with 1 rank
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -140,8 +141,20 @@ def main():
         if local_rank >= torch.cuda.device_count():      # launcher restricted the visible devices
             local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)                        # forces communicator creation now
+            torch.cuda.synchronize()
+            backend = "nccl"
+        except Exception as e:                            # keep the measurement alive: control plane
+            print("bench.py: RCCL init failed (%r); falling back to gloo for barrier/gather" % (e,),
+                  file=sys.stderr)                        # over gloo, topics gathered through the host
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            backend = "gloo"
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torchrun for N > 1" % (args.gpus, world),
@@ -167,21 +180,29 @@ def main():
     def barrier():
         eng.synchronize()
         if dist is not None:
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
 
     gather_buf = None
     if dist is not None:
-        gather_buf = (torch.empty((k, m), dtype=torch.float32, device="cuda"),
-                      torch.empty((world, k, m), dtype=torch.float32, device="cuda"))
+        dev = "cuda" if backend == "nccl" else "cpu"
+        gather_buf = (torch.empty((k, m), dtype=torch.float32, device=dev),
+                      torch.empty((world, k, m), dtype=torch.float32, device=dev))
 
     def gather_components():
+        """the np.vstack of enstop_.py:231 as one all-gather of the (k, m) topic matrices"""
         if dist is None:
             return
         send, recv = gather_buf
-        eng.copy_components_to_device(send.data_ptr())
-        dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
-        torch.cuda.synchronize()
+        if backend == "nccl":
+            eng.copy_components_to_device(send.data_ptr())        # D2D into the RCCL send buffer
+            dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+            torch.cuda.synchronize()
+        else:
+            _, V = eng.get_factors(want_u=False)
+            send.copy_(torch.from_numpy(V))
+            dist.all_gather(list(recv.unbind(0)), send)
 
     # ---- warmup (untimed): W EM iterations + the collective --------------------------------------
     if args.warmup > 0:
@@ -203,10 +224,11 @@ def main():
     eng.timing(False)
 
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        rdev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([float(nnz_act)], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([float(nnz_act)], dtype=torch.float64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         nnz_total = float(tot.item())
     else:
@@ -269,7 +291,7 @@ def main():
         "config": {"workload": cfg["name"], "n_docs": n, "n_vocab": m, "nnz": nnz, "k": k,
                    "schedule": args.schedule,
                    "parallelism": "single fit" if n_gpus == 1 else
-                   "ensemble: one bootstrap member per GPU x%d, RCCL all-gather of topics" % n_gpus,
+                   "ensemble: one bootstrap member per GPU x%d, %s all-gather of topics" % (n_gpus, "RCCL" if backend == "nccl" else "gloo(host)"),
                    "ll_test_every": 10, "tolerance": 0.0, "e_step_thresh": 1e-32},
         "gcell_per_s": round(nnz_total * k * args.steps / dt / 1e9, 3),
         "ensemble_fits_per_min": round(n_gpus * args.steps / dt / FITS_ITERS * 60.0, 3),

@@ -288,13 +288,6 @@ int ensure_csc(plsa_ctx *c) {
     CHK(ensure(c, c->csc_pos, sizeof(int) * (size_t)nnz));
     CHK(ensure(c, c->tmp0, sizeof(int) * (size_t)std::max<i64>(nnz, m + 1)));  // counts, then sorted keys
     CHK(ensure(c, c->tmp1, sizeof(int) * (size_t)nnz));                         // iota
-    // column histogram -> colptr
-    HIPCHK(c, hipMemsetAsync(c->tmp0.p, 0, sizeof(int) * (size_t)(m + 1), c->stream));
-    if (nnz > 0)
-        hipLaunchKernelGGL(plsa::k_col_count, dim3(grid_for(c, nnz, 256)), dim3(256), 0, c->stream,
-                           c->col, nnz, c->tmp0.as<int>());
-    CHK(launch_check(c, "k_col_count"));
-    CHK(exclusive_sum_int(c, c->tmp0.as<int>(), c->colptr.as<int>(), m + 1));
     // stable sort of entry positions by column: within a column entries stay in document order
     if (nnz > 0) {
         hipLaunchKernelGGL(plsa::k_iota, dim3(grid_for(c, nnz, 256)), dim3(256), 0, c->stream,
@@ -309,10 +302,14 @@ int ensure_csc(plsa_ctx *c) {
         HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, bytes, c->col, c->tmp0.as<int>(),
                                                      c->tmp1.as<int>(), c->csc_pos.as<int>(), nnz, 0,
                                                      bits, c->stream));
+        hipLaunchKernelGGL(plsa::k_colptr_from_sorted, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, c->stream,
+                           c->tmp0.as<int>(), nnz, (int)m, c->colptr.as<int>());
         hipLaunchKernelGGL(plsa::k_csc_gather, dim3(grid_for(c, nnz, 256)), dim3(256), 0, c->stream,
                            c->csc_pos.as<int>(), c->rowidx.as<int>(), c->val, nnz,
                            c->csc_row.as<int>(), c->csc_val.as<float>());
         CHK(launch_check(c, "k_csc_gather"));
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->colptr.p, 0, sizeof(int) * (size_t)(m + 1), c->stream));
     }
     // column items
     CHK(ensure(c, c->item_first, sizeof(int) * (size_t)(m + 1)));
@@ -765,6 +762,37 @@ int plsa_set_factors(plsa_ctx *c, const float *U, const float *V, int64_t n, int
                            c->Vt[0].as<float>(), k, (int)m, kp);
         CHK(launch_check(c, "k_v_to_vt"));
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Throughput-mode initialisation on the device (counter-based RNG; not the reference's stream).
+int plsa_init_factors_device(plsa_ctx *c, int32_t k, uint64_t seed) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n <= 0) return fail(c, "plsa_init_factors_device: upload a corpus first");
+    if (k <= 0 || k > 1024) return fail(c, "plsa_init_factors_device: k=%d outside [1,1024]", k);
+    const i64 n = c->n, m = c->m;
+    const int kp = (k + 3) / 4 * 4;
+    c->k = k; c->kp = kp; c->fac_n = n; c->fac_m = m;
+    int lpn = 1;
+    while (lpn < kp / 4 && lpn < 64) lpn *= 2;
+    if (lpn >= 32 && lpn * 4 >= kp && c->chunks_per_lane == 2) lpn /= 2;
+    c->lpn = lpn;
+    c->ch = (kp / 4 + lpn - 1) / lpn;
+    if (c->ch == 3) c->ch = 4;
+    for (int i = 0; i < 2; ++i) CHK(ensure(c, c->U[i], sizeof(float) * (size_t)n * kp));
+    for (int i = 0; i < 2; ++i) CHK(ensure(c, c->Vt[i], sizeof(float) * (size_t)m * kp));
+    CHK(ensure(c, c->Vacc, sizeof(float) * (size_t)m * kp));
+    c->p_valid = false; c->cu = 0; c->cv = 0;
+    // P(w|z): uniform draws per (topic, word), topic rows normalised -> generate [k, m] then transpose
+    CHK(ensure(c, c->tmp0, sizeof(float) * (size_t)std::max<i64>(k, 4) * m));
+    hipLaunchKernelGGL(plsa::k_init_rows, dim3(grid_for(c, k, 4)), dim3(256), 0, c->stream, c->tmp0.as<float>(),
+                       (i64)k, (int)m, (int)m, (unsigned long long)plsa::mix64(seed ^ 0x5157ull));
+    dim3 grid((unsigned)((m + 31) / 32), (unsigned)((kp + 31) / 32));
+    hipLaunchKernelGGL(plsa::k_v_to_vt, grid, dim3(256), 0, c->stream, c->tmp0.as<float>(), c->Vt[0].as<float>(), k, (int)m, kp);
+    hipLaunchKernelGGL(plsa::k_init_rows, dim3(grid_for(c, n, 4)), dim3(256), 0, c->stream, c->U[0].as<float>(),
+                       n, k, kp, (unsigned long long)plsa::mix64(seed ^ 0xD0C5ull));
+    CHK(launch_check(c, "k_init_rows"));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

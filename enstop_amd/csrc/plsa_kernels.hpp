@@ -720,9 +720,42 @@ __global__ void k_iota(int *__restrict__ a, i64 nn) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += (i64)gridDim.x * blockDim.x)
         a[i] = (int)i;
 }
-__global__ void k_col_count(const int *__restrict__ colidx, i64 nnz, int *__restrict__ counts) {
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (i64)gridDim.x * blockDim.x)
-        atomicAdd(counts + colidx[i], 1);
+// colptr[w] = first position of a key >= w in the sorted column keys (w = 0..m); no atomics -- an
+// int-atomic histogram spent 12 ms on the Zipf head words' same-address contention
+__global__ void k_colptr_from_sorted(const int *__restrict__ keys_sorted, i64 nnz, int m,
+                                     int *__restrict__ colptr) {
+    const i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > m) return;
+    i64 lo = 0, hi = nnz;
+    while (lo < hi) {
+        const i64 mid = (lo + hi) >> 1;
+        if (keys_sorted[mid] < (int)w) lo = mid + 1; else hi = mid;
+    }
+    colptr[w] = (int)lo;
+}
+
+// device-side factor initialisation for throughput runs (NOT the reference's MT19937 stream):
+// counter-based uniform numbers, rows L1-normalised in place.  One group of 64 lanes per row.
+__global__ void k_init_rows(float *__restrict__ A, i64 rows, int k, int kp, unsigned long long seed) {
+    const int lane = threadIdx.x & 63;
+    const i64 wid = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const i64 nw = ((i64)gridDim.x * blockDim.x) >> 6;
+    for (i64 r = wid; r < rows; r += nw) {
+        float part = 0.f;
+        for (int z = lane; z < kp; z += 64) {
+            float v = 0.f;
+            if (z < k) {
+                unsigned long long x = seed ^ ((unsigned long long)r * 0x9E3779B97F4A7C15ull + (unsigned long long)z);
+                x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+                x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; x ^= x >> 31;
+                v = ((float)(x >> 40) + 0.5f) * (1.0f / 16777216.0f);
+            }
+            A[r * kp + z] = v;
+            part += v;
+        }
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        for (int z = lane; z < k; z += 64) A[r * kp + z] /= part;
+    }
 }
 __global__ void k_csc_gather(const int *__restrict__ pos, const int *__restrict__ rowidx,
                              const float *__restrict__ vals, i64 nnz, int *__restrict__ csc_row,

@@ -132,6 +132,12 @@ class Engine:
         self.k = k
         return self
 
+    def init_factors_device(self, k, seed=0):
+        """Throughput-mode random init on the device (not the reference's MT19937 stream)."""
+        self._ok(self._L.plsa_init_factors_device(self._h, int(k), int(seed) & (2 ** 64 - 1)))
+        self.k = int(k)
+        return self
+
     def get_factors(self, want_u=True, want_v=True):
         n, m, _ = self.shape
         U = np.empty((n, self.k), np.float32) if want_u else None

@@ -1,0 +1,199 @@
+"""EnsembleTopics on top of the GPU ensemble path (a "next" row).
+
+The expensive stages -- the bootstrapped pLSA fits (`ensemble_of_topics`) and the final refit of the
+document vectors (`plsa_refit`) -- run on the MI355X engine.  The topic *combination* stage in
+between works on a few hundred topic vectors and stays on the host.
+
+Parity status of this module: **unpinned**.  The reference clusters with the third-party `hdbscan`
+and `umap` packages (enstop/enstop_.py:234-414), neither of which is available in the build image, so
+no golden vectors exist for it.  Here `"hellinger"` and `"kl_divergence"` use scikit-learn's HDBSCAN
+(`sklearn.cluster.HDBSCAN`, the maintained successor of the `hdbscan` package) on a precomputed
+divergence matrix; `"hellinger_umap"` needs `umap-learn` and raises ImportError when it is absent.
+The representative of a cluster is formed exactly as the reference does: the (optionally
+membership-weighted) mean of the square-rooted member topics, squared and L1-normalised
+(enstop_.py:299-308, 340-345, 385-393).
+"""
+import numpy as np
+from scipy.sparse import coo_matrix, csr_matrix, issparse
+from sklearn.base import BaseEstimator, TransformerMixin
+from sklearn.utils import check_array, check_random_state
+
+from .enstop_ import ensemble_of_topics
+from .plsa import plsa_refit
+from .utils import _check_sample_weight
+
+
+def all_pairs_hellinger_distance(distributions):
+    """sqrt(1 - BC(p, q) / sqrt(|p|_1 |q|_1)) for all pairs (umap.distances.hellinger's definition,
+    which enstop_.py:258-266 applies pairwise); one small GEMM."""
+    P = np.asarray(distributions, dtype=np.float64)
+    root = np.sqrt(P)
+    l1 = P.sum(axis=1)
+    denom = np.sqrt(np.outer(l1, l1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = np.where(denom > 0, (root @ root.T) / denom, 0.0)
+    D = np.sqrt(np.clip(1.0 - ratio, 0.0, None))
+    both_empty = np.outer(l1 == 0, l1 == 0)
+    one_empty = np.logical_xor.outer(l1 == 0, l1 == 0)
+    D[both_empty] = 0.0
+    D[one_empty] = 1.0
+    np.fill_diagonal(D, 0.0)
+    return D
+
+
+def all_pairs_kl_divergence(distributions):
+    """KL(p_i || p_j) in bits over the common support (enstop_.py:234-253)."""
+    P = np.asarray(distributions, dtype=np.float64)
+    with np.errstate(divide="ignore"):
+        L = np.where(P > 0, np.log2(np.where(P > 0, P, 1.0)), 0.0)
+    pos = (P > 0).astype(np.float64)
+    # sum_w p_i[w] (log p_i[w] - log p_j[w]) restricted to p_i > 0 and p_j > 0
+    return (P * L) @ pos.T - P @ L.T
+
+
+def _cluster_representatives(all_topics, labels, weights=None):
+    n_clusters = int(labels.max()) + 1 if labels.size else 0
+    result = np.empty((n_clusters, all_topics.shape[1]), dtype=np.float32)
+    root = np.sqrt(all_topics)
+    for i in range(n_clusters):
+        mask = labels == i
+        w = None if weights is None else weights[mask]
+        if w is not None and not np.any(w > 0):
+            w = None
+        rep = np.average(root[mask], axis=0, weights=w) ** 2
+        result[i] = rep / rep.sum()
+    return result
+
+
+def _hdbscan_precomputed(D, min_samples, min_cluster_size):
+    from sklearn.cluster import HDBSCAN
+    return HDBSCAN(min_samples=min_samples, min_cluster_size=min_cluster_size, metric="precomputed",
+                   cluster_selection_method="leaf").fit(D)
+
+
+def generate_combined_topics_kl(all_topics, min_samples=5, min_cluster_size=5):
+    D = all_pairs_kl_divergence(all_topics)
+    D = np.maximum(D, D.T)                       # symmetrised, as the reference's mutual reachability is
+    np.fill_diagonal(D, 0.0)
+    labels = _hdbscan_precomputed(np.clip(D, 0.0, None), min_samples, min_cluster_size).labels_
+    return _cluster_representatives(np.asarray(all_topics), labels)
+
+
+def generate_combined_topics_hellinger(all_topics, min_samples=5, min_cluster_size=5):
+    D = all_pairs_hellinger_distance(all_topics)
+    labels = _hdbscan_precomputed(D, min_samples, min_cluster_size).labels_
+    return _cluster_representatives(np.asarray(all_topics), labels)
+
+
+def generate_combined_topics_hellinger_umap(all_topics, min_samples=5, min_cluster_size=5,
+                                            n_neighbors=15, reduced_dim=5):
+    try:
+        import umap
+    except ImportError as e:
+        raise ImportError('topic_combination="hellinger_umap" needs the umap-learn package; '
+                          'use topic_combination="hellinger" instead') from e
+    from sklearn.cluster import HDBSCAN
+    embedding = umap.UMAP(n_neighbors=n_neighbors, n_components=reduced_dim,
+                          metric="hellinger").fit_transform(all_topics)
+    clusterer = HDBSCAN(min_samples=min_samples, min_cluster_size=min_cluster_size,
+                        cluster_selection_method="leaf", allow_single_cluster=True).fit(embedding)
+    return _cluster_representatives(np.asarray(all_topics), clusterer.labels_, clusterer.probabilities_)
+
+
+_topic_combiner = {
+    "kl_divergence": generate_combined_topics_kl,
+    "hellinger": generate_combined_topics_hellinger,
+    "hellinger_umap": generate_combined_topics_hellinger_umap,
+}
+
+
+def ensemble_fit(X, estimated_n_topics=10, model="plsa", init="random", min_samples=3,
+                 min_cluster_size=4, n_starts=16, n_jobs=1, parallelism="dask",
+                 topic_combination="hellinger_umap", bootstrap=True, n_iter=100, n_iter_per_test=10,
+                 tolerance=0.001, e_step_thresh=1e-16, lift_factor=1, beta_loss=1, alpha=0.0,
+                 solver="mu", random_state=None, device=None):
+    """Stable topics from an ensemble of bootstrapped pLSA fits, then document vectors against them
+    (enstop_.py:417-584).  Returns (doc_vectors [n_docs, M], stable_topics [M, n_words])."""
+    if model != "plsa":
+        raise ValueError('Only model="plsa" is implemented on this engine')
+    if topic_combination not in _topic_combiner:
+        raise ValueError("topic_combination must be one of {}".format(tuple(_topic_combiner.keys())))
+    X = check_array(X, accept_sparse="csr", dtype=np.float32)
+    X = X.tocsr() if issparse(X) else csr_matrix(X, dtype=np.float32)
+    all_topics = ensemble_of_topics(X, estimated_n_topics, model, n_jobs, n_starts, parallelism,
+                                    init=init, n_iter=n_iter, n_iter_per_test=n_iter_per_test,
+                                    tolerance=tolerance, e_step_thresh=e_step_thresh, bootstrap=bootstrap,
+                                    random_state=random_state, device=device)
+    stable_topics = _topic_combiner[topic_combination](all_topics, min_samples, min_cluster_size)
+    if stable_topics.shape[0] == 0:
+        raise ValueError("topic combination found no stable topic cluster; lower min_samples / "
+                         "min_cluster_size or raise n_starts")
+    if lift_factor != 1:
+        stable_topics = stable_topics.astype(np.float64) ** lift_factor
+        stable_topics = (stable_topics / stable_topics.sum(axis=1, keepdims=True)).astype(np.float32)
+    sample_weight = _check_sample_weight(None, X, dtype=np.float32)
+    rs = random_state if not isinstance(random_state, np.random.RandomState) else random_state
+    doc_vectors = plsa_refit(X, stable_topics, sample_weight, e_step_thresh=e_step_thresh,
+                             random_state=rs, device=device)
+    return doc_vectors, stable_topics
+
+
+class EnsembleTopics(BaseEstimator, TransformerMixin):
+    """Ensemble topic modelling with the reference estimator's constructor, methods and fitted
+    attributes (enstop_.py:587-927): `components_`, `embedding_`, `training_data_`,
+    `n_components_`.  `transform` passes unit sample weights to `plsa_refit` (the reference omits
+    the argument and raises TypeError, enstop_.py:847-854)."""
+
+    def __init__(self, n_components=10, model="plsa", init="random", n_starts=16, min_samples=3,
+                 min_cluster_size=5, n_jobs=8, parallelism="dask", topic_combination="hellinger_umap",
+                 bootstrap=True, n_iter=80, n_iter_per_test=10, tolerance=0.001, e_step_thresh=1e-32,
+                 lift_factor=1, beta_loss=1, alpha=0.0, solver="mu", transform_random_seed=42,
+                 random_state=None, device=None):
+        self.n_components = n_components
+        self.model = model
+        self.init = init
+        self.n_starts = n_starts
+        self.min_samples = min_samples
+        self.min_cluster_size = min_cluster_size
+        self.n_jobs = n_jobs
+        self.parallelism = parallelism
+        self.topic_combination = topic_combination
+        self.bootstrap = bootstrap
+        self.n_iter = n_iter
+        self.n_iter_per_test = n_iter_per_test
+        self.tolerance = tolerance
+        self.e_step_thresh = e_step_thresh
+        self.lift_factor = lift_factor
+        self.beta_loss = beta_loss
+        self.alpha = alpha
+        self.solver = solver
+        self.transform_random_seed = transform_random_seed
+        self.random_state = random_state
+        self.device = device
+
+    def fit(self, X, y=None):
+        self.fit_transform(X)
+        return self
+
+    def fit_transform(self, X, y=None, **fit_params):
+        X = check_array(X, accept_sparse="csr")
+        if not issparse(X):
+            X = csr_matrix(X)
+        U, V = ensemble_fit(X, self.n_components, self.model, self.init, self.min_samples,
+                            self.min_cluster_size, self.n_starts, self.n_jobs, self.parallelism,
+                            self.topic_combination, self.bootstrap, self.n_iter, self.n_iter_per_test,
+                            self.tolerance, self.e_step_thresh, self.lift_factor, self.beta_loss,
+                            self.alpha, self.solver, self.random_state, device=self.device)
+        self.components_ = V
+        self.embedding_ = U
+        self.training_data_ = X
+        self.n_components_ = self.components_.shape[0]
+        return U
+
+    def transform(self, X, y=None):
+        X = check_array(X, accept_sparse="csr")
+        random_state = check_random_state(self.transform_random_seed)
+        X = coo_matrix(X) if not issparse(X) else X.tocoo()
+        sample_weight = _check_sample_weight(None, X, dtype=np.float32)
+        return plsa_refit(X, self.components_, sample_weight, n_iter=50, n_iter_per_test=5,
+                          tolerance=0.001, random_state=random_state, device=self.device)

@@ -69,6 +69,10 @@ int plsa_download_active_csr(plsa_ctx *ctx, int32_t *indptr, int32_t *indices, f
  *   memory (e.g. a buffer handed to an RCCL all-gather: the np.vstack of enstop/enstop_.py:231).  */
 int plsa_set_factors(plsa_ctx *ctx, const float *U, const float *V, int64_t n, int64_t m, int32_t k);
 int plsa_get_factors(plsa_ctx *ctx, float *U, float *V);
+/* Throughput-mode alternative to plsa_init(random) + plsa_set_factors: uniform draws from a
+ * counter-based generator, rows L1-normalised, entirely on the device.  NOT the reference's NumPy
+ * MT19937 stream -- use plsa_set_factors for seed-for-seed parity (enstop/plsa.py:455-456).      */
+int plsa_init_factors_device(plsa_ctx *ctx, int32_t k, uint64_t seed);
 int plsa_copy_components_to_device(plsa_ctx *ctx, void *dst_device_km);
 
 /* ---- kernel-level operators ---------------------------------------------------------------------

@@ -409,3 +409,48 @@ def test_init_nndsvd_and_nmf_run(amd):
         U, V = amd.plsa_fit(X, 5, np.ones(200, np.float32), init=init, n_iter=5, random_state=0)
         assert np.all(np.isfinite(U)) and np.all(np.isfinite(V))
         np.testing.assert_allclose(V.sum(1), 1.0, atol=1e-4)
+
+
+def test_device_random_init(amd):
+    """init="device_random": additive throughput option (counter-based RNG on the GPU)."""
+    X = _corpus(400, 700, 0.04, seed=3)
+    ones = np.ones(400, np.float32)
+    kw = dict(init="device_random", n_iter=8, n_iter_per_test=2, tolerance=0.0, return_info=True)
+    U1, V1, i1 = amd.plsa_fit(X, 20, ones, random_state=4, **kw)
+    U2, V2, i2 = amd.plsa_fit(X, 20, ones, random_state=4, **kw)
+    U3, V3, _ = amd.plsa_fit(X, 20, ones, random_state=5, **kw)
+    np.testing.assert_array_equal(U1, U2); np.testing.assert_array_equal(V1, V2)
+    assert not np.array_equal(V1, V3)
+    np.testing.assert_allclose(U1.sum(1), 1.0, atol=1e-5); np.testing.assert_allclose(V1.sum(1), 1.0, atol=1e-4)
+    ll = i1["log_likelihood_trace"].astype(np.float64)
+    assert np.all(np.diff(ll) >= -1e-6 * abs(ll[0]))
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        eng.init_factors_device(20, 9)
+        U0, V0 = eng.get_factors()
+        assert U0.min() > 0 and V0.min() > 0
+        np.testing.assert_allclose(U0.sum(1), 1.0, atol=1e-5); np.testing.assert_allclose(V0.sum(1), 1.0, atol=1e-4)
+        assert abs(U0.mean() - 1 / 20) < 1e-3 and U0.std() > 0.01
+
+
+def test_ensemble_topics_end_to_end(amd):
+    """EnsembleTopics on planted topics: GPU ensemble members -> host clustering -> GPU refit."""
+    rs = np.random.RandomState(0)
+    n, m, k_true = 600, 300, 4
+    topics = rs.dirichlet(np.full(m, 0.03), size=k_true)
+    mix = rs.dirichlet(np.full(k_true, 0.2), size=n)
+    X = sp.csr_matrix(rs.poisson(80 * (mix @ topics)).astype(np.float32))
+    X = X[np.asarray(X.sum(1)).ravel() > 0]
+    model = amd.EnsembleTopics(n_components=k_true, n_starts=8, min_samples=2, min_cluster_size=3,
+                               topic_combination="hellinger", parallelism="none", n_iter=40,
+                               random_state=np.random.RandomState(3))
+    emb = model.fit_transform(X)
+    assert model.components_.shape[1] == m and model.n_components_ == model.components_.shape[0] >= 2
+    assert emb.shape == (X.shape[0], model.n_components_)
+    np.testing.assert_allclose(model.components_.sum(1), 1.0, atol=1e-4)
+    np.testing.assert_allclose(emb.sum(1), 1.0, atol=1e-4)
+    from enstop_amd.ensemble import all_pairs_hellinger_distance
+    D = all_pairs_hellinger_distance(np.vstack([topics, model.components_]))[:k_true, k_true:]
+    assert (D.min(axis=1) < 0.35).sum() >= 3          # most planted topics have a close stable topic
+    tr = model.transform(X[:50])
+    assert tr.shape == (50, model.n_components_)
