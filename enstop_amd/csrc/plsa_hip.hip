@@ -378,6 +378,13 @@ int need_factors(plsa_ctx *c) {
 // ---------------------------------------------------------------------------------------------
 int run_e_step(plsa_ctx *c, float thresh) {
     CHK(ensure_rowidx(c));
+    {   // the materialised schedule needs the whole nnz x kp array: say so instead of a bare OOM
+        const size_t need = sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp;
+        size_t free_b = 0, total_b = 0;
+        if (c->P.cap < need && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + c->P.cap < need)
+            return fail(c, "materialising P(z|w,d) needs %.1f GB but only %.1f GB of HBM are free; use the fused "
+                           "schedule (PLSA_FUSED), which never stores it", need / 1e9, (free_b + c->P.cap) / 1e9);
+    }
     // one tile (64 rows) of slack: the last tile is stored without a predicate
     CHK(ensure(c, c->P, sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp));
     const i64 tiles = (c->nnz + 63) / 64;

@@ -454,3 +454,100 @@ def test_ensemble_topics_end_to_end(amd):
     assert (D.min(axis=1) < 0.35).sum() >= 3          # most planted topics have a close stable topic
     tr = model.transform(X[:50])
     assert tr.shape == (50, model.n_components_)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties (the oracle cannot run these in seconds)
+# ------------------------------------------------------------------------------------------------
+def _host_init(n, m, k, seed):
+    from enstop_amd.plsa import plsa_init
+
+    class S:
+        shape = (n, m)
+    U, V = plsa_init(S, k, rng=np.random.RandomState(seed))
+    return U.astype(np.float32), V.astype(np.float32)
+
+
+@pytest.mark.parametrize("cfg", [(100_000, 50_000, 10_000_000, 32), (1_000_000, 100_000, 100_000_000, 64)],
+                         ids=["config2", "config3"])
+def test_full_size_properties(amd, cfg):
+    n, m, nnz_t, k = cfg
+    with amd.Engine() as eng:
+        nnz = eng.generate_synthetic(n, m, nnz_t, seed=0)
+        assert abs(nnz - nnz_t) / nnz_t < 0.006
+        U0, V0 = _host_init(n, m, k, 42)
+        out = {}
+        for name, flags in MODES.items():
+            eng.set_factors(U0, V0)
+            iters, ll = eng.fit(None, n_iter=5, n_iter_per_test=1, tolerance=0.0, e_step_thresh=1e-32,
+                                flags=flags, trace=True)
+            assert iters == 5 and ll.shape == (6,)
+            ll64 = ll.astype(np.float64)
+            assert np.all(np.diff(ll64) > 0), "EM must increase the log-likelihood from a random start"
+            U, V = eng.get_factors()
+            assert U.min() >= 0 and V.min() >= 0
+            np.testing.assert_allclose(U.sum(1, dtype=np.float64), 1.0, atol=3e-5)
+            np.testing.assert_allclose(V.sum(1, dtype=np.float64), 1.0, atol=3e-4)
+            out[name] = (U, V, ll)
+        # the two schedules are the same algorithm
+        close_ll(out["fused"][2], out["materialised"][2])
+        close_factors(out["fused"][0], out["materialised"][0])
+        close_factors(out["fused"][1], out["materialised"][1])
+        # idempotent re-run: no atomics anywhere -> bit-identical
+        eng.set_factors(U0, V0)
+        eng.fit(None, n_iter=5, n_iter_per_test=1, tolerance=0.0, flags=FUSED, trace=True)
+        U2, V2 = eng.get_factors()
+        np.testing.assert_array_equal(U2, out["fused"][0]); np.testing.assert_array_equal(V2, out["fused"][1])
+        # kernel-level consistency at full size: M-step(E-step(.)) == one fused iteration
+        eng.set_factors(U0, V0)
+        eng.e_step(1e-32, want_host_copy=False)
+        eng.m_step()
+        Um, Vm = eng.get_factors()
+        eng.set_factors(U0, V0)
+        eng.fit(None, n_iter=1, n_iter_per_test=10, tolerance=0.0, flags=FUSED)
+        Uf, Vf = eng.get_factors()
+        close_factors(Uf, Um, tol=2e-5); close_factors(Vf, Vm, tol=2e-5)
+
+
+def test_count_scaling_invariance(amd):
+    """X -> 2X leaves every EM iterate bit-identical (all norms scale by an exact power of two)
+    and doubles the log-likelihood."""
+    with amd.Engine() as eng:
+        eng.generate_synthetic(100_000, 50_000, 10_000_000, seed=1)
+        A = eng.download_active_csr()
+        U0, V0 = _host_init(100_000, 50_000, 32, 7)
+        res = []
+        for scale in (1.0, 2.0):
+            B = A.copy(); B.data = B.data * np.float32(scale)
+            eng.upload_csr(B)
+            eng.set_factors(U0, V0)
+            _, ll = eng.fit(None, n_iter=4, n_iter_per_test=1, tolerance=0.0, flags=FUSED, trace=True)
+            res.append(eng.get_factors() + (ll,))
+        np.testing.assert_array_equal(res[0][0], res[1][0])
+        np.testing.assert_array_equal(res[0][1], res[1][1])
+        np.testing.assert_allclose(res[1][2], 2.0 * res[0][2], rtol=1e-6)
+
+
+def test_document_permutation_equivariance(amd):
+    """Permuting the documents permutes P(z|d) and leaves P(w|z) unchanged (up to summation order)."""
+    with amd.Engine() as eng:
+        n, m, k = 100_000, 50_000, 32
+        eng.generate_synthetic(n, m, 10_000_000, seed=2)
+        A = eng.download_active_csr()
+        U0, V0 = _host_init(n, m, k, 9)
+        eng.set_factors(U0, V0)
+        eng.fit(None, n_iter=4, n_iter_per_test=10, tolerance=0.0, flags=FUSED)
+        U, V = eng.get_factors()
+        perm = np.random.RandomState(0).permutation(n)
+        eng.bootstrap(perm)                         # a permutation is a bootstrap sample without repeats
+        eng.set_factors(U0[perm], V0)
+        eng.fit(None, n_iter=4, n_iter_per_test=10, tolerance=0.0, flags=FUSED)
+        Up, Vp = eng.get_factors()
+        close_factors(Up, U[perm], tol=2e-5)
+        close_factors(Vp, V, tol=2e-5)
+        # and the device gather itself is exact at this size
+        B = eng.download_active_csr()
+        ref = A[perm]
+        np.testing.assert_array_equal(B.indptr, ref.indptr)
+        np.testing.assert_array_equal(B.indices, ref.indices)
+        np.testing.assert_array_equal(B.data, ref.data)
