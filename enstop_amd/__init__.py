@@ -10,9 +10,10 @@ from .plsa import (PLSA, StreamedPLSA, BlockParallelPLSA, log_likelihood, plsa_e
                    plsa_refit_m_step)
 from .enstop_ import ensemble_of_topics, plsa_topics
 from .ensemble import EnsembleTopics, ensemble_fit
+from .sharded import sharded_plsa_fit
 from .engine import Engine, DeviceError, PLSA_FUSED
 
 __all__ = ["PLSA", "StreamedPLSA", "BlockParallelPLSA", "plsa_fit", "plsa_refit", "plsa_fit_inner", "plsa_refit_inner", "plsa_init",
            "plsa_e_step", "plsa_m_step", "plsa_m_step_w_sample_weight", "plsa_refit_m_step",
-           "log_likelihood", "plsa_topics", "ensemble_of_topics", "EnsembleTopics", "ensemble_fit", "Engine", "DeviceError",
+           "log_likelihood", "plsa_topics", "ensemble_of_topics", "EnsembleTopics", "ensemble_fit", "sharded_plsa_fit", "Engine", "DeviceError",
            "PLSA_FUSED"]

@@ -48,6 +48,11 @@ SIGNATURES = {
                            C.POINTER(_i32)]),
     "plsa_refit": (C.c_int, [_ctx, _vp, _i32, _i32, C.c_double, C.c_float, _i32, C.POINTER(_i32), _vp,
                              C.POINTER(_i32)]),
+    "plsa_em_accumulate": (C.c_int, [_ctx, _vp, C.c_float, _vp]),
+    "plsa_em_finish": (C.c_int, [_ctx]),
+    "plsa_accumulator_device": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(_i64)]),
+    "plsa_accumulator_get": (C.c_int, [_ctx, _f32p]),
+    "plsa_accumulator_set": (C.c_int, [_ctx, _f32p]),
     "plsa_timing_enable": (C.c_int, [_ctx, _i32]),
     "plsa_timing_reset": (C.c_int, [_ctx]),
     "plsa_timing_get": (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),

@@ -1018,6 +1018,52 @@ int plsa_refit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_
     return 0;
 }
 
+// ---- doc-sharded single fit: local accumulate / (caller all-reduces) / finish -----------------------
+int plsa_em_accumulate(plsa_ctx *c, const float *sw, float thresh, double *ll_partial) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    const float *d_sw = nullptr;
+    CHK(upload_sw(c, sw, &d_sw));
+    int blocks = 0;
+    CHK(run_row_pass(c, false, ll_partial != nullptr, d_sw, thresh, nullptr, &blocks));
+    CHK(run_col_pass(c, false, d_sw, thresh));
+    if (ll_partial) CHK(finish_ll(c, blocks, ll_partial));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_em_finish(plsa_ctx *c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    CHK(run_v_normalise(c));
+    c->cu ^= 1; c->cv ^= 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_accumulator_device(plsa_ctx *c, void **ptr, int64_t *n_floats) {
+    CHK(need_factors(c));
+    if (ptr) *ptr = c->Vacc.p;
+    if (n_floats) *n_floats = c->m * c->kp;
+    return 0;
+}
+
+int plsa_accumulator_get(plsa_ctx *c, float *host) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    HIPCHK(c, hipMemcpyAsync(host, c->Vacc.p, sizeof(float) * (size_t)c->m * c->kp, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_accumulator_set(plsa_ctx *c, const float *host) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    HIPCHK(c, hipMemcpyAsync(c->Vacc.p, host, sizeof(float) * (size_t)c->m * c->kp, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int plsa_timing_enable(plsa_ctx *c, int32_t on) {
     if (!on) CHK(timing_flush(c));
     c->timing = on != 0;

@@ -196,6 +196,31 @@ class Engine:
         return self._drive(self._L.plsa_refit, sample_weight, n_iter, n_iter_per_test, tolerance,
                            e_step_thresh, flags, trace)
 
+    # -- doc-sharded fit building blocks ---------------------------------------------------------------
+    def em_accumulate(self, sample_weight=None, e_step_thresh=1e-32, want_ll=False):
+        sw = None if sample_weight is None else _f32(sample_weight)
+        ll = C.c_double(0.0)
+        self._ok(self._L.plsa_em_accumulate(self._h, ptr(sw), np.float32(e_step_thresh),
+                                            C.addressof(ll) if want_ll else None))
+        return ll.value if want_ll else None
+
+    def em_finish(self):
+        self._ok(self._L.plsa_em_finish(self._h))
+
+    def accumulator_device(self):
+        p, n = C.c_void_p(), C.c_int64(0)
+        self._ok(self._L.plsa_accumulator_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def accumulator_get(self):
+        _, n = self.accumulator_device()
+        out = np.empty(n, np.float32)
+        self._ok(self._L.plsa_accumulator_get(self._h, out))
+        return out
+
+    def accumulator_set(self, a):
+        self._ok(self._L.plsa_accumulator_set(self._h, _f32(a)))
+
     # -- measurement ---------------------------------------------------------------------------------
     def timing(self, on=True):
         self._ok(self._L.plsa_timing_enable(self._h, int(on)))

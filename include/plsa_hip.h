@@ -109,6 +109,23 @@ int plsa_refit(plsa_ctx *ctx, const float *sw, int32_t n_iter, int32_t n_iter_pe
                double tolerance, float thresh, int32_t flags, int32_t *iters_done, float *ll_trace,
                int32_t *n_ll);
 
+/* ---- doc-sharded single fit ----------------------------------------------------------------------
+ * Replacement for the tile reduction of enstop/distributed_plsa.py:99-131 (dask.delayed tiles summed
+ * with da.dstack(...).sum) and enstop/block_parallel_plsa.py:182-185: every rank (GPU) holds a row
+ * range of X, its rows of P(z|d) and the full P(w|z).  One EM iteration =
+ *   plsa_em_accumulate   fused E+M over the local rows: local P(z|d) rows are final, the
+ *                        un-normalised P(w|z) sums of the local rows are left in the accumulator;
+ *                        ll_partial (nullable) = log-likelihood of the CURRENT factors, local rows
+ *   <all-reduce(sum) of the accumulator across ranks -- the caller's RCCL call on the pointer from
+ *    plsa_accumulator_device, or plsa_accumulator_get/set through the host>
+ *   plsa_em_finish       norm_pwz, division, buffer swap (identical on every rank)
+ * Skipping plsa_em_finish discards the iteration (late stop decision, see plsa_fit).             */
+int plsa_em_accumulate(plsa_ctx *ctx, const float *sw, float thresh, double *ll_partial);
+int plsa_em_finish(plsa_ctx *ctx);
+int plsa_accumulator_device(plsa_ctx *ctx, void **ptr, int64_t *n_floats);
+int plsa_accumulator_get(plsa_ctx *ctx, float *host);
+int plsa_accumulator_set(plsa_ctx *ctx, const float *host);
+
 /* ---- measurement --------------------------------------------------------------------------------
  * HIP events on the context's own stream around every kernel launch (bench.py roofline figures).  */
 int plsa_timing_enable(plsa_ctx *ctx, int32_t on);

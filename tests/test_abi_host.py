@@ -128,3 +128,14 @@ def test_standardize_input():
     assert standardize_input(Xi) is Xi
     Xf = sp.csr_matrix(np.arange(12, dtype=np.float64).reshape(3, 4) + 1)
     np.testing.assert_allclose(np.asarray(standardize_input(Xf).sum(axis=1)).ravel(), 1.0)
+
+
+def test_row_ranges_by_nnz():
+    from enstop_amd.sharded import row_ranges_by_nnz
+    indptr = np.array([0, 10, 10, 30, 35, 80, 100], np.int32)
+    for parts in (1, 2, 3, 4, 6, 9):
+        r = row_ranges_by_nnz(indptr, parts)
+        assert len(r) == parts and r[0][0] == 0 and r[-1][1] == 6
+        assert all(r[i][1] == r[i + 1][0] for i in range(parts - 1)) and all(a <= b for a, b in r)
+    r = row_ranges_by_nnz(indptr, 2)
+    assert abs((indptr[r[0][1]] - indptr[r[0][0]]) - 50) <= 45

@@ -551,3 +551,64 @@ def test_document_permutation_equivariance(amd):
         np.testing.assert_array_equal(B.indptr, ref.indptr)
         np.testing.assert_array_equal(B.indices, ref.indices)
         np.testing.assert_array_equal(B.data, ref.data)
+
+
+# ------------------------------------------------------------------------------------------------
+# doc-sharded single fit (accumulate / all-reduce / finish)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shards", [2, 3])
+def test_sharded_fit_matches_reference_golden(amd, shards):
+    """N row shards on one device (all-reduce emulated through the host) == the reference's fit."""
+    for case in ("fit_k5_earlystop", "fit_k4_weighted", "fit_k16_mid"):
+        g = load_golden(case)
+        X = golden_csr(g)
+        U, V, info = amd.sharded_plsa_fit(X, int(g["k"]), g["sw"], n_iter=int(g["n_iter"]),
+                                          n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+                                          e_step_thresh=float(g["thresh"]), random_state=int(g["fit_seed"]),
+                                          local_shards=shards, return_info=True)
+        assert info["n_iter"] == int(g["iters"])
+        close_ll(info["log_likelihood_trace"], g["ll_trace"])
+        close_factors(U, g["U"]); close_factors(V, g["V"])
+
+
+def test_sharded_fit_matches_single_gpu_fit_midsize(amd):
+    X = _corpus(5000, 3000, 0.02, seed=21, empty_rows=4)
+    sw = np.ones(5000, np.float32)
+    kw = dict(n_iter=12, n_iter_per_test=5, tolerance=0.0, e_step_thresh=1e-16, random_state=3)
+    U1, V1, i1 = amd.plsa_fit(X, 64, sw, return_info=True, **kw)
+    U4, V4, i4 = amd.sharded_plsa_fit(X, 64, sw, local_shards=4, return_info=True, **kw)
+    assert i1["n_iter"] == i4["n_iter"] == 12
+    close_ll(i4["log_likelihood_trace"], i1["log_likelihood_trace"])
+    close_factors(U4, U1, tol=2e-5); close_factors(V4, V1, tol=2e-5)
+
+
+def test_sharded_fit_over_rccl_single_rank(tmp_path):
+    """The torch.distributed path (nccl = RCCL, zero-copy all-reduce on the engine's accumulator)
+    with world_size 1: plumbing check of what the multi-GPU launch runs."""
+    import os, subprocess, sys, textwrap
+    from conftest import ROOT
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent('''
+        import os, sys
+        import numpy as np, scipy.sparse as sp
+        import torch, torch.distributed as dist
+        sys.path.insert(0, os.environ["REPO_ROOT"])
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        import enstop_amd
+        rs = np.random.RandomState(0)
+        X = sp.random(3000, 2000, density=0.02, format="csr", random_state=rs, dtype=np.float32)
+        X.data = np.ceil(X.data * 5).astype(np.float32)
+        sw = np.ones(3000, np.float32)
+        kw = dict(n_iter=8, n_iter_per_test=3, tolerance=0.0, random_state=1)
+        U1, V1, i1 = enstop_amd.plsa_fit(X, 32, sw, return_info=True, **kw)
+        U2, V2, i2 = enstop_amd.sharded_plsa_fit(X, 32, sw, return_info=True, **kw)
+        assert i1["n_iter"] == i2["n_iter"]
+        np.testing.assert_allclose(i2["log_likelihood_trace"], i1["log_likelihood_trace"], rtol=1e-6)
+        assert np.abs(U1 - U2).max() <= 2e-5 * U1.max() and np.abs(V1 - V2).max() <= 2e-5 * V1.max()
+        dist.destroy_process_group()
+        print("sharded-rccl ok")
+    '''))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", REPO_ROOT=ROOT, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "sharded-rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
