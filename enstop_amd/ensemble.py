@@ -19,7 +19,7 @@ from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_array, check_random_state
 
 from .enstop_ import ensemble_of_topics
-from .plsa import plsa_refit
+from .plsa import _TopicMetricsMixin, plsa_refit
 from .utils import _check_sample_weight
 
 
@@ -138,7 +138,7 @@ def ensemble_fit(X, estimated_n_topics=10, model="plsa", init="random", min_samp
     return doc_vectors, stable_topics
 
 
-class EnsembleTopics(BaseEstimator, TransformerMixin):
+class EnsembleTopics(_TopicMetricsMixin, BaseEstimator, TransformerMixin):
     """Ensemble topic modelling with the reference estimator's constructor, methods and fitted
     attributes (enstop_.py:587-927): `components_`, `embedding_`, `training_data_`,
     `n_components_`.  `transform` passes unit sample weights to `plsa_refit` (the reference omits

@@ -22,7 +22,8 @@ from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_array, check_random_state
 
 from .engine import Engine, get_engine
-from .utils import _check_sample_weight, normalize, standardize_input
+from .utils import (_check_sample_weight, coherence, log_lift, mean_coherence, mean_log_lift, normalize,
+                    standardize_input)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -252,7 +253,26 @@ def plsa_refit(X, topics, sample_weight, n_iter=50, n_iter_per_test=10, toleranc
 # ------------------------------------------------------------------------------------------------
 # estimator
 # ------------------------------------------------------------------------------------------------
-class PLSA(BaseEstimator, TransformerMixin):
+class _TopicMetricsMixin:
+    """coherence() / log_lift() of the fitted topics, signatures as enstop/plsa.py:1222-1285."""
+
+    def _metric(self, topic_num, n_words, single, mean):
+        if not isinstance(topic_num, int) and topic_num is not None:
+            raise ValueError("Topic number must be an integer or None.")
+        if topic_num is None:
+            return mean(self.components_, self.training_data_, n_words)
+        if 0 <= topic_num < self.n_components:
+            return single(self.components_, topic_num, self.training_data_, n_words)
+        raise ValueError("Topic number must be in range 0 to {}".format(self.n_components))
+
+    def coherence(self, topic_num=None, n_words=20):
+        return self._metric(topic_num, n_words, coherence, mean_coherence)
+
+    def log_lift(self, topic_num=None, n_words=20):
+        return self._metric(topic_num, n_words, log_lift, mean_log_lift)
+
+
+class PLSA(_TopicMetricsMixin, BaseEstimator, TransformerMixin):
     """Probabilistic Latent Semantic Analysis with the reference estimator's constructor, methods
     and fitted attributes (enstop/plsa.py:1000-1285): `components_` = P(w|z) [k, m],
     `embedding_` = P(z|d) [n, k], `training_data_`.  Additive: `n_iter_` (EM iterations run),

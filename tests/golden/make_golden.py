@@ -277,6 +277,20 @@ def gen_member(name, seed):
          V_rs5=Va, idx_rs5=idx_a, V_int9=Vb, idx_int9=idx_b, V_nobootstrap=Vc, V_stack_rs21=Vd)
 
 
+def gen_metrics(name, seed):
+    """coherence / log_lift of enstop/utils.py on random topics + a small corpus (host-side metrics)."""
+    import enstop.utils as ru
+    n, m, k = 80, 60, 5
+    X = make_counts(n, m, 0.15, seed)
+    rs = np.random.RandomState(seed + 1)
+    topics = rs.dirichlet(np.full(m, 0.3), size=k).astype(np.float32)
+    coh = np.array([ru.coherence(topics, z, X, n_words=10) for z in range(k)])
+    lift = np.array([ru.log_lift(topics, z, X, n_words=10) for z in range(k)])
+    lift_all = np.array([ru.log_lift(topics, z, X) for z in range(k)])
+    save(name, **csr_parts(X), topics=topics, coherence=coh, mean_coherence=np.float64(ru.mean_coherence(topics, X, n_words=10)),
+         log_lift=lift, log_lift_allwords=lift_all, mean_log_lift=np.float64(ru.mean_log_lift(topics, X, n_words=10)))
+
+
 if __name__ == "__main__":
     gen_kernels("kernels_k6", n=40, m=50, k=6, density=0.15, seed=100, thresh=1e-32)
     gen_kernels("kernels_k8_thresh", n=36, m=44, k=8, density=0.2, seed=110, thresh=2.5e-3, zero_doc=3)
@@ -299,3 +313,5 @@ if __name__ == "__main__":
     gen_estimator("estimator_int_emptyrows", "int", empty_rows=(0, 17, 47), seed=420)
 
     gen_member("member_k6", seed=500)
+
+    gen_metrics("metrics", seed=600)

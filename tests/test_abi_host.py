@@ -139,3 +139,26 @@ def test_row_ranges_by_nnz():
         assert all(r[i][1] == r[i + 1][0] for i in range(parts - 1)) and all(a <= b for a, b in r)
     r = row_ranges_by_nnz(indptr, 2)
     assert abs((indptr[r[0][1]] - indptr[r[0][0]]) - 50) <= 45
+
+
+def test_topic_metrics_match_reference():
+    """coherence / log_lift (host-side) against values computed by the reference's enstop/utils.py."""
+    from enstop_amd import utils
+    g = load_golden("metrics")
+    X = golden_csr(g)
+    T = g["topics"]
+    for z in range(T.shape[0]):
+        np.testing.assert_allclose(utils.coherence(T, z, X, n_words=10), g["coherence"][z], rtol=1e-10)
+        np.testing.assert_allclose(utils.log_lift(T, z, X, n_words=10), g["log_lift"][z], rtol=1e-6)
+        np.testing.assert_allclose(utils.log_lift(T, z, X), g["log_lift_allwords"][z], rtol=1e-6)
+    np.testing.assert_allclose(utils.mean_coherence(T, X, n_words=10), g["mean_coherence"], rtol=1e-10)
+    np.testing.assert_allclose(utils.mean_log_lift(T, X, n_words=10), g["mean_log_lift"], rtol=1e-6)
+    from enstop_amd import PLSA
+    model = PLSA(n_components=T.shape[0])
+    model.components_, model.training_data_ = T, X
+    np.testing.assert_allclose(model.coherence(n_words=10), g["mean_coherence"], rtol=1e-10)
+    np.testing.assert_allclose(model.log_lift(2, n_words=10), g["log_lift"][2], rtol=1e-6)
+    with pytest.raises(ValueError):
+        model.coherence(topic_num=99)
+    with pytest.raises(ValueError):
+        model.log_lift(topic_num="a")
