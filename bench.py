@@ -280,7 +280,7 @@ def main():
                 entry["GBps"] = round(bts / 1e9 / (ms / cnt / 1e3), 1)
             kernels_mat[name] = entry
         e_entry = kernels_mat["k_e_step"]
-        mat = {"schedule": "materialised (reference kernel sequence)", "steps": it2,
+        mat = {"schedule": "materialised (reference kernel sequence)", "steps": it2, "p_placement": eng.placement_info(),
                "value": round(it2 / dt2, 4), "ms_per_step": round(dt2 / it2 * 1e3, 4), "kernels": kernels_mat}
 
     out = {

@@ -53,6 +53,8 @@ SIGNATURES = {
     "plsa_accumulator_device": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(_i64)]),
     "plsa_accumulator_get": (C.c_int, [_ctx, _f32p]),
     "plsa_accumulator_set": (C.c_int, [_ctx, _f32p]),
+    "plsa_placement_info": (C.c_int, [_ctx, C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "plsa_release_scratch": (C.c_int, [_ctx]),
     "plsa_timing_enable": (C.c_int, [_ctx, _i32]),
     "plsa_timing_reset": (C.c_int, [_ctx]),
     "plsa_timing_get": (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),

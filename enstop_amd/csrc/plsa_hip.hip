@@ -81,6 +81,9 @@ struct plsa_ctx {
     int cu = 0, cv = 0;
     i64 fac_n = 0, fac_m = 0;
     DevBuf P;
+    int placement_candidates = 4, placement_tried = 0;
+    double placement_gbps[2] = {0.0, 0.0};
+    size_t p_shift = 0;   // experiment knob: byte offset of P inside its allocation (PLSA_P_OFFSET_KB)
     bool p_valid = false;
 
     // small buffers
@@ -97,6 +100,8 @@ struct plsa_ctx {
 };
 
 namespace {
+
+inline float *p_base(plsa_ctx *c) { return reinterpret_cast<float *>(reinterpret_cast<char *>(c->P.p) + c->p_shift); }
 
 int fail(plsa_ctx *c, const char *fmt, ...) {
     char buf[512];
@@ -122,12 +127,66 @@ int fail(plsa_ctx *c, const char *fmt, ...) {
         if (r_) return r_;                                                                         \
     } while (0)
 
+int grid_for(plsa_ctx *c, i64 work_items, int items_per_block);
+bool g_contig = false;   // PLSA_CONTIG=1: ask for physically contiguous HBM for large buffers
+
 int ensure(plsa_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return 0;
     if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    if (g_contig && bytes >= ((size_t)64 << 20)) {
+        if (hipExtMallocWithFlags(&b.p, bytes, hipDeviceMallocContiguous) == hipSuccess) { b.cap = bytes; return 0; }
+        (void)hipGetLastError();
+        b.p = nullptr;
+    }
     HIPCHK(c, hipMalloc(&b.p, bytes));
     b.cap = bytes;
+    return 0;
+}
+
+// HBM placement matters for the streamed P array: the same kernel on the same data ran 6.3 ... 7.4 ms
+// depending only on which physical pages hipMalloc happened to hand out (tools/p_offset_probe*.py;
+// the start offset inside one allocation is irrelevant).  For that one buffer the engine therefore
+// allocates a few candidates, streams a non-temporal fill through each (~5 ms per 25 GB) and keeps
+// the fastest.  Candidates are held simultaneously so the allocator cannot return the same pages.
+int ensure_best_placement(plsa_ctx *c, DevBuf &b, size_t bytes, int max_candidates, double *gbps, int *n_tried) {
+    if (b.cap >= bytes) return 0;
+    if (gbps) { gbps[0] = gbps[1] = 0.0; }
+    if (n_tried) *n_tried = 0;
+    if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t free_b = 0, total_b = 0;
+    int ncand = 1;
+    if (max_candidates > 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        ncand = (int)std::min<size_t>((size_t)max_candidates, (size_t)((double)free_b * 0.6) / std::max<size_t>(bytes, 1));
+    if (ncand < 2 || bytes < ((size_t)256 << 20)) return ensure(c, b, bytes);
+    std::vector<void *> cand;
+    std::vector<float> ms;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const i64 n4 = (i64)(bytes / 16);
+    const int grid = grid_for(c, n4, 256);
+    for (int i = 0; i < ncand; ++i) {
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        cand.push_back(p);
+        hipLaunchKernelGGL((plsa::k_probe_fill<true>), dim3(grid), dim3(256), 0, c->stream, (float *)p, n4);   // first touch
+        (void)hipEventRecord(e0, c->stream);
+        hipLaunchKernelGGL((plsa::k_probe_fill<true>), dim3(grid), dim3(256), 0, c->stream, (float *)p, n4);
+        hipLaunchKernelGGL((plsa::k_probe_fill<true>), dim3(grid), dim3(256), 0, c->stream, (float *)p, n4);
+        (void)hipEventRecord(e1, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e0, e1);
+        ms.push_back(t / 2.f);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (cand.empty()) return ensure(c, b, bytes);
+    size_t best = 0, worst = 0;
+    for (size_t i = 1; i < cand.size(); ++i) { if (ms[i] < ms[best]) best = i; if (ms[i] > ms[worst]) worst = i; }
+    for (size_t i = 0; i < cand.size(); ++i) if (i != best) (void)hipFree(cand[i]);
+    b.p = cand[best]; b.cap = bytes;
+    if (gbps) { gbps[0] = bytes / 1e9 / (ms[best] / 1e3); gbps[1] = bytes / 1e9 / (ms[worst] / 1e3); }
+    if (n_tried) *n_tried = (int)cand.size();
     return 0;
 }
 
@@ -386,14 +445,20 @@ int run_e_step(plsa_ctx *c, float thresh) {
                            "schedule (PLSA_FUSED), which never stores it", need / 1e9, (free_b + c->P.cap) / 1e9);
     }
     // one tile (64 rows) of slack: the last tile is stored without a predicate
-    CHK(ensure(c, c->P, sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp));
+    {   // placement experiment knobs: PLSA_P_SLACK_MB over-allocates, PLSA_P_OFFSET_KB shifts the start
+        const char *s1 = getenv("PLSA_P_SLACK_MB"), *s2 = getenv("PLSA_P_OFFSET_KB");
+        const size_t slack = s1 ? (size_t)atoll(s1) << 20 : 0;
+        c->p_shift = s2 ? (size_t)atoll(s2) * 1024 : 0;
+        CHK(ensure_best_placement(c, c->P, sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp + std::max(slack, c->p_shift),
+                                  c->placement_candidates, c->placement_gbps, &c->placement_tried));
+    }
     const i64 tiles = (c->nnz + 63) / 64;
     const int grid = grid_for(c, tiles, 4);
     CHK(dispatch_shape(c, [&](auto S) {
         Scope s(c, "k_e_step");
         hipLaunchKernelGGL((plsa::k_e_step<decltype(S)>), dim3(grid), dim3(256), 0, c->stream,
                            c->rowidx.as<int>(), c->col, c->nnz, c->U[c->cu].as<float>(),
-                           c->Vt[c->cv].as<float>(), c->P.as<float>(), c->kp, thresh);
+                           c->Vt[c->cv].as<float>(), p_base(c), c->kp, thresh);
     }));
     CHK(launch_check(c, "k_e_step"));
     c->p_valid = true;
@@ -411,7 +476,7 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, floa
         using Sh = decltype(S);
         const int *ip = c->indptr, *cl = c->col;
         const float *vl = c->val, *U = c->U[c->cu].as<float>(), *Vt = c->Vt[c->cv].as<float>();
-        const float *P = c->P.as<float>();
+        const float *P = p_base(c);
         float *Un = c->U[1 - c->cu].as<float>();
         double *llp = c->ll_partials.as<double>();
         const int n = (int)c->n, kp = c->kp;
@@ -450,14 +515,14 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh) {
                                    c->item_col.as<int>(), c->item_start.as<int>(), c->colptr.as<int>(),
                                    c->n_items, c->seg, c->csc_row.as<int>(), c->csc_val.as<float>(),
                                    c->csc_pos.as<int>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
-                                   c->P.as<float>(), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split);
+                                   p_base(c), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split);
             } else {
                 Scope s(c, "k_col_pass<fused>");
                 hipLaunchKernelGGL((plsa::k_col_pass<Sh, false>), dim3(grid), dim3(256), 0, c->stream, order,
                                    c->item_col.as<int>(), c->item_start.as<int>(), c->colptr.as<int>(),
                                    c->n_items, c->seg, c->csc_row.as<int>(), c->csc_val.as<float>(),
                                    c->csc_pos.as<int>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
-                                   c->P.as<float>(), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split);
+                                   p_base(c), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split);
             }
         }
         {
@@ -595,6 +660,8 @@ int plsa_create(int device, plsa_ctx **out) {
     int mult = 64;   // blocks per CU a grid may hold: large grids measured best
     if (const char *s = getenv("PLSA_GRID_MULT")) mult = std::max(1, atoi(s));
     c->grid_cap = c->prop.multiProcessorCount * mult;
+    if (const char *s = getenv("PLSA_CONTIG")) g_contig = atoi(s) != 0;
+    if (const char *s = getenv("PLSA_PLACEMENT_CANDIDATES")) c->placement_candidates = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_COL_SEG")) c->seg = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_HEAVY_ITEMS")) c->heavy_items = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_SORT_ROWS")) c->sort_rows = atoi(s) != 0;
@@ -838,7 +905,7 @@ int plsa_e_step(plsa_ctx *c, float thresh, float *P_out) {
     CHK(need_factors(c));
     CHK(run_e_step(c, thresh));
     if (P_out && c->nnz)
-        HIPCHK(c, hipMemcpy2DAsync(P_out, sizeof(float) * c->k, c->P.p, sizeof(float) * c->kp,
+        HIPCHK(c, hipMemcpy2DAsync(P_out, sizeof(float) * c->k, p_base(c), sizeof(float) * c->kp,
                                    sizeof(float) * c->k, (size_t)c->nnz, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -847,10 +914,10 @@ int plsa_e_step(plsa_ctx *c, float thresh, float *P_out) {
 int plsa_set_p(plsa_ctx *c, const float *P) {
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
-    CHK(ensure(c, c->P, sizeof(float) * (size_t)(c->nnz + 64) * c->kp));
-    if (c->kp != c->k) HIPCHK(c, hipMemsetAsync(c->P.p, 0, sizeof(float) * (size_t)c->nnz * c->kp, c->stream));
+    CHK(ensure(c, c->P, sizeof(float) * (size_t)(c->nnz + 64) * c->kp + c->p_shift));
+    if (c->kp != c->k) HIPCHK(c, hipMemsetAsync(p_base(c), 0, sizeof(float) * (size_t)c->nnz * c->kp, c->stream));
     if (c->nnz)
-        HIPCHK(c, hipMemcpy2DAsync(c->P.p, sizeof(float) * c->kp, P, sizeof(float) * c->k,
+        HIPCHK(c, hipMemcpy2DAsync(p_base(c), sizeof(float) * c->kp, P, sizeof(float) * c->k,
                                    sizeof(float) * c->k, (size_t)c->nnz, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->p_valid = true;
@@ -1061,6 +1128,22 @@ int plsa_accumulator_set(plsa_ctx *c, const float *host) {
     CHK(need_factors(c));
     HIPCHK(c, hipMemcpyAsync(c->Vacc.p, host, sizeof(float) * (size_t)c->m * c->kp, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_placement_info(plsa_ctx *c, int32_t *candidates, double *best_gbps, double *worst_gbps) {
+    if (candidates) *candidates = c->placement_tried;
+    if (best_gbps) *best_gbps = c->placement_gbps[0];
+    if (worst_gbps) *worst_gbps = c->placement_gbps[1];
+    return 0;
+}
+
+int plsa_release_scratch(plsa_ctx *c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    release(c->P); release(c->partial); release(c->tmp0); release(c->tmp1); release(c->tmp2); release(c->cubtmp);
+    c->p_valid = false;
+    c->p_shift = 0;
     return 0;
 }
 

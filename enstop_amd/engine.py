@@ -221,6 +221,15 @@ class Engine:
     def accumulator_set(self, a):
         self._ok(self._L.plsa_accumulator_set(self._h, _f32(a)))
 
+    def placement_info(self):
+        n, a, b = C.c_int32(0), C.c_double(0.0), C.c_double(0.0)
+        self._ok(self._L.plsa_placement_info(self._h, C.byref(n), C.byref(a), C.byref(b)))
+        return dict(candidates=n.value, kept_fill_GBps=round(a.value, 1), worst_fill_GBps=round(b.value, 1))
+
+    def release_scratch(self):
+        """Free the materialised P and other large scratch buffers (re-created on demand)."""
+        self._ok(self._L.plsa_release_scratch(self._h))
+
     # -- measurement ---------------------------------------------------------------------------------
     def timing(self, on=True):
         self._ok(self._L.plsa_timing_enable(self._h, int(on)))

@@ -126,6 +126,15 @@ int plsa_accumulator_device(plsa_ctx *ctx, void **ptr, int64_t *n_floats);
 int plsa_accumulator_get(plsa_ctx *ctx, float *host);
 int plsa_accumulator_set(plsa_ctx *ctx, const float *host);
 
+/* The materialised P array is placed by probing: up to PLSA_PLACEMENT_CANDIDATES (default 4)
+ * allocations are streamed through once and the fastest is kept (HBM placement alone moves the
+ * E-step by ~15 %).  Reports the last probe: candidates tried and the fill
+ * bandwidth of the kept / the worst candidate (0 when no probing took place).                    */
+int plsa_placement_info(plsa_ctx *ctx, int32_t *candidates, double *best_gbps, double *worst_gbps);
+
+/* frees the large scratch buffers (materialised P, column-pass partials); they are re-created on demand */
+int plsa_release_scratch(plsa_ctx *ctx);
+
 /* ---- measurement --------------------------------------------------------------------------------
  * HIP events on the context's own stream around every kernel launch (bench.py roofline figures).  */
 int plsa_timing_enable(plsa_ctx *ctx, int32_t on);
