@@ -657,7 +657,7 @@ int plsa_create(int device, plsa_ctx **out) {
         delete c;
         return fail(nullptr, "stream / pinned buffer creation failed");
     }
-    int mult = 64;   // blocks per CU a grid may hold: large grids measured best
+    int mult = 128;  // blocks per CU a grid may hold: large (but bounded) grids measured best
     if (const char *s = getenv("PLSA_GRID_MULT")) mult = std::max(1, atoi(s));
     c->grid_cap = c->prop.multiProcessorCount * mult;
     if (const char *s = getenv("PLSA_CONTIG")) g_contig = atoi(s) != 0;

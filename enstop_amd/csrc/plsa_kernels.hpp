@@ -28,6 +28,9 @@
 #define PLSA_NT_STREAMS 0   // non-temporal loads for read-once streams: measured neutral on the fused
                             // passes and -14 % on the E-step (U rows are re-used from L1 by ~100 nnz)
 #endif
+#ifndef PLSA_UNR_E
+#define PLSA_UNR_E PLSA_UNR   // E-step: steps (of 64/LPN non-zeros each) per gather batch
+#endif
 #ifndef PLSA_UNR_COL
 #define PLSA_UNR_COL 8  // same for the column pass (its U gathers miss L2 more often: measured best)
 #endif
@@ -62,11 +65,12 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
 typedef float f4v __attribute__((ext_vector_type(4)));
+// P stores are non-temporal.  sc1 / sc0 sc1 (write-through, line dropped from L2) and sc1 nt were
+// measured 4-9 % slower for the E-step on MI355X; plain stores 5 % slower (they evict the factor rows).
 __device__ __forceinline__ void st4_nt(float *p, const float4 &v) {
     f4v t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));  // global_store_dwordx4 ... nt
 }
-
 __device__ __forceinline__ float4 ld4_nt(const float *p) {
     const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));   // global_load_dwordx4 ... nt
     return make_float4(t.x, t.y, t.z, t.w);
@@ -82,6 +86,7 @@ struct Shape {
     static constexpr bool FULL = FULL_;
     static constexpr int UNR = (LPN_ < PLSA_UNR) ? LPN_ : PLSA_UNR;
     static constexpr int UNR_COL = (LPN_ < PLSA_UNR_COL) ? LPN_ : PLSA_UNR_COL;
+    static constexpr int UNR_E = (LPN_ < PLSA_UNR_E) ? LPN_ : PLSA_UNR_E;
     __device__ static __forceinline__ int kp(int kp_rt) { return FULL_ ? 4 * LPN_ * CH_ : kp_rt; }
     // offset of chunk j for lane li, and whether it lies inside the row
     __device__ static __forceinline__ int c4(int li, int j) { return 4 * (li + LPN_ * j); }
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void k_e_step(const int *__restrict__ rowidx,
                                                 const float *__restrict__ U,
                                                 const float *__restrict__ Vt, float *__restrict__ P,
                                                 int kp_rt, float thresh) {
-    constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR;
+    constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR_E;
     constexpr int GPW = 64 / LPN;  // groups (= non-zeros per step) per wave
     const int kp = S::kp(kp_rt);
     const int lane = threadIdx.x & 63;
