@@ -68,12 +68,18 @@ struct plsa_ctx {
 
     // CSC copy + column items
     bool csc_valid = false;
-    int seg = 256;
+    int seg = 256, seg_override = 0;   // column item length: adaptive unless PLSA_COL_SEG is set
     i64 n_items = 0;
     DevBuf colptr, csc_row, csc_val, csc_pos, item_first, item_col, item_start, item_order, partial, heavy_cols;
     bool use_item_order = true, xcd_split = true;
     int chunks_per_lane = 2;
     int heavy_items = 32, n_heavy = 0;
+
+    // row items (documents cut into pieces) for corpora with few / very uneven rows
+    bool ritems_valid = false, use_ritems = false;
+    int rseg = 64, ritems_mode = -1;   // -1 auto, 0 never, 1 always (PLSA_ROW_ITEMS)
+    i64 n_ritems = 0;
+    DevBuf ritem_first, ritem_row, ritem_start, rpartial;
 
     // rows in descending-length order (row-owned kernels: groups of a wave finish together)
     bool sort_rows = true, roworder_valid = false;
@@ -293,6 +299,7 @@ void set_active_pointers(plsa_ctx *c) {
     c->rowidx_valid = false;
     c->csc_valid = false;
     c->roworder_valid = false;
+    c->ritems_valid = false;
     c->p_valid = false;
 }
 
@@ -334,6 +341,39 @@ int ensure_roworder(plsa_ctx *c, const int **out) {
     return 0;
 }
 
+int exclusive_sum_int(plsa_ctx *c, const int *in, int *out, i64 count);
+
+// Decide whether the document pass should run over row items, and build them.  Row ownership needs
+// enough rows to fill 256 CUs x 32 waves x (64/LPN) groups, and rows of comparable length.
+int ensure_ritems(plsa_ctx *c) {
+    if (c->ritems_valid) return 0;
+    const i64 n = c->n;
+    const i64 group_slots = (i64)c->prop.multiProcessorCount * 32 * (64 / std::max(1, c->lpn));
+    const double avg = (double)c->nnz / (double)std::max<i64>(n, 1);
+    c->use_ritems = c->ritems_mode == 1 || (c->ritems_mode < 0 && n < 2 * group_slots && avg > 2.0 * c->rseg);
+    c->n_ritems = 0;
+    if (c->use_ritems) {
+        CHK(ensure(c, c->ritem_first, sizeof(int) * (size_t)(n + 1)));
+        CHK(ensure(c, c->tmp0, sizeof(int) * (size_t)(n + 1)));
+        HIPCHK(c, hipMemsetAsync(c->tmp0.p, 0, sizeof(int) * (size_t)(n + 1), c->stream));
+        hipLaunchKernelGGL(plsa::k_item_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           c->indptr, (int)n, c->rseg, c->tmp0.as<int>());
+        CHK(exclusive_sum_int(c, c->tmp0.as<int>(), c->ritem_first.as<int>(), n + 1));
+        int cnt = 0;
+        HIPCHK(c, hipMemcpyAsync(&cnt, c->ritem_first.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->n_ritems = cnt;
+        CHK(ensure(c, c->ritem_row, sizeof(int) * (size_t)std::max(cnt, 1)));
+        CHK(ensure(c, c->ritem_start, sizeof(int) * (size_t)std::max(cnt, 1)));
+        hipLaunchKernelGGL(plsa::k_ritem_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           c->indptr, c->ritem_first.as<int>(), (int)n, c->rseg, c->ritem_row.as<int>(),
+                           c->ritem_start.as<int>());
+        CHK(launch_check(c, "k_ritem_fill"));
+    }
+    c->ritems_valid = true;
+    return 0;
+}
+
 int exclusive_sum_int(plsa_ctx *c, const int *in, int *out, i64 count) {
     size_t bytes = 0;
     HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)count, c->stream));
@@ -345,6 +385,15 @@ int exclusive_sum_int(plsa_ctx *c, const int *in, int *out, i64 count) {
 int ensure_csc(plsa_ctx *c) {
     if (c->csc_valid) return 0;
     CHK(ensure_rowidx(c));
+    {   // item length: a group walks seg/LPN dependent gather batches per item, so small problems want
+        // short items (enough items to fill the chip: config 1 0.244 -> 0.094 ms at 16) and large
+        // ones long items (fewer partial rows: 256 measured best at config 3)
+        const i64 slots = (i64)c->prop.multiProcessorCount * 32 * (64 / std::max(1, c->lpn));
+        i64 want = c->nnz / std::max<i64>(4 * slots, 1);
+        int seg = 16;
+        while (seg * 2 <= want && seg < 256) seg *= 2;
+        c->seg = c->seg_override ? c->seg_override : seg;
+    }
     const i64 nnz = c->nnz, m = c->m;
     CHK(ensure(c, c->colptr, sizeof(int) * (size_t)(m + 1)));
     CHK(ensure(c, c->csc_row, sizeof(int) * (size_t)nnz));
@@ -473,9 +522,17 @@ int run_e_step(plsa_ctx *c, float thresh) {
 // document-owned pass: writes U[1-cu]; optional LL partials of the current factors
 int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, float thresh,
                  float *d_norm_pdz, int *ll_blocks) {
-    const int grid = grid_for(c, c->n, 256 / c->lpn);
+    CHK(ensure_ritems(c));
+    const bool items = c->use_ritems && c->n_ritems > 0;
+    const int grid = grid_for(c, items ? c->n_ritems : c->n, 256 / c->lpn);
     const int *order = nullptr;
-    CHK(ensure_roworder(c, &order));
+    if (!items) CHK(ensure_roworder(c, &order));
+    if (items) CHK(ensure(c, c->rpartial, sizeof(float) * (size_t)c->n_ritems * c->kp));
+    const int *ri_row = items ? c->ritem_row.as<int>() : nullptr;
+    const int *ri_start = items ? c->ritem_start.as<int>() : nullptr;
+    float *rpart = items ? c->rpartial.as<float>() : nullptr;
+    const int rseg = c->rseg;
+    const i64 n_ritems = c->n_ritems;
     if (want_ll) CHK(ensure(c, c->ll_partials, sizeof(double) * (size_t)grid));
     CHK(dispatch_shape(c, [&](auto S) {
         using Sh = decltype(S);
@@ -489,13 +546,18 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, floa
             Scope s(c, name);
             hipLaunchKernelGGL((plsa::k_row_pass<Sh, decltype(FP)::value, decltype(LL)::value>),
                                dim3(grid), dim3(256), 0, c->ls, ip, cl, vl, n, order, U, Vt, P, Un,
-                               d_sw, d_norm_pdz, kp, thresh, llp);
+                               d_sw, d_norm_pdz, kp, thresh, llp, ri_row, ri_start, rseg, n_ritems, rpart);
         };
         using T = std::true_type;
         using F = std::false_type;
         if (from_p) go(T{}, F{}, "k_row_pass<P>");
         else if (want_ll) go(F{}, T{}, "k_row_pass<fused,LL>");
         else go(F{}, F{}, "k_row_pass<fused>");
+        if (items) {
+            Scope s(c, "k_row_reduce");
+            hipLaunchKernelGGL((plsa::k_row_reduce<Sh>), dim3(grid_for(c, c->n, 256 / Sh::LPN)), dim3(256), 0, c->ls,
+                               c->ritem_first.as<int>(), n, rpart, Un, d_norm_pdz, kp);
+        }
     }));
     CHK(launch_check(c, "k_row_pass"));
     if (ll_blocks) *ll_blocks = grid;
@@ -667,12 +729,14 @@ int plsa_create(int device, plsa_ctx **out) {
     }
     c->ls = c->stream;
     if (const char *s = getenv("PLSA_OVERLAP")) c->overlap = atoi(s) != 0;
+    if (const char *s = getenv("PLSA_ROW_ITEMS")) c->ritems_mode = atoi(s);
+    if (const char *s = getenv("PLSA_ROW_SEG")) c->rseg = std::max(1, atoi(s));
     int mult = 128;  // blocks per CU a grid may hold: large (but bounded) grids measured best
     if (const char *s = getenv("PLSA_GRID_MULT")) mult = std::max(1, atoi(s));
     c->grid_cap = c->prop.multiProcessorCount * mult;
     if (const char *s = getenv("PLSA_CONTIG")) g_contig = atoi(s) != 0;
     if (const char *s = getenv("PLSA_PLACEMENT_CANDIDATES")) c->placement_candidates = std::max(1, atoi(s));
-    if (const char *s = getenv("PLSA_COL_SEG")) c->seg = std::max(1, atoi(s));
+    if (const char *s = getenv("PLSA_COL_SEG")) c->seg_override = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_HEAVY_ITEMS")) c->heavy_items = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_SORT_ROWS")) c->sort_rows = atoi(s) != 0;
     if (const char *s = getenv("PLSA_ITEM_ORDER")) c->use_item_order = atoi(s) != 0;
@@ -688,7 +752,7 @@ void plsa_destroy(plsa_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
-                     &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,
+                     &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,
                      &c->P, &c->sw, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
                      &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp};
     for (DevBuf *b : all) release(*b);
@@ -824,6 +888,8 @@ int plsa_set_factors(plsa_ctx *c, const float *U, const float *V, int64_t n, int
     const int kp = (k + 3) / 4 * 4;
     c->k = k; c->kp = kp;
     c->fac_n = n; c->fac_m = m;
+    c->ritems_valid = false;      // the row-item decision depends on the lane shape
+    if (!c->seg_override) c->csc_valid = false;   // ... and so does the column item length
     int lpn = 1;
     while (lpn < kp / 4 && lpn < 64) lpn *= 2;
     // k >= 128: 8 floats per lane (two float4 chunks) -- fewer reduction/shuffle instructions per
@@ -861,6 +927,8 @@ int plsa_init_factors_device(plsa_ctx *c, int32_t k, uint64_t seed) {
     const i64 n = c->n, m = c->m;
     const int kp = (k + 3) / 4 * 4;
     c->k = k; c->kp = kp; c->fac_n = n; c->fac_m = m;
+    c->ritems_valid = false;
+    if (!c->seg_override) c->csc_valid = false;
     int lpn = 1;
     while (lpn < kp / 4 && lpn < 64) lpn *= 2;
     if (lpn >= 32 && lpn * 4 >= kp && c->chunks_per_lane == 2) lpn /= 2;
@@ -1011,8 +1079,9 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 // (fabric-bound gathers of P(z|d) rows) read the same current factors and write
                 // disjoint outputs: run them on two streams so their stalls overlap
                 CHK(ensure_csc(c));
+                CHK(ensure_ritems(c));
                 const int *unused = nullptr;
-                CHK(ensure_roworder(c, &unused));
+                if (!c->use_ritems) CHK(ensure_roworder(c, &unused));
                 HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
                 HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
                 c->ls = c->stream2;

@@ -221,16 +221,25 @@ __global__ __launch_bounds__(256) void k_row_pass(const int *__restrict__ indptr
                                                   float *__restrict__ U_new,
                                                   const float *__restrict__ sw,
                                                   float *__restrict__ norm_pdz_out, int kp_rt,
-                                                  float thresh, double *__restrict__ ll_partials) {
+                                                  float thresh, double *__restrict__ ll_partials,
+                                                  const int *__restrict__ ritem_row,
+                                                  const int *__restrict__ ritem_start, int rseg,
+                                                  i64 n_ritems, float *__restrict__ rpartial) {
     constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR;
     constexpr int GPB = 256 / LPN;  // groups per block
     const int kp = S::kp(kp_rt);
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
     double ll = 0.0;
-    for (i64 r = (i64)blockIdx.x * GPB + gid; r < n; r += (i64)gridDim.x * GPB) {
-        const int d = row_order ? row_order[r] : (int)r;
-        const int j0 = indptr[d], j1 = indptr[d + 1];
+    // item mode (ritem_row != nullptr): rows are cut into items of <= rseg entries, a group owns
+    // one item and writes an un-normalised partial row that k_row_reduce adds up in item order.
+    // Used when there are too few / too uneven rows to fill the chip (few long documents).
+    const bool items = ritem_row != nullptr;
+    const i64 n_work = items ? n_ritems : (i64)n;
+    for (i64 r = (i64)blockIdx.x * GPB + gid; r < n_work; r += (i64)gridDim.x * GPB) {
+        const int d = items ? ritem_row[r] : (row_order ? row_order[r] : (int)r);
+        const int j0 = items ? ritem_start[r] : indptr[d];
+        const int j1 = items ? min(j0 + rseg, indptr[d + 1]) : indptr[d + 1];
         float4 u[CH], acc[CH];
         load_row<S, true, PLSA_NT_STREAMS>(U + (i64)d * kp, li, kp, u);
 #pragma unroll
@@ -281,6 +290,12 @@ __global__ __launch_bounds__(256) void k_row_pass(const int *__restrict__ indptr
                 }
             }
         }
+        if (items) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (S::ok(li, j, kp)) st4(rpartial + r * kp + S::c4(li, j), acc[j]);
+            continue;
+        }
         // norm_pdz[d] and the division, plsa.py:194, 200-202
         float part = 0.f;
 #pragma unroll
@@ -309,6 +324,59 @@ __global__ __launch_bounds__(256) void k_row_pass(const int *__restrict__ indptr
     }
 }
 
+// k_row_reduce: adds the item partials of each document (fixed order), then norm_pdz and the
+// division (plsa.py:194, 200-202) -- the tail of k_row_pass for the item mode.
+template <class S>
+__global__ __launch_bounds__(256) void k_row_reduce(const int *__restrict__ ritem_first, int n,
+                                                    const float *__restrict__ rpartial,
+                                                    float *__restrict__ U_new,
+                                                    float *__restrict__ norm_pdz_out, int kp_rt) {
+    constexpr int LPN = S::LPN, CH = S::CH;
+    constexpr int GPB = 256 / LPN;
+    const int kp = S::kp(kp_rt);
+    const int li = threadIdx.x % LPN;
+    const int gid = threadIdx.x / LPN;
+    for (i64 d = (i64)blockIdx.x * GPB + gid; d < n; d += (i64)gridDim.x * GPB) {
+        const int i0 = ritem_first[d], i1 = ritem_first[d + 1];
+        float4 acc[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[j] = zero4();
+        for (int it = i0; it < i1; ++it) {
+            float4 p[CH];
+            load_row<S, true>(rpartial + (i64)it * kp, li, kp, p);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                acc[j].x += p[j].x; acc[j].y += p[j].y; acc[j].z += p[j].z; acc[j].w += p[j].w;
+            }
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) part += hsum(acc[j]);
+        const float rown = group_sum<LPN>(part);
+        if (norm_pdz_out && li == 0) norm_pdz_out[d] = rown;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (S::ok(li, j, kp)) {
+                float4 o = acc[j];
+                if (rown > 0.f) { o.x /= rown; o.y /= rown; o.z /= rown; o.w /= rown; }
+                st4(U_new + d * kp + S::c4(li, j), o);
+            }
+        }
+    }
+}
+
+__global__ void k_ritem_fill(const int *__restrict__ indptr, const int *__restrict__ ritem_first, int n,
+                             int seg, int *__restrict__ ritem_row, int *__restrict__ ritem_start) {
+    const i64 d = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n) {
+        const int i0 = ritem_first[d], i1 = ritem_first[d + 1];
+        for (int i = i0; i < i1; ++i) {
+            ritem_row[i] = (int)d;
+            ritem_start[i] = indptr[d] + (i - i0) * seg;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_col_pass: vocabulary-owned half of the M-step (plsa.py:190/296, 193/299) without atomics.  The
 // active matrix is also held column-major (CSC: colptr, csc_row, csc_val, csc_pos = position of the
@@ -319,6 +387,44 @@ __global__ __launch_bounds__(256) void k_row_pass(const int *__restrict__ indptr
 // concurrently gather from the same band of U rows.  FROM_P = false recomputes the
 // responsibilities from U (gather) and Vt (registers).
 // ------------------------------------------------------------------------------------------------
+// one batch of UN entries of a column item: all UN gathers are issued before the first use
+template <class S, bool FROM_P, int UN>
+__device__ __forceinline__ void col_batch(int s0, int d_l, float x_l, int p_l, int li, int kp, float thresh,
+                                          const float *__restrict__ U, const float *__restrict__ P,
+                                          const float4 (&vt)[S::CH], float4 (&acc)[S::CH]) {
+    constexpr int LPN = S::LPN, CH = S::CH;
+    float4 a[UN][CH];   // U rows (fused) or P rows (FROM_P)
+    float x[UN];
+#pragma unroll
+    for (int q = 0; q < UN; ++q) {
+        x[q] = __shfl(x_l, s0 + q, LPN);     // lanes beyond the item hold (doc 0, count 0): exact zeros
+        if (FROM_P) {
+            const int pos = __shfl(p_l, s0 + q, LPN);
+            load_row<S, false>(P + (i64)pos * kp, li, kp, a[q]);
+        } else {
+            const int d = __shfl(d_l, s0 + q, LPN);
+            load_row<S, false>(U + (i64)d * kp, li, kp, a[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < UN; ++q) {
+        float4 pz[CH];
+        if (FROM_P) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) pz[j] = S::ok(li, j, kp) ? a[q][j] : zero4();
+        } else {
+            float unth;
+            const float norm = group_sum<LPN>(products<CH, false>(a[q], vt, thresh, pz, unth));
+            x[q] *= inv_norm(norm);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            acc[j].x += x[q] * pz[j].x; acc[j].y += x[q] * pz[j].y;
+            acc[j].z += x[q] * pz[j].z; acc[j].w += x[q] * pz[j].w;
+        }
+    }
+}
+
 template <class S, bool FROM_P>
 __global__ __launch_bounds__(256) void k_col_pass(const int *__restrict__ item_order,
                                                   const int *__restrict__ item_col,
@@ -367,38 +473,14 @@ __global__ __launch_bounds__(256) void k_col_pass(const int *__restrict__ item_o
             if (FROM_P) p_n = jn < j1 ? ldi(csc_pos + jn) : 0;
             if (sw) x_l *= sw[d_l];  // t = s * sample_weight[d]  (plsa.py:294), folded into the count
             const int cnt = min(LPN, j1 - jb);
-            for (int s0 = 0; s0 < cnt; s0 += UNR) {
-                float4 a[UNR][CH];   // U rows (fused) or P rows (FROM_P)
-                float x[UNR];
-#pragma unroll
-                for (int q = 0; q < UNR; ++q) {
-                    x[q] = __shfl(x_l, s0 + q, LPN);
-                    if (FROM_P) {
-                        const int pos = __shfl(p_l, s0 + q, LPN);
-                        load_row<S, false>(P + (i64)pos * kp, li, kp, a[q]);
-                    } else {
-                        const int d = __shfl(d_l, s0 + q, LPN);
-                        load_row<S, false>(U + (i64)d * kp, li, kp, a[q]);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < UNR; ++q) {
-                    float4 pz[CH];
-                    if (FROM_P) {
-#pragma unroll
-                        for (int j = 0; j < CH; ++j) pz[j] = S::ok(li, j, kp) ? a[q][j] : zero4();
-                    } else {
-                        float unth;
-                        const float norm = group_sum<LPN>(products<CH, false>(a[q], vt, thresh, pz, unth));
-                        x[q] *= inv_norm(norm);
-                    }
-#pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        acc[j].x += x[q] * pz[j].x; acc[j].y += x[q] * pz[j].y;
-                        acc[j].z += x[q] * pz[j].z; acc[j].w += x[q] * pz[j].w;
-                    }
-                }
-            }
+            // full batches of UNR gathers, then the remainder two at a time: most vocabulary columns
+            // are short (Zipf tail) and must not pay for UNR padded gathers
+            int s0 = 0;
+            for (; s0 + UNR <= cnt; s0 += UNR)
+                col_batch<S, FROM_P, UNR>(s0, d_l, x_l, p_l, li, kp, thresh, U, P, vt, acc);
+            constexpr int TAIL = (UNR >= 2 && LPN >= 2) ? 2 : 1;
+            for (; s0 < cnt; s0 += TAIL)
+                col_batch<S, FROM_P, TAIL>(s0, d_l, x_l, p_l, li, kp, thresh, U, P, vt, acc);
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j)
