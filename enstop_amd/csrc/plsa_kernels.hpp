@@ -31,6 +31,9 @@
 #ifndef PLSA_UNR_E
 #define PLSA_UNR_E PLSA_UNR   // E-step: steps (of 64/LPN non-zeros each) per gather batch
 #endif
+#ifndef PLSA_WAVES
+#define PLSA_WAVES 1    // min waves per SIMD requested from the register allocator for the hot kernels
+#endif
 #ifndef PLSA_UNR_COL
 #define PLSA_UNR_COL 8  // same for the column pass (its U gathers miss L2 more often: measured best)
 #endif
@@ -153,7 +156,7 @@ __device__ __forceinline__ void scale(float4 (&a)[CH], float s) {
 // Algorithmic bytes: 4(n+1) + 4 nnz + 4k nnz + 4k(n+m)   (SURVEY.md section 8d).
 // ------------------------------------------------------------------------------------------------
 template <class S>
-__global__ __launch_bounds__(256) void k_e_step(const int *__restrict__ rowidx,
+__global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step(const int *__restrict__ rowidx,
                                                 const int *__restrict__ colidx, i64 nnz,
                                                 const float *__restrict__ U,
                                                 const float *__restrict__ Vt, float *__restrict__ P,
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void k_e_step(const int *__restrict__ rowidx,
 // together; entries beyond the row end are padded with (word 0, count 0) and add exact zeros.
 // ------------------------------------------------------------------------------------------------
 template <class S, bool FROM_P, bool WANT_LL>
-__global__ __launch_bounds__(256) void k_row_pass(const int *__restrict__ indptr,
+__global__ __launch_bounds__(256, PLSA_WAVES) void k_row_pass(const int *__restrict__ indptr,
                                                   const int *__restrict__ colidx,
                                                   const float *__restrict__ vals, int n,
                                                   const int *__restrict__ row_order,
@@ -426,7 +429,7 @@ __device__ __forceinline__ void col_batch(int s0, int d_l, float x_l, int p_l, i
 }
 
 template <class S, bool FROM_P>
-__global__ __launch_bounds__(256) void k_col_pass(const int *__restrict__ item_order,
+__global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int *__restrict__ item_order,
                                                   const int *__restrict__ item_col,
                                                   const int *__restrict__ item_start,
                                                   const int *__restrict__ colptr, i64 n_items,
@@ -659,7 +662,7 @@ __global__ void k_ll_final(const double *__restrict__ partials, int nb, double *
 
 // standalone log-likelihood, plsa.py:375-384 (row-owned; same traversal as k_row_pass)
 template <class S>
-__global__ __launch_bounds__(256) void k_loglik(const int *__restrict__ indptr,
+__global__ __launch_bounds__(256, PLSA_WAVES) void k_loglik(const int *__restrict__ indptr,
                                                 const int *__restrict__ colidx,
                                                 const float *__restrict__ vals, int n,
                                                 const int *__restrict__ row_order,
