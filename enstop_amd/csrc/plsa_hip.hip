@@ -68,7 +68,7 @@ struct plsa_ctx {
 
     // CSC copy + column items
     bool csc_valid = false;
-    int seg = 256, seg_override = 0;   // column item length: adaptive unless PLSA_COL_SEG is set
+    int seg = 256, seg_override = 0, struct_lpn = 0;   // column item length: adaptive unless PLSA_COL_SEG is set
     i64 n_items = 0;
     DevBuf colptr, csc_row, csc_val, csc_pos, item_first, item_col, item_start, item_order, partial, heavy_cols;
     bool use_item_order = true, xcd_split = true;
@@ -888,8 +888,7 @@ int plsa_set_factors(plsa_ctx *c, const float *U, const float *V, int64_t n, int
     const int kp = (k + 3) / 4 * 4;
     c->k = k; c->kp = kp;
     c->fac_n = n; c->fac_m = m;
-    c->ritems_valid = false;      // the row-item decision depends on the lane shape
-    if (!c->seg_override) c->csc_valid = false;   // ... and so does the column item length
+    const int prev_lpn = c->struct_lpn;
     int lpn = 1;
     while (lpn < kp / 4 && lpn < 64) lpn *= 2;
     // k >= 128: 8 floats per lane (two float4 chunks) -- fewer reduction/shuffle instructions per
@@ -898,6 +897,11 @@ int plsa_set_factors(plsa_ctx *c, const float *U, const float *V, int64_t n, int
     c->lpn = lpn;
     c->ch = (kp / 4 + lpn - 1) / lpn;
     if (c->ch == 3) c->ch = 4;
+    if (lpn != prev_lpn) {        // item lengths / the row-item decision depend on the lane shape
+        c->ritems_valid = false;
+        if (!c->seg_override) c->csc_valid = false;
+        c->struct_lpn = lpn;
+    }
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->U[i], sizeof(float) * (size_t)n * kp));
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->Vt[i], sizeof(float) * (size_t)m * kp));
     CHK(ensure(c, c->Vacc, sizeof(float) * (size_t)m * kp));
@@ -927,14 +931,18 @@ int plsa_init_factors_device(plsa_ctx *c, int32_t k, uint64_t seed) {
     const i64 n = c->n, m = c->m;
     const int kp = (k + 3) / 4 * 4;
     c->k = k; c->kp = kp; c->fac_n = n; c->fac_m = m;
-    c->ritems_valid = false;
-    if (!c->seg_override) c->csc_valid = false;
+    const int prev_lpn = c->struct_lpn;
     int lpn = 1;
     while (lpn < kp / 4 && lpn < 64) lpn *= 2;
     if (lpn >= 32 && lpn * 4 >= kp && c->chunks_per_lane == 2) lpn /= 2;
     c->lpn = lpn;
     c->ch = (kp / 4 + lpn - 1) / lpn;
     if (c->ch == 3) c->ch = 4;
+    if (lpn != prev_lpn) {        // item lengths / the row-item decision depend on the lane shape
+        c->ritems_valid = false;
+        if (!c->seg_override) c->csc_valid = false;
+        c->struct_lpn = lpn;
+    }
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->U[i], sizeof(float) * (size_t)n * kp));
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->Vt[i], sizeof(float) * (size_t)m * kp));
     CHK(ensure(c, c->Vacc, sizeof(float) * (size_t)m * kp));
