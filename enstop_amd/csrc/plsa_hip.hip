@@ -960,6 +960,57 @@ int plsa_init_factors_device(plsa_ctx *c, int32_t k, uint64_t seed) {
     return 0;
 }
 
+// plsa_init(X, k, init="random", rng) + the float32 casts of plsa_fit (plsa.py:455-456, 510-511,
+// 709-710) with the reference's own MT19937 stream, evaluated on the device.  state_io: the 624 key
+// words + position of numpy.random.RandomState.get_state(); on return it holds the advanced state.
+int plsa_init_factors_mt19937(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n <= 0) return fail(c, "plsa_init_factors_mt19937: upload a corpus first");
+    if (k <= 0 || k > 1024) return fail(c, "plsa_init_factors_mt19937: k=%d outside [1,1024]", k);
+    if (state_io[624] > 624) return fail(c, "plsa_init_factors_mt19937: bad generator position");
+    const i64 n = c->n, m = c->m;
+    const int kp = (k + 3) / 4 * 4;
+    const int prev_lpn = c->struct_lpn;
+    c->k = k; c->kp = kp; c->fac_n = n; c->fac_m = m;
+    int lpn = 1;
+    while (lpn < kp / 4 && lpn < 64) lpn *= 2;
+    if (lpn >= 32 && lpn * 4 >= kp && c->chunks_per_lane == 2) lpn /= 2;
+    c->lpn = lpn;
+    c->ch = (kp / 4 + lpn - 1) / lpn;
+    if (c->ch == 3) c->ch = 4;
+    if (lpn != prev_lpn) { c->ritems_valid = false; if (!c->seg_override) c->csc_valid = false; c->struct_lpn = lpn; }
+    for (int i = 0; i < 2; ++i) CHK(ensure(c, c->U[i], sizeof(float) * (size_t)n * kp));
+    for (int i = 0; i < 2; ++i) CHK(ensure(c, c->Vt[i], sizeof(float) * (size_t)m * kp));
+    CHK(ensure(c, c->Vacc, sizeof(float) * (size_t)m * kp));
+    c->p_valid = false; c->cu = 0; c->cv = 0;
+    const i64 n_doubles = (i64)k * m + n * (i64)k;
+    DevBuf words, st;
+    int rc = ensure(c, words, sizeof(unsigned) * (size_t)(2 * n_doubles));
+    if (!rc) rc = ensure(c, st, sizeof(unsigned) * 640);
+    if (rc) { release(words); release(st); return rc; }
+    hipError_t e = hipMemcpyAsync(st.p, state_io, sizeof(unsigned) * 625, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        { Scope s(c, "k_mt19937_fill");
+          hipLaunchKernelGGL(plsa::k_mt19937_fill, dim3(1), dim3(256), 0, c->stream, st.as<unsigned>(), words.as<unsigned>(), 2 * n_doubles); }
+        {
+            // V[k, m] in the reference layout (words are consumed in that order), then the layout transpose
+            float *Vtmp = reinterpret_cast<float *>(c->Vt[1].p);     // [m*kp] floats >= k*m: free scratch here
+            hipLaunchKernelGGL(plsa::k_mt_init_v, dim3((unsigned)k), dim3(64), 0, c->stream,
+                               words.as<unsigned>(), k, (int)m, Vtmp);
+            dim3 grid((unsigned)((m + 31) / 32), (unsigned)((kp + 31) / 32));
+            hipLaunchKernelGGL(plsa::k_v_to_vt, grid, dim3(256), 0, c->stream, Vtmp, c->Vt[0].as<float>(), k, (int)m, kp);
+        }
+        hipLaunchKernelGGL(plsa::k_mt_init_u, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           words.as<unsigned>(), (i64)k * m, n, k, kp, c->U[0].as<float>());
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(state_io, st.p, sizeof(unsigned) * 625, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    release(words); release(st);
+    if (e != hipSuccess) return fail(c, "plsa_init_factors_mt19937: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int plsa_get_factors(plsa_ctx *c, float *U, float *V) {
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));

@@ -878,6 +878,119 @@ __global__ void k_item_fill(const int *__restrict__ colptr, const int *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// plsa_init(random) on the device with the REFERENCE'S random stream.  NumPy's legacy
+// RandomState.rand() is MT19937: every double consumes two tempered 32-bit outputs,
+// (a >> 5) * 2^26 + (b >> 6)) / 2^53.  k_mt19937_fill continues a given generator state (624 words
+// + position) with one workgroup -- the recurrence is sequential across 624-word blocks but each
+// block update is three data-parallel sweeps -- and leaves the advanced state behind so that the host
+// generator can be set to exactly where the reference would be.  k_mt_init_v / k_mt_init_u turn the
+// stream into the factors the way plsa.py:455-456, 510-511, 709-710 do: rand(k, m) first, then
+// rand(n, k); float64 row sums accumulated left to right (enstop/utils.py:22-29), division, cast to
+// float32 -- bit-identical to the host path.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mt_temper(unsigned y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+__device__ __forceinline__ unsigned mt_mix(unsigned hi, unsigned lo, unsigned far) {
+    const unsigned y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__global__ __launch_bounds__(256) void k_mt19937_fill(unsigned *__restrict__ state /*[625]*/,
+                                                      unsigned *__restrict__ out, i64 n_words) {
+    // two copies of the state: each sweep reads the old copy (and already finished parts of the new
+    // one) and writes the new copy, so one barrier per sweep suffices
+    __shared__ unsigned buf[2][624];
+    const int t = threadIdx.x;
+    for (int i = t; i < 624; i += 256) buf[0][i] = state[i];
+    int pos = (int)state[624];
+    int cur = 0;
+    __syncthreads();
+    i64 written = 0;
+    {   // the rest of the current block
+        const i64 take = min((i64)(624 - pos), n_words);
+        for (i64 i = t; i < take; i += 256) out[i] = mt_temper(buf[0][pos + i]);
+        written = take;
+        pos += (int)take;
+    }
+    while (written < n_words) {
+        const unsigned *o = buf[cur];
+        unsigned *nw = buf[cur ^ 1];
+        if (t < 227) nw[t] = mt_mix(o[t], o[t + 1], o[t + 397]);              // i in [0, 227): old words only
+        __syncthreads();
+        if (t < 227) nw[t + 227] = mt_mix(o[t + 227], o[t + 228], nw[t]);     // [227, 454): new [0, 227)
+        __syncthreads();
+        if (t < 169) nw[t + 454] = mt_mix(o[t + 454], o[t + 455], nw[t + 227]);   // [454, 623): new [227, 396)
+        else if (t == 169) nw[623] = mt_mix(o[623], nw[0], nw[396]);
+        __syncthreads();
+        cur ^= 1;
+        const i64 take = min((i64)624, n_words - written);
+        for (i64 i = t; i < take; i += 256) out[written + i] = mt_temper(nw[i]);
+        written += take;
+        pos = (int)take;
+        // the next sweep 1 writes buf[cur ^ 1] (the copy read two sweeps ago) -- safe without a
+        // further barrier: every thread passed the third barrier after its last read of that copy
+    }
+    __syncthreads();
+    for (int i = t; i < 624; i += 256) state[i] = buf[cur][i];
+    if (t == 0) state[624] = (unsigned)pos;
+}
+
+__device__ __forceinline__ double mt_double(const unsigned *w, i64 idx) {
+    const unsigned a = w[2 * idx] >> 5, b = w[2 * idx + 1] >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+
+// left-to-right float64 sum of the 64 lanes' values (lanes >= cnt excluded), same rounding sequence
+// as the reference's sequential marginal (enstop/utils.py:24-29); every lane gets the result
+__device__ __forceinline__ double seq_sum64(double acc, double v, int cnt) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) {
+        if (l < cnt) acc += __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
+    }
+    return acc;
+}
+
+// one wave per topic z: doubles [z*m, (z+1)*m) of the stream, coalesced loads, sequential float64
+// marginal, division, float32 cast; writes V[z, :] (reference layout) for the transpose kernel
+__global__ __launch_bounds__(64) void k_mt_init_v(const unsigned *__restrict__ words, int k, int m,
+                                                  float *__restrict__ V) {
+    const int z = blockIdx.x, lane = threadIdx.x;
+    if (z >= k) return;
+    const i64 base = (i64)z * m;
+    double marginal = 0.0;
+    for (int w0 = 0; w0 < m; w0 += 64) {
+        const int cnt = min(64, m - w0);
+        const double v = lane < cnt ? mt_double(words, base + w0 + lane) : 0.0;
+        marginal = seq_sum64(marginal, v, cnt);
+    }
+    for (int w = lane; w < m; w += 64) {
+        double v = mt_double(words, base + w);
+        if (marginal > 0.0) v /= marginal;
+        V[base + w] = (float)v;
+    }
+}
+
+// document d: doubles [off + d*k, off + (d+1)*k); writes U[d, :] (pad columns zeroed)
+__global__ void k_mt_init_u(const unsigned *__restrict__ words, i64 off, i64 n, int k, int kp, float *__restrict__ U) {
+    const i64 d = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n) return;
+    const i64 base = off + d * k;
+    double marginal = 0.0;
+    for (int z = 0; z < k; ++z) marginal += mt_double(words, base + z);
+    for (int z = 0; z < kp; ++z) {
+        double v = z < k ? mt_double(words, base + z) : 0.0;
+        if (z < k && marginal > 0.0) v /= marginal;
+        U[d * kp + z] = (float)v;
+    }
+}
+
 // streaming-bandwidth probes (measurement only): fill with plain / non-temporal stores, copy
 template <bool NT>
 __global__ __launch_bounds__(256) void k_probe_fill(float *__restrict__ p, i64 n4) {

@@ -138,6 +138,21 @@ class Engine:
         self.k = int(k)
         return self
 
+    def init_factors_numpy_stream(self, k, rng):
+        """plsa_init(random) + float32 casts on the device, drawing from `rng` (a legacy
+        numpy.random.RandomState, MT19937) exactly as rng.rand(k, m); rng.rand(n, k) would; `rng`
+        is left in the state the host path would leave it in."""
+        kind, key, pos, has_gauss, cached = rng.get_state()
+        if kind != "MT19937":
+            raise ValueError("not an MT19937 RandomState")
+        state = np.empty(625, np.uint32)
+        state[:624] = key
+        state[624] = pos
+        self._ok(self._L.plsa_init_factors_mt19937(self._h, int(k), state))
+        rng.set_state((kind, state[:624].copy(), int(state[624]), has_gauss, cached))
+        self.k = int(k)
+        return self
+
     def get_factors(self, want_u=True, want_v=True):
         n, m, _ = self.shape
         U = np.empty((n, self.k), np.float32) if want_u else None

@@ -16,6 +16,8 @@ anywhere, calling anything needs libplsa_hip.so and a gfx950 device.
   plsa_refit_inner / plsa_refit :820 / :923 plsa_refit_inner / plsa_refit -> plsa_refit (C ABI)
   PLSA                         :1000        PLSA
 """
+import os
+
 import numpy as np
 from scipy.sparse import coo_matrix, csr_matrix, issparse
 from sklearn.base import BaseEstimator, TransformerMixin
@@ -176,6 +178,18 @@ def _fit_on_engine(eng, k, sample_weight, init, n_iter, n_iter_per_test, toleran
         # additive, non-reference option: counter-based RNG on the GPU (host MT19937 draws cost
         # ~1 s for 1M x 64 + 64 x 100k, four times the 50-iteration fit itself)
         eng.init_factors_device(k, int(rng.randint(0, 2 ** 31 - 1)))
+        sw = None
+        if sample_weight is not None and np.any(np.asarray(sample_weight) != 1.0):
+            sw = np.asarray(sample_weight, np.float32)
+        return eng.fit(sw, n_iter, n_iter_per_test, tolerance, e_step_thresh, flags, trace=trace)
+
+    device_init = os.environ.get("ENSTOP_AMD_HOST_INIT", "auto")   # "1": host, "0": device, auto: by size
+    use_device_init = device_init == "0" or (device_init == "auto" and k * (n + m) >= 8_000_000)
+    if isinstance(init, str) and init == "random" and isinstance(rng, np.random.RandomState) and use_device_init:
+        # same draws, same float64 normalisation, same float32 casts as plsa_init + plsa.py:709-710,
+        # evaluated on the device from rng's own MT19937 state (bit-identical, rng is advanced; 2x
+        # faster than the host draws at config 3, no gain below a few million draws)
+        eng.init_factors_numpy_stream(k, rng)
         sw = None
         if sample_weight is not None and np.any(np.asarray(sample_weight) != 1.0):
             sw = np.asarray(sample_weight, np.float32)

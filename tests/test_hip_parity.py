@@ -612,3 +612,33 @@ def test_sharded_fit_over_rccl_single_rank(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", REPO_ROOT=ROOT, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "sharded-rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("n_m_k", [(40, 50, 6), (333, 1000, 20), (5000, 3000, 64), (17, 9, 33)])
+def test_device_mt19937_init_is_bit_identical_to_numpy(amd, n_m_k):
+    """plsa_init(random) evaluated on the GPU from the RandomState's own MT19937 state: identical
+    factors, and the generator is left exactly where the host path leaves it."""
+    n, m, k = n_m_k
+    X = _corpus(n, m, 0.05, seed=n + k)
+    for prime in (0, 3, 700):                       # start at different positions inside a 624-word block
+        rng_h, rng_d = np.random.RandomState(k + prime), np.random.RandomState(k + prime)
+        rng_h.randint(0, 10, size=prime); rng_d.randint(0, 10, size=prime)
+        Uh, Vh = amd.plsa_init(X, k, rng=rng_h)
+        with amd.Engine() as eng:
+            eng.upload_csr(X)
+            eng.init_factors_numpy_stream(k, rng_d)
+            Ud, Vd = eng.get_factors()
+        np.testing.assert_array_equal(Ud, Uh.astype(np.float32))
+        np.testing.assert_array_equal(Vd, Vh.astype(np.float32))
+        np.testing.assert_array_equal(rng_h.rand(5), rng_d.rand(5))      # same continuation
+
+
+def test_host_and_device_init_paths_give_identical_fits(amd, monkeypatch):
+    X = _corpus(800, 600, 0.05, seed=77)
+    ones = np.ones(800, np.float32)
+    kw = dict(n_iter=6, n_iter_per_test=2, tolerance=0.0, random_state=5)
+    monkeypatch.setenv("ENSTOP_AMD_HOST_INIT", "0")
+    U1, V1 = amd.plsa_fit(X, 20, ones, **kw)
+    monkeypatch.setenv("ENSTOP_AMD_HOST_INIT", "1")
+    U2, V2 = amd.plsa_fit(X, 20, ones, **kw)
+    np.testing.assert_array_equal(U1, U2); np.testing.assert_array_equal(V1, V2)

@@ -21,7 +21,7 @@ def main():
     eng = Engine(0)
     for name, (n, m, nnz_t, k, n_iter, members) in CONFIGS.items():
         nnz = eng.generate_synthetic(n, m, nnz_t, seed=0)
-        for init_mode in ("host_mt19937", "device_random"):
+        for init_mode in ("host_mt19937", "device_mt19937", "device_random"):
             t = dict(bootstrap=0.0, init=0.0, fit=0.0, download=0.0)
             for r in range(members):
                 rng = np.random.RandomState(100 + r)
@@ -32,6 +32,8 @@ def main():
                     class S: shape = (n, m)
                     U, V = plsa_init(S, k, rng=rng)
                     eng.set_factors(U.astype(np.float32), V.astype(np.float32))
+                elif init_mode == "device_mt19937":
+                    eng.init_factors_numpy_stream(k, rng)      # same stream as the host path, bit-identical
                 else:
                     eng.init_factors_device(k, 100 + r)
                 eng.synchronize()
