@@ -1,0 +1,56 @@
+/* Plain-C consumer of the drop-in boundary (include/plsa_hip.h): no Python, no C++ types.  Built by
+ * tests/test_hip_parity.py::test_c_abi_from_plain_c with gcc and run on the GPU box.            */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "plsa_hip.h"
+
+static unsigned long long s = 88172645463325252ull;
+static double rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0; }
+
+#define CHECK(call) do { if (call) { fprintf(stderr, "%s failed: %s\n", #call, plsa_last_error(ctx)); return 2; } } while (0)
+
+int main(void) {
+    const int64_t n = 300, m = 200;
+    const int32_t k = 12;
+    int32_t *indptr = malloc(sizeof(int32_t) * (n + 1));
+    int32_t *indices = malloc(sizeof(int32_t) * n * 40);
+    float *data = malloc(sizeof(float) * n * 40);
+    int64_t nnz = 0;
+    indptr[0] = 0;
+    for (int64_t d = 0; d < n; d++) {
+        int len = 5 + (int)(rnd() * 30), w = 0;
+        for (int j = 0; j < len && w < m; j++) {
+            w += 1 + (int)(rnd() * 5);
+            if (w >= m) break;
+            indices[nnz] = w; data[nnz] = (float)(1 + (int)(rnd() * 4)); nnz++;
+        }
+        indptr[d + 1] = (int32_t)nnz;
+    }
+    float *U = malloc(sizeof(float) * n * k), *V = malloc(sizeof(float) * k * m);
+    for (int64_t d = 0; d < n; d++) { double t = 0; for (int z = 0; z < k; z++) { U[d * k + z] = (float)rnd(); t += U[d * k + z]; }
+                                      for (int z = 0; z < k; z++) U[d * k + z] /= (float)t; }
+    for (int z = 0; z < k; z++) { double t = 0; for (int64_t w = 0; w < m; w++) { V[z * m + w] = (float)rnd(); t += V[z * m + w]; }
+                                  for (int64_t w = 0; w < m; w++) V[z * m + w] /= (float)t; }
+    plsa_ctx *ctx = NULL;
+    if (plsa_create(0, &ctx)) { fprintf(stderr, "plsa_create: %s\n", plsa_last_error(NULL)); return 1; }
+    CHECK(plsa_upload_csr(ctx, indptr, indices, data, n, m, nnz));
+    CHECK(plsa_set_factors(ctx, U, V, n, m, k));
+    double ll0 = 0, ll1 = 0;
+    CHECK(plsa_log_likelihood(ctx, NULL, &ll0));
+    int32_t iters = 0, n_ll = 0;
+    float trace[64];
+    CHECK(plsa_fit(ctx, NULL, 20, 5, 0.0, 1e-32f, PLSA_FUSED | PLSA_TRACE_LL, &iters, trace, &n_ll));
+    CHECK(plsa_log_likelihood(ctx, NULL, &ll1));
+    CHECK(plsa_get_factors(ctx, U, V));
+    double worst = 0;
+    for (int64_t d = 0; d < n; d++) { double t = 0; for (int z = 0; z < k; z++) t += U[d * k + z]; if (indptr[d + 1] > indptr[d] && fabs(t - 1) > worst) worst = fabs(t - 1); }
+    for (int z = 0; z < k; z++) { double t = 0; for (int64_t w = 0; w < m; w++) t += V[z * m + w]; if (fabs(t - 1) > worst) worst = fabs(t - 1); }
+    plsa_destroy(ctx);
+    if (iters != 20 || n_ll != 5 || !(ll1 > ll0) || worst > 1e-4 || fabs(trace[0] - (float)ll0) > 1e-3 * fabs(ll0)) {
+        fprintf(stderr, "unexpected: iters=%d n_ll=%d ll0=%g ll1=%g worst=%g\n", iters, n_ll, ll0, ll1, worst);
+        return 3;
+    }
+    printf("c-abi ok: %d iterations, LL %.4f -> %.4f, row-sum error %.2e\n", iters, ll0, ll1, worst);
+    return 0;
+}

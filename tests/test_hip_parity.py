@@ -642,3 +642,15 @@ def test_host_and_device_init_paths_give_identical_fits(amd, monkeypatch):
     monkeypatch.setenv("ENSTOP_AMD_HOST_INIT", "1")
     U2, V2 = amd.plsa_fit(X, 20, ones, **kw)
     np.testing.assert_array_equal(U1, U2); np.testing.assert_array_equal(V1, V2)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary is a real C ABI: a gcc-built C program drives a fit through include/plsa_hip.h."""
+    import os, subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", os.path.join(ROOT, "tests", "c_abi_smoke.c"),
+                           "-I", os.path.join(ROOT, "include"), "-L", os.path.join(ROOT, "enstop_amd"),
+                           "-l:libplsa_hip.so", "-Wl,-rpath," + os.path.join(ROOT, "enstop_amd"), "-lm", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "c-abi ok" in out.stdout, out.stdout + out.stderr
