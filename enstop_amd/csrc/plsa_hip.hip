@@ -991,7 +991,7 @@ int plsa_init_factors_mt19937(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]
     hipError_t e = hipMemcpyAsync(st.p, state_io, sizeof(unsigned) * 625, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         { Scope s(c, "k_mt19937_fill");
-          hipLaunchKernelGGL(plsa::k_mt19937_fill, dim3(1), dim3(256), 0, c->stream, st.as<unsigned>(), words.as<unsigned>(), 2 * n_doubles); }
+          hipLaunchKernelGGL(plsa::k_mt19937_fill, dim3(1), dim3(PLSA_MT_THREADS), 0, c->stream, st.as<unsigned>(), words.as<unsigned>(), 2 * n_doubles); }
         {
             // V[k, m] in the reference layout (words are consumed in that order), then the layout transpose
             float *Vtmp = reinterpret_cast<float *>(c->Vt[1].p);     // [m*kp] floats >= k*m: free scratch here

@@ -901,43 +901,50 @@ __device__ __forceinline__ unsigned mt_mix(unsigned hi, unsigned lo, unsigned fa
     return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
-__global__ __launch_bounds__(256) void k_mt19937_fill(unsigned *__restrict__ state /*[625]*/,
-                                                      unsigned *__restrict__ out, i64 n_words) {
+#ifndef PLSA_MT_THREADS
+#define PLSA_MT_THREADS 256  // measured: 256 threads 142 ms, 128 threads 187 ms for 140 M words (config 3)
+#endif
+__global__ __launch_bounds__(PLSA_MT_THREADS) void k_mt19937_fill(unsigned *__restrict__ state /*[625]*/,
+                                                                 unsigned *__restrict__ out, i64 n_words) {
     // two copies of the state: each sweep reads the old copy (and already finished parts of the new
-    // one) and writes the new copy, so one barrier per sweep suffices
+    // one) and writes the new copy, so one synchronisation per sweep suffices
+    constexpr int T = PLSA_MT_THREADS;
     __shared__ unsigned buf[2][624];
     const int t = threadIdx.x;
-    for (int i = t; i < 624; i += 256) buf[0][i] = state[i];
+    for (int i = t; i < 624; i += T) buf[0][i] = state[i];
     int pos = (int)state[624];
     int cur = 0;
     __syncthreads();
     i64 written = 0;
     {   // the rest of the current block
         const i64 take = min((i64)(624 - pos), n_words);
-        for (i64 i = t; i < take; i += 256) out[i] = mt_temper(buf[0][pos + i]);
+        for (i64 i = t; i < take; i += T) out[i] = mt_temper(buf[0][pos + i]);
         written = take;
         pos += (int)take;
     }
     while (written < n_words) {
         const unsigned *o = buf[cur];
         unsigned *nw = buf[cur ^ 1];
-        if (t < 227) nw[t] = mt_mix(o[t], o[t + 1], o[t + 397]);              // i in [0, 227): old words only
+#pragma unroll
+        for (int i = t; i < 227; i += T) nw[i] = mt_mix(o[i], o[i + 1], o[i + 397]);            // old words only
         __syncthreads();
-        if (t < 227) nw[t + 227] = mt_mix(o[t + 227], o[t + 228], nw[t]);     // [227, 454): new [0, 227)
+#pragma unroll
+        for (int i = t; i < 227; i += T) nw[i + 227] = mt_mix(o[i + 227], o[i + 228], nw[i]);   // new [0, 227)
         __syncthreads();
-        if (t < 169) nw[t + 454] = mt_mix(o[t + 454], o[t + 455], nw[t + 227]);   // [454, 623): new [227, 396)
-        else if (t == 169) nw[623] = mt_mix(o[623], nw[0], nw[396]);
+#pragma unroll
+        for (int i = t; i < 169; i += T) nw[i + 454] = mt_mix(o[i + 454], o[i + 455], nw[i + 227]);   // new [227, 396)
+        if (t == T - 1) nw[623] = mt_mix(o[623], nw[0], nw[396]);
         __syncthreads();
         cur ^= 1;
         const i64 take = min((i64)624, n_words - written);
-        for (i64 i = t; i < take; i += 256) out[written + i] = mt_temper(nw[i]);
+        for (i64 i = t; i < take; i += T) out[written + i] = mt_temper(nw[i]);
         written += take;
         pos = (int)take;
-        // the next sweep 1 writes buf[cur ^ 1] (the copy read two sweeps ago) -- safe without a
-        // further barrier: every thread passed the third barrier after its last read of that copy
+        // the next sweep 1 writes buf[cur ^ 1] (the copy read two sweeps ago): every thread passed the
+        // third synchronisation after its last read of that copy
     }
     __syncthreads();
-    for (int i = t; i < 624; i += 256) state[i] = buf[cur][i];
+    for (int i = t; i < 624; i += T) state[i] = buf[cur][i];
     if (t == 0) state[624] = (unsigned)pos;
 }
 
