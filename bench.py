@@ -107,6 +107,36 @@ def cpu_baseline(eng, cfg, k, budget_cells=1.2e9, iters=3):
     }
 
 
+def quick_config(eng, cfg_id, steps, warmup, seed):
+    """Compact measurement of another BASELINE.json config on the same device (N = 1 only): fused EM
+    iterations/s and the materialising E-step's roofline fraction, same method as the main legs."""
+    from enstop_amd.engine import PLSA_FUSED
+    cfg = CONFIGS[cfg_id]
+    n, m, k = cfg["n"], cfg["m"], cfg["k"]
+    nnz = eng.generate_synthetic(n, m, cfg["nnz"], zipf_s=1.07, seed=seed)
+    U0, V0 = init_factors(n, m, k, 42)
+    eng.release_scratch()
+    eng.set_factors(U0, V0)
+    eng.fit(None, n_iter=warmup, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=PLSA_FUSED)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    it, _ = eng.fit(None, n_iter=steps, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=PLSA_FUSED)
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    eng.timing(True)
+    eng.e_step(1e-32, want_host_copy=False)
+    eng.timing_reset()
+    for _ in range(5):
+        eng.e_step(1e-32, want_host_copy=False)
+    ms, cnt = eng.timing_get("k_e_step")
+    eng.timing(False)
+    b = algorithmic_bytes("e_step", n, m, nnz, k)
+    return {"workload": cfg["name"], "nnz": nnz, "k": k, "steps": it, "value": round(it / dt, 2), "unit": "iter/s",
+            "ms_per_step": round(dt / it * 1e3, 4),
+            "e_step": {"avg_launch_ms": round(ms / cnt, 5), "achieved_GBps": round(b / 1e9 / (ms / cnt / 1e3), 1),
+                       "frac": round(b / 1e9 / (ms / cnt / 1e3) / HBM_PEAK_GBS, 4)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -320,6 +350,12 @@ def main():
             except Exception as e:       # the baseline must never cost the GPU measurement
                 out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+    if rank == 0 and n_gpus == 1 and dist is None and args.config == 3 and not args.no_cpu_baseline:
+        # BASELINE.json configs[1] (100k x 50k, 10M nnz, k=32) on the same device, compact form
+        try:
+            out["other_configs"] = {"config2": quick_config(eng, 2, args.steps, args.warmup, args.seed)}
+        except Exception as e:
+            out["other_configs"] = {"config2": "failed: %r" % (e,)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
