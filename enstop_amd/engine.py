@@ -6,6 +6,7 @@ The reference keeps all of this state in NumPy arrays handed from function to fu
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -42,6 +43,9 @@ class Engine:
         self.device = dev
         self.k = 0
         self.base_rows = 0
+        # a context is not thread-safe: callers that share the process-wide engine (the reference is
+        # driven from dask/joblib thread pools, enstop_.py:209-217) serialise on this lock
+        self.lock = threading.RLock()
 
     # -- lifetime --------------------------------------------------------------------------------
     def close(self):

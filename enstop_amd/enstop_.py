@@ -13,7 +13,7 @@ from scipy.sparse import issparse, csr_matrix
 from sklearn.utils import check_random_state
 
 from .engine import get_engine
-from .plsa import _fit_on_engine
+from .plsa import _fit_on_engine, _locked
 
 
 def _member_on_engine(eng, k, bootstrap=True, random_state=None, init="random", n_iter=100,
@@ -35,6 +35,7 @@ def _member_on_engine(eng, k, bootstrap=True, random_state=None, init="random", 
     return V
 
 
+@_locked
 def plsa_topics(X, k, **kwargs):
     """Bootstrap-resample the documents of X and fit pLSA; returns the (k, n_words) topic matrix.
     Keyword arguments as the reference: bootstrap, random_state, init, n_iter, n_iter_per_test,
@@ -49,6 +50,7 @@ def plsa_topics(X, k, **kwargs):
         e_step_thresh=kwargs.get("e_step_thresh", 1e-16), flags=kwargs.get("flags", None))
 
 
+@_locked
 def ensemble_of_topics(X, k, model="plsa", n_jobs=4, n_runs=16, parallelism="dask", **kwargs):
     """All topics of `n_runs` bootstrapped fits stacked to (n_runs * k, n_words), enstop_.py:164-231.
 

@@ -48,6 +48,24 @@ def _coo_to_csr(X_rows, X_cols, X_vals, n, m):
     return csr, order
 
 
+def _locked(fn):
+    """Serialise calls that use the process-wide engine of a device (thread pools of callers)."""
+    import functools
+    import inspect
+    sig = inspect.signature(fn)
+    has_kwargs = any(p.kind is inspect.Parameter.VAR_KEYWORD for p in sig.parameters.values())
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        if has_kwargs and "device" not in sig.parameters:
+            device = kwargs.get("device", None)
+        else:
+            device = sig.bind_partial(*args, **kwargs).arguments.get("device", None)
+        with get_engine(device).lock:
+            return fn(*args, **kwargs)
+    return wrapper
+
+
 def _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device=None):
     k, m = p_w_given_z.shape
     n = p_z_given_d.shape[0]
@@ -58,6 +76,7 @@ def _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device=None):
     return eng, order
 
 
+@_locked
 def plsa_e_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd,
                 probability_threshold=1e-32, device=None):
     """P(z|w,d) for every stored (d, w); fills and returns `p_z_given_wd` [nnz, k]."""
@@ -70,6 +89,7 @@ def plsa_e_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd,
     return p_z_given_wd
 
 
+@_locked
 def _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, sample_weight,
             norm_pwz, norm_pdz, update_v, device):
     eng, order = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device)
@@ -109,6 +129,7 @@ def plsa_refit_m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_give
                    norm_pdz, False, device)
 
 
+@_locked
 def log_likelihood(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, sample_weight, device=None):
     """sum x * log(sum_z P(w|z) P(z|d)) * sample_weight[d], returned as float32 like the reference."""
     eng, _ = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device)
@@ -153,6 +174,7 @@ def plsa_init(X, k, init="random", rng=np.random):
 # ------------------------------------------------------------------------------------------------
 # EM drivers
 # ------------------------------------------------------------------------------------------------
+@_locked
 def plsa_fit_inner(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, sample_weight, n_iter=100,
                    n_iter_per_test=10, tolerance=0.001, e_step_thresh=1e-32,
                    use_sample_weights=False, device=None, flags=None):
@@ -212,6 +234,7 @@ def _fit_on_engine(eng, k, sample_weight, init, n_iter, n_iter_per_test, toleran
     return iters, ll
 
 
+@_locked
 def plsa_fit(X, k, sample_weight, init="random", n_iter=100, n_iter_per_test=10, tolerance=0.001,
              e_step_thresh=1e-32, random_state=None, device=None, flags=None, return_info=False):
     """Fit pLSA with k topics to the sparse doc-term matrix X; returns (P(z|d) [n,k], P(w|z) [k,m]),
@@ -229,6 +252,7 @@ def plsa_fit(X, k, sample_weight, init="random", n_iter=100, n_iter_per_test=10,
     return p_z_given_d, p_w_given_z
 
 
+@_locked
 def plsa_refit_inner(X_rows, X_cols, X_vals, topics, p_z_given_d, sample_weight, n_iter=50,
                      n_iter_per_test=10, tolerance=0.005, e_step_thresh=1e-32, device=None, flags=None):
     """EM on P(z|d) with the topics frozen (plsa.py:820-920); returns P(z|d)."""
@@ -240,6 +264,7 @@ def plsa_refit_inner(X_rows, X_cols, X_vals, topics, p_z_given_d, sample_weight,
     return p_z_given_d
 
 
+@_locked
 def plsa_refit(X, topics, sample_weight, n_iter=50, n_iter_per_test=10, tolerance=0.005,
                e_step_thresh=1e-32, random_state=None, device=None, flags=None, return_info=False):
     """Document vectors P(z|d) for X against fixed `topics` (plsa.py:923-997)."""

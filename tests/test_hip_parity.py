@@ -654,3 +654,17 @@ def test_c_abi_from_plain_c(tmp_path):
                            "-l:libplsa_hip.so", "-Wl,-rpath," + os.path.join(ROOT, "enstop_amd"), "-lm", "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "c-abi ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_thread_pool_callers_are_serialised(amd):
+    """The reference is driven from thread pools (dask / joblib threads); concurrent calls that share
+    the process-wide engine must not corrupt each other."""
+    from concurrent.futures import ThreadPoolExecutor
+    X = _corpus(700, 500, 0.05, seed=31)
+    ones = np.ones(700, np.float32)
+    kw = dict(n_iter=8, n_iter_per_test=4, tolerance=0.0)
+    expect = {s: amd.plsa_fit(X, 16, ones, random_state=s, **kw) for s in range(4)}
+    with ThreadPoolExecutor(4) as pool:
+        got = list(pool.map(lambda s: (s, amd.plsa_fit(X, 16, ones, random_state=s, **kw)), [0, 1, 2, 3] * 3))
+    for s, (U, V) in got:
+        np.testing.assert_array_equal(U, expect[s][0]); np.testing.assert_array_equal(V, expect[s][1])
