@@ -1349,7 +1349,7 @@ int plsa_timing_report(plsa_ctx *c, char *buf, int64_t cap) {
 
 int plsa_measure_stream_bandwidth(plsa_ctx *c, int64_t bytes, int32_t kind, int32_t reps, double *gbps) {
     HIPCHK(c, hipSetDevice(c->device));
-    if (bytes < (1 << 20) || reps < 1 || kind < 0 || kind > 2) return fail(c, "plsa_measure_stream_bandwidth: bad arguments");
+    if (bytes < (1 << 20) || reps < 1 || kind < 0 || kind > 3) return fail(c, "plsa_measure_stream_bandwidth: bad arguments");
     DevBuf a, b;
     const i64 n4 = bytes / 16;
     int rc = ensure(c, a, (size_t)n4 * 16);
@@ -1362,6 +1362,7 @@ int plsa_measure_stream_bandwidth(plsa_ctx *c, int64_t bytes, int32_t kind, int3
         if (r == 0) (void)hipEventRecord(e0, c->stream);
         if (kind == 0) hipLaunchKernelGGL((plsa::k_probe_fill<true>), dim3(grid), dim3(256), 0, c->stream, a.as<float>(), n4);
         else if (kind == 1) hipLaunchKernelGGL((plsa::k_probe_fill<false>), dim3(grid), dim3(256), 0, c->stream, a.as<float>(), n4);
+        else if (kind == 3) hipLaunchKernelGGL(plsa::k_probe_read, dim3(grid), dim3(256), 0, c->stream, a.as<float>(), a.as<float>(), n4);
         else hipLaunchKernelGGL(plsa::k_probe_copy, dim3(grid), dim3(256), 0, c->stream, a.as<float>(), b.as<float>(), n4);
     }
     (void)hipEventRecord(e1, c->stream);

@@ -1006,6 +1006,15 @@ __global__ __launch_bounds__(256) void k_probe_fill(float *__restrict__ p, i64 n
         if (NT) st4_nt(p + i * 4, v); else st4(p + i * 4, v);
     }
 }
+// read-only stream: every lane accumulates its float4s, one store per thread at the end
+__global__ __launch_bounds__(256) void k_probe_read(const float *__restrict__ a, float *__restrict__ sink, i64 n4) {
+    float4 acc = zero4();
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n4; i += (i64)gridDim.x * 256) {
+        const float4 v = ld4(a + i * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == -1.2345f) sink[0] = acc.x;   // keeps the loads alive
+}
 __global__ __launch_bounds__(256) void k_probe_copy(const float *__restrict__ a, float *__restrict__ b, i64 n4) {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n4; i += (i64)gridDim.x * 256)
         st4(b + i * 4, ld4(a + i * 4));
