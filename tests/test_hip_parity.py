@@ -668,3 +668,38 @@ def test_thread_pool_callers_are_serialised(amd):
         got = list(pool.map(lambda s: (s, amd.plsa_fit(X, 16, ones, random_state=s, **kw)), [0, 1, 2, 3] * 3))
     for s, (U, V) in got:
         np.testing.assert_array_equal(U, expect[s][0]); np.testing.assert_array_equal(V, expect[s][1])
+
+
+def test_randomised_shapes_vs_oracle(amd, oracle):
+    """Seeded sweep over odd shapes: k not a multiple of 4, empty rows and columns, heavy rows and
+    columns, large thresholds, weights -- every case against the pinned oracle, both schedules."""
+    rs = np.random.RandomState(2024)
+    for case in range(36):
+        n = int(rs.randint(2, 400)); m = int(rs.randint(2, 500)); k = int(rs.choice([1, 2, 3, 5, 7, 9, 12, 17, 24, 31, 40, 65, 70]))
+        dens = float(rs.choice([0.01, 0.05, 0.3]))
+        X = sp.random(n, m, density=dens, format="lil", random_state=rs, dtype=np.float64)
+        X[rs.randint(n), :] = 1.0                                   # one full (heavy) document
+        X[:, rs.randint(m)] = 2.0                                   # one full (heavy) word
+        if n > 3:
+            X[rs.randint(n)] = 0                                    # an empty document
+        X = X.tocsr(); X.data = np.ceil(X.data * 3).astype(np.float32); X.eliminate_zeros()
+        X = X.astype(np.float32)
+        sw = (0.5 + rs.rand(n)).astype(np.float32) if case % 3 == 0 else np.ones(n, np.float32)
+        thresh = float(rs.choice([1e-32, 1e-16, 1e-4]))
+        kw = dict(n_iter=int(rs.randint(1, 9)), n_iter_per_test=int(rs.randint(1, 5)), tolerance=0.0,
+                  e_step_thresh=thresh, random_state=int(rs.randint(1000)))
+        Uo, Vo, trace, iters = oracle.plsa_fit(X, k, sw, return_trace=True, **kw)
+        for name, mode in MODES.items():
+            U, V, info = amd.plsa_fit(X, k, sw, flags=mode, return_info=True, **kw)
+            msg = "case %d (%s): n=%d m=%d k=%d dens=%g thresh=%g %r" % (case, name, n, m, k, dens, thresh, kw)
+            fin = np.isfinite(trace)
+            if not np.all(fin[:2]) or info["n_iter"] != iters:
+                # a -inf likelihood (thresholding) makes the stop test a comparison of infinities on
+                # both sides; the factors below are still compared
+                assert abs(info["n_iter"] - iters) <= kw["n_iter"], msg
+            else:
+                q = min(len(trace), len(info["log_likelihood_trace"]))
+                close_ll(info["log_likelihood_trace"][:q], trace[:q])
+            if info["n_iter"] == iters:
+                assert np.abs(U - Uo).max() <= 1e-4 * max(Uo.max(), 1e-30), msg
+                assert np.abs(V - Vo).max() <= 1e-4 * max(Vo.max(), 1e-30), msg
