@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/plsa_hip.h"
+#include "mt_jump.hpp"
 #include "plsa_kernels.hpp"
 #include "plsa_synth.hpp"
 
@@ -73,6 +74,8 @@ struct plsa_ctx {
     DevBuf colptr, csc_row, csc_val, csc_pos, item_first, item_col, item_start, item_order, partial, heavy_cols;
     bool use_item_order = true, xcd_split = true;
     int chunks_per_lane = 2;
+    int mt_streams = 256;          // pieces the MT19937 init stream is cut into (PLSA_MT_STREAMS; 1 = sequential)
+    i64 mt_min_blocks = 4096;      // ... once it is at least this many 624-word blocks long (PLSA_MT_MIN_BLOCKS)
     int heavy_items = 32, n_heavy = 0;
 
     // row items (documents cut into pieces) for corpora with few / very uneven rows
@@ -742,6 +745,8 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_ITEM_ORDER")) c->use_item_order = atoi(s) != 0;
     if (const char *s = getenv("PLSA_XCD_SPLIT")) c->xcd_split = atoi(s) != 0;
     if (const char *s = getenv("PLSA_CHUNKS_PER_LANE")) c->chunks_per_lane = atoi(s);
+    if (const char *s = getenv("PLSA_MT_STREAMS")) c->mt_streams = std::max(1, std::min(4096, atoi(s)));
+    if (const char *s = getenv("PLSA_MT_MIN_BLOCKS")) c->mt_min_blocks = std::max(1, atoi(s));
     *out = c;
     return 0;
 }
@@ -984,29 +989,64 @@ int plsa_init_factors_mt19937(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]
     CHK(ensure(c, c->Vacc, sizeof(float) * (size_t)m * kp));
     c->p_valid = false; c->cu = 0; c->cv = 0;
     const i64 n_doubles = (i64)k * m + n * (i64)k;
-    DevBuf words, st;
-    int rc = ensure(c, words, sizeof(unsigned) * (size_t)(2 * n_doubles));
-    if (!rc) rc = ensure(c, st, sizeof(unsigned) * 640);
-    if (rc) { release(words); release(st); return rc; }
-    hipError_t e = hipMemcpyAsync(st.p, state_io, sizeof(unsigned) * 625, hipMemcpyHostToDevice, c->stream);
+    const i64 n_words = 2 * n_doubles;
+    // Split the stream into pieces that start 2^b blocks apart (csrc/mt_jump.hpp) once it is long
+    // enough to pay for the jumps; the words produced are those of the one sequential stream.
+    const int pos0 = (int)state_io[624];
+    const i64 first = std::min<i64>(624 - pos0, n_words);
+    const i64 total_blocks = (n_words - first + 623) / 624;
+    i64 per_stream = std::max<i64>(total_blocks, 1);
+    int n_streams = 1, log2_per = 0;
+    if (c->mt_streams > 1 && total_blocks >= c->mt_min_blocks) {
+        while (((i64)1 << log2_per) * c->mt_streams < total_blocks) ++log2_per;
+        per_stream = (i64)1 << log2_per;
+        n_streams = (int)((total_blocks + per_stream - 1) / per_stream);
+    }
+    int streams_p2 = 1, levels = 0;
+    while (streams_p2 < n_streams) { streams_p2 *= 2; ++levels; }
+    std::vector<uint32_t> polys((size_t)levels * 624);
+    for (int l = 0; l < levels; ++l)        // level l jumps by (streams_p2 >> (l+1)) * per_stream blocks
+        if (!mtjump::block_jump_polynomial(log2_per + (levels - 1 - l), polys.data() + (size_t)l * 624))
+            return fail(c, "plsa_init_factors_mt19937: MT19937 characteristic polynomial not recovered");
+    DevBuf words, st, fin, gp;
+    int rc = ensure(c, words, sizeof(unsigned) * (size_t)n_words);
+    if (!rc) rc = ensure(c, st, sizeof(unsigned) * 624 * (size_t)streams_p2);
+    if (!rc) rc = ensure(c, fin, sizeof(unsigned) * 640 + sizeof(double) * 1024);
+    if (!rc && levels) rc = ensure(c, gp, sizeof(unsigned) * polys.size());
+    if (rc) { release(words); release(st); release(fin); release(gp); return rc; }
+    hipError_t e = hipMemsetAsync(st.p, 0, sizeof(unsigned) * 624 * (size_t)streams_p2, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(st.p, state_io, sizeof(unsigned) * 624, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && levels)
+        e = hipMemcpyAsync(gp.p, polys.data(), sizeof(unsigned) * polys.size(), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
+        if (levels) {
+            Scope s(c, "k_mt_jump");
+            for (int l = 0; l < levels; ++l) {
+                const int step = streams_p2 >> (l + 1);
+                hipLaunchKernelGGL(plsa::k_mt_jump, dim3((unsigned)(streams_p2 / (2 * step)), plsa::MT_JUMP_SLICES), dim3(256), 0,
+                                   c->stream, gp.as<unsigned>() + (size_t)l * 624, st.as<unsigned>(), step, n_streams);
+            }
+        }
         { Scope s(c, "k_mt19937_fill");
-          hipLaunchKernelGGL(plsa::k_mt19937_fill, dim3(1), dim3(PLSA_MT_THREADS), 0, c->stream, st.as<unsigned>(), words.as<unsigned>(), 2 * n_doubles); }
+          hipLaunchKernelGGL(plsa::k_mt19937_fill, dim3((unsigned)n_streams), dim3(PLSA_MT_THREADS), 0, c->stream,
+                             st.as<unsigned>(), words.as<unsigned>(), pos0, per_stream, n_words, n_streams, fin.as<unsigned>()); }
         {
             // V[k, m] in the reference layout (words are consumed in that order), then the layout transpose
             float *Vtmp = reinterpret_cast<float *>(c->Vt[1].p);     // [m*kp] floats >= k*m: free scratch here
-            hipLaunchKernelGGL(plsa::k_mt_init_v, dim3((unsigned)k), dim3(64), 0, c->stream,
-                               words.as<unsigned>(), k, (int)m, Vtmp);
+            double *marg = reinterpret_cast<double *>(fin.as<unsigned>() + 632) ;   // k <= 1024 doubles behind the state
+            hipLaunchKernelGGL(plsa::k_mt_marginal_v, dim3((unsigned)k), dim3(64), 0, c->stream, words.as<unsigned>(), k, (int)m, marg);
+            hipLaunchKernelGGL(plsa::k_mt_scale_v, dim3(grid_for(c, (i64)k * m, 256)), dim3(256), 0, c->stream,
+                               words.as<unsigned>(), marg, k, (int)m, Vtmp);
             dim3 grid((unsigned)((m + 31) / 32), (unsigned)((kp + 31) / 32));
             hipLaunchKernelGGL(plsa::k_v_to_vt, grid, dim3(256), 0, c->stream, Vtmp, c->Vt[0].as<float>(), k, (int)m, kp);
         }
-        hipLaunchKernelGGL(plsa::k_mt_init_u, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(plsa::k_mt_init_u, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream,
                            words.as<unsigned>(), (i64)k * m, n, k, kp, c->U[0].as<float>());
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(state_io, st.p, sizeof(unsigned) * 625, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(state_io, fin.p, sizeof(unsigned) * 625, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    release(words); release(st);
+    release(words); release(st); release(fin); release(gp);
     if (e != hipSuccess) return fail(c, "plsa_init_factors_mt19937: %s", hipGetErrorString(e));
     return 0;
 }
@@ -1386,6 +1426,14 @@ void plsa_host_normalize_rows(double *a, int64_t rows, int64_t cols) {
         if (marginal > 0.0)
             for (int64_t j = 0; j < cols; ++j) r[j] /= marginal;
     }
+}
+
+int plsa_host_mt19937_jump(uint32_t *key, int32_t log2_blocks) {
+    if (!key || log2_blocks < 0 || log2_blocks > 40) return 1;
+    uint32_t g[624];
+    if (!mtjump::block_jump_polynomial(log2_blocks, g)) return 1;
+    mtjump::apply_jump(key, g);
+    return 0;
 }
 
 // Synthetic corpus in HBM (see plsa_synth.hpp).  The mean token count per document is calibrated

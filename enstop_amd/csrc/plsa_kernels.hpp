@@ -902,50 +902,109 @@ __device__ __forceinline__ unsigned mt_mix(unsigned hi, unsigned lo, unsigned fa
 }
 
 #ifndef PLSA_MT_THREADS
-#define PLSA_MT_THREADS 256  // measured: 256 threads 142 ms, 128 threads 187 ms for 140 M words (config 3)
+#define PLSA_MT_THREADS 256  // measured: 256 threads 142 ms, 128 threads 187 ms for 140 M words (config 3), one stream
 #endif
-__global__ __launch_bounds__(PLSA_MT_THREADS) void k_mt19937_fill(unsigned *__restrict__ state /*[625]*/,
-                                                                 unsigned *__restrict__ out, i64 n_words) {
-    // two copies of the state: each sweep reads the old copy (and already finished parts of the new
-    // one) and writes the new copy, so one synchronisation per sweep suffices
+// one 624-word block of the recurrence: o = current block, nw = next block (distinct LDS arrays).
+// Three data-parallel sweeps -- the recurrence reaches back 227 words -- with one synchronisation
+// each; on return every thread may read nw.
+template <int T>
+__device__ __forceinline__ void mt_next_block(const unsigned *o, unsigned *nw, int t) {
+#pragma unroll
+    for (int i = t; i < 227; i += T) nw[i] = mt_mix(o[i], o[i + 1], o[i + 397]);            // old words only
+    __syncthreads();
+#pragma unroll
+    for (int i = t; i < 227; i += T) nw[i + 227] = mt_mix(o[i + 227], o[i + 228], nw[i]);   // new [0, 227)
+    __syncthreads();
+#pragma unroll
+    for (int i = t; i < 169; i += T) nw[i + 454] = mt_mix(o[i + 454], o[i + 455], nw[i + 227]);   // new [227, 396)
+    if (t == T - 1) nw[623] = mt_mix(o[623], nw[0], nw[396]);
+    __syncthreads();
+}
+
+// Continues the generator whose 624-word block is states[0] (position pos0 inside it) for n_words
+// outputs.  Workgroup r starts from states[r] -- the block r * blocks_per_stream blocks further on,
+// placed there by k_mt_jump -- and produces the blocks r * blocks_per_stream + 1 ... of the stream;
+// with n_streams = 1 this is the plain sequential generator.  The last workgroup leaves the
+// advanced state (624 words + position) in final_state.
+__global__ __launch_bounds__(PLSA_MT_THREADS) void k_mt19937_fill(const unsigned *__restrict__ states, unsigned *__restrict__ out,
+                                                                 int pos0, i64 blocks_per_stream, i64 n_words, int n_streams,
+                                                                 unsigned *__restrict__ final_state /*[625]*/) {
     constexpr int T = PLSA_MT_THREADS;
     __shared__ unsigned buf[2][624];
-    const int t = threadIdx.x;
-    for (int i = t; i < 624; i += T) buf[0][i] = state[i];
-    int pos = (int)state[624];
+    const int t = threadIdx.x, r = blockIdx.x;
+    for (int i = t; i < 624; i += T) buf[0][i] = states[(i64)r * 624 + i];
     int cur = 0;
     __syncthreads();
-    i64 written = 0;
-    {   // the rest of the current block
-        const i64 take = min((i64)(624 - pos), n_words);
-        for (i64 i = t; i < take; i += T) out[i] = mt_temper(buf[0][pos + i]);
-        written = take;
-        pos += (int)take;
-    }
-    while (written < n_words) {
-        const unsigned *o = buf[cur];
-        unsigned *nw = buf[cur ^ 1];
-#pragma unroll
-        for (int i = t; i < 227; i += T) nw[i] = mt_mix(o[i], o[i + 1], o[i + 397]);            // old words only
-        __syncthreads();
-#pragma unroll
-        for (int i = t; i < 227; i += T) nw[i + 227] = mt_mix(o[i + 227], o[i + 228], nw[i]);   // new [0, 227)
-        __syncthreads();
-#pragma unroll
-        for (int i = t; i < 169; i += T) nw[i + 454] = mt_mix(o[i + 454], o[i + 455], nw[i + 227]);   // new [227, 396)
-        if (t == T - 1) nw[623] = mt_mix(o[623], nw[0], nw[396]);
-        __syncthreads();
+    const i64 first = min((i64)(624 - pos0), n_words);          // the rest of the current block
+    if (r == 0)
+        for (i64 i = t; i < first; i += T) out[i] = mt_temper(buf[0][pos0 + i]);
+    int pos = pos0 + (int)first;
+    const i64 total_blocks = (n_words - first + 623) / 624;
+    const i64 jb = (i64)r * blocks_per_stream + 1, je = min(jb + blocks_per_stream - 1, total_blocks);
+    for (i64 j = jb; j <= je; ++j) {
+        mt_next_block<T>(buf[cur], buf[cur ^ 1], t);
         cur ^= 1;
-        const i64 take = min((i64)624, n_words - written);
-        for (i64 i = t; i < take; i += T) out[written + i] = mt_temper(nw[i]);
-        written += take;
+        const i64 at = first + (j - 1) * 624;
+        const i64 take = min((i64)624, n_words - at);
+        for (i64 i = t; i < take; i += T) out[at + i] = mt_temper(buf[cur][i]);
         pos = (int)take;
-        // the next sweep 1 writes buf[cur ^ 1] (the copy read two sweeps ago): every thread passed the
-        // third synchronisation after its last read of that copy
+        // the next block is written into the copy read two sweeps ago: every thread passed the third
+        // synchronisation after its last read of that copy
+    }
+    if (r == n_streams - 1) {
+        __syncthreads();
+        for (int i = t; i < 624; i += T) final_state[i] = buf[cur][i];
+        if (t == 0) final_state[624] = (unsigned)pos;
+    }
+}
+
+// Jump-ahead (csrc/mt_jump.hpp): word j of the block J words further on is XOR_{i : g_i = 1} x[i + j]
+// over the raw word sequence x of the source block.  blockIdx.x picks the source stream
+// q = 2 * step * blockIdx.x and fills stream q + step (zeroed beforehand); blockIdx.y takes one
+// slice of the polynomial's 624 coefficient words, regenerates the stretch of x it needs in LDS and
+// XORs its share into the destination.
+constexpr int MT_JUMP_SLICES = 16;
+constexpr int MT_JUMP_GW = 624 / MT_JUMP_SLICES;                 // coefficient words per slice
+constexpr int MT_JUMP_WIN = MT_JUMP_GW * 32 + 624;               // words of x a slice touches
+__global__ __launch_bounds__(256) void k_mt_jump(const unsigned *__restrict__ g /*[624]*/, unsigned *__restrict__ states,
+                                                 int step, int n_streams) {
+    const int q = (int)blockIdx.x * 2 * step, dst = q + step;
+    if (dst >= n_streams) return;
+    __shared__ unsigned buf[2][624];
+    __shared__ unsigned win[MT_JUMP_WIN + 8];
+    __shared__ unsigned gw[MT_JUMP_GW];
+    const int t = threadIdx.x;
+    const int i0 = (int)blockIdx.y * MT_JUMP_GW * 32, i1 = i0 + MT_JUMP_WIN;
+    for (int i = t; i < 624; i += 256) buf[0][i] = states[(i64)q * 624 + i];
+    if (t < MT_JUMP_GW) gw[t] = g[blockIdx.y * MT_JUMP_GW + t];
+    __syncthreads();
+    int cur = 0;
+    for (int base = 0;; base += 624) {
+        for (int i = t; i < 624; i += 256) {
+            const int gi = base + i;
+            if (gi >= i0 && gi < i1) win[gi - i0] = buf[cur][i];
+        }
+        if (base + 624 >= i1) break;
+        mt_next_block<256>(buf[cur], buf[cur ^ 1], t);
+        cur ^= 1;
     }
     __syncthreads();
-    for (int i = t; i < 624; i += T) state[i] = buf[cur][i];
-    if (t == 0) state[624] = (unsigned)pos;
+    unsigned a0 = 0, a1 = 0, a2 = 0;
+    const bool third = t + 512 < 624;
+    for (int w = 0; w < MT_JUMP_GW; ++w) {
+        unsigned bits = gw[w];
+        while (bits) {
+            const unsigned *x = win + w * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            a0 ^= x[t];
+            a1 ^= x[t + 256];
+            if (third) a2 ^= x[t + 512];
+        }
+    }
+    unsigned *d = states + (i64)dst * 624;
+    atomicXor(d + t, a0);
+    atomicXor(d + t + 256, a1);
+    if (third) atomicXor(d + t + 512, a2);
 }
 
 __device__ __forceinline__ double mt_double(const unsigned *w, i64 idx) {
@@ -953,48 +1012,99 @@ __device__ __forceinline__ double mt_double(const unsigned *w, i64 idx) {
     return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
 }
 
-// left-to-right float64 sum of the 64 lanes' values (lanes >= cnt excluded), same rounding sequence
-// as the reference's sequential marginal (enstop/utils.py:24-29); every lane gets the result
-__device__ __forceinline__ double seq_sum64(double acc, double v, int cnt) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-#pragma unroll 8
-    for (int l = 0; l < 64; ++l) {
-        if (l < cnt) acc += __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
-    }
-    return acc;
-}
-
-// one wave per topic z: doubles [z*m, (z+1)*m) of the stream, coalesced loads, sequential float64
-// marginal, division, float32 cast; writes V[z, :] (reference layout) for the transpose kernel
-__global__ __launch_bounds__(64) void k_mt_init_v(const unsigned *__restrict__ words, int k, int m,
-                                                  float *__restrict__ V) {
+// Sequential float64 marginal of each topic row, same rounding sequence as the reference's
+// left-to-right sum (enstop/utils.py:24-29).  One wave per row: the 64 values of a chunk go through
+// LDS so that every lane adds them in stream order (broadcast reads, one dependent add per value --
+// the chain of m adds is the whole cost); chunks are prefetched four deep.  Padding adds +0.0,
+// which leaves a non-negative sum unchanged.
+__global__ __launch_bounds__(64) void k_mt_marginal_v(const unsigned *__restrict__ words, int k, int m,
+                                                      double *__restrict__ marg) {
+    constexpr int PF = 4;
+    __shared__ double tile[2][64];
     const int z = blockIdx.x, lane = threadIdx.x;
     if (z >= k) return;
     const i64 base = (i64)z * m;
-    double marginal = 0.0;
-    for (int w0 = 0; w0 < m; w0 += 64) {
-        const int cnt = min(64, m - w0);
-        const double v = lane < cnt ? mt_double(words, base + w0 + lane) : 0.0;
-        marginal = seq_sum64(marginal, v, cnt);
+    double nxt[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const int w = p * 64 + lane;
+        nxt[p] = w < m ? mt_double(words, base + w) : 0.0;
     }
-    for (int w = lane; w < m; w += 64) {
-        double v = mt_double(words, base + w);
-        if (marginal > 0.0) v /= marginal;
-        V[base + w] = (float)v;
+    double s = 0.0;
+    for (int w0 = 0; w0 < m; w0 += 64 * PF) {
+        double cur[PF];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) cur[p] = nxt[p];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const i64 w = (i64)w0 + 64 * PF + p * 64 + lane;
+            nxt[p] = w < m ? mt_double(words, base + w) : 0.0;
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            if (w0 + p * 64 >= m) break;
+            tile[p & 1][lane] = cur[p];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 64; ++i) s += tile[p & 1][i];
+        }
+    }
+    if (lane == 0) marg[z] = s;
+}
+
+// V[z, w] = float32(draw / marginal_z) in the reference layout, for the transpose kernel
+__global__ __launch_bounds__(256) void k_mt_scale_v(const unsigned *__restrict__ words, const double *__restrict__ marg,
+                                                    int k, int m, float *__restrict__ V) {
+    const i64 total = (i64)k * m;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += (i64)gridDim.x * 256) {
+        const double mg = marg[i / m];
+        double v = mt_double(words, i);
+        if (mg > 0.0) v /= mg;
+        V[i] = (float)v;
     }
 }
 
-// document d: doubles [off + d*k, off + (d+1)*k); writes U[d, :] (pad columns zeroed)
-__global__ void k_mt_init_u(const unsigned *__restrict__ words, i64 off, i64 n, int k, int kp, float *__restrict__ U) {
-    const i64 d = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= n) return;
-    const i64 base = off + d * k;
-    double marginal = 0.0;
-    for (int z = 0; z < k; ++z) marginal += mt_double(words, base + z);
-    for (int z = 0; z < kp; ++z) {
-        double v = z < k ? mt_double(words, base + z) : 0.0;
-        if (z < k && marginal > 0.0) v /= marginal;
-        U[d * kp + z] = (float)v;
+// 64 documents per wave: doubles [off + d*k, off + (d+1)*k) of the stream per document.  The draws
+// are read coalesced (the 64 documents' values are one contiguous range) into an LDS tile of
+// MT_U_COLS columns at a time, lane d adds document d's values in stream order, then the range is
+// read again, divided and written as U[d, :] (pad columns zeroed) -- again coalesced.
+constexpr int MT_U_COLS = 32;
+__global__ __launch_bounds__(64) void k_mt_init_u(const unsigned *__restrict__ words, i64 off, i64 n, int k, int kp,
+                                                  float *__restrict__ U) {
+    __shared__ double tile[64][MT_U_COLS + 1];
+    __shared__ double marg[64];
+    const int lane = threadIdx.x;
+    const i64 d0 = (i64)blockIdx.x * 64;
+    const int docs = (int)min((i64)64, n - d0);
+    double s = 0.0;
+    for (int kc = 0; kc < k; kc += MT_U_COLS) {
+        const int cols = min(MT_U_COLS, k - kc);
+        const int cnt = docs * cols;
+#pragma unroll 4
+        for (int e = lane; e < cnt; e += 64) {
+            const int r = e / cols, col = e - r * cols;
+            tile[r][col] = mt_double(words, off + (d0 + r) * k + kc + col);
+        }
+        __syncthreads();
+        if (lane < docs) {
+#pragma unroll 8
+            for (int i = 0; i < cols; ++i) s += tile[lane][i];
+        }
+        __syncthreads();
+    }
+    marg[lane] = s;
+    __syncthreads();
+    const int cnt = docs * kp;
+#pragma unroll 4
+    for (int e = lane; e < cnt; e += 64) {
+        const int r = e / kp, z = e - r * kp;
+        double v = 0.0;
+        if (z < k) {
+            v = mt_double(words, off + (d0 + r) * k + z);
+            const double mg = marg[r];
+            if (mg > 0.0) v /= mg;
+        }
+        U[d0 * kp + e] = (float)v;
     }
 }
 

@@ -206,11 +206,12 @@ def _fit_on_engine(eng, k, sample_weight, init, n_iter, n_iter_per_test, toleran
         return eng.fit(sw, n_iter, n_iter_per_test, tolerance, e_step_thresh, flags, trace=trace)
 
     device_init = os.environ.get("ENSTOP_AMD_HOST_INIT", "auto")   # "1": host, "0": device, auto: by size
-    use_device_init = device_init == "0" or (device_init == "auto" and k * (n + m) >= 8_000_000)
+    use_device_init = device_init == "0" or (device_init == "auto" and k * (n + m) >= 262_144)
     if isinstance(init, str) and init == "random" and isinstance(rng, np.random.RandomState) and use_device_init:
         # same draws, same float64 normalisation, same float32 casts as plsa_init + plsa.py:709-710,
-        # evaluated on the device from rng's own MT19937 state (bit-identical, rng is advanced; 2x
-        # faster than the host draws at config 3, no gain below a few million draws)
+        # evaluated on the device from rng's own MT19937 state (bit-identical, rng is advanced).  Long
+        # streams are cut into jump-ahead pieces (csrc/mt_jump.hpp): config 3's 141 M words take 8 ms
+        # against 0.45 s for the host draws + normalisation + upload; tiny problems stay on the host
         eng.init_factors_numpy_stream(k, rng)
         sw = None
         if sample_weight is not None and np.any(np.asarray(sample_weight) != 1.0):

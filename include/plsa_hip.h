@@ -161,6 +161,12 @@ int plsa_measure_stream_bandwidth(plsa_ctx *ctx, int64_t bytes, int32_t kind, in
  *   sequential marginal, used by the factor initialisation (enstop/plsa.py:510-511, 980).          */
 void plsa_host_normalize_rows(double *a, int64_t rows, int64_t cols);
 
+/* plsa_host_mt19937_jump: advance a numpy.random.RandomState key (624 words) by 624 * 2^log2_blocks
+ *   outputs with the jump polynomial the device initialisation uses (csrc/mt_jump.hpp); the position
+ *   inside the block is unaffected by a whole-block jump.  Host-only (tests pin the polynomial
+ *   arithmetic against NumPy without a GPU).  Returns 0, or 1 if log2_blocks is outside [0, 40].   */
+int plsa_host_mt19937_jump(uint32_t *key /*[624]*/, int32_t log2_blocks);
+
 /* synthetic bag-of-words CSR generated on the device (bench.py / large-size tests; not part of the
  * reference): lognormal document lengths, Zipf(s) word ids, counts 1 + Poisson(0.5).  The result
  * becomes base + active matrix.  nnz_target is approximate; the exact nnz is returned.            */

@@ -162,3 +162,30 @@ def test_topic_metrics_match_reference():
         model.coherence(topic_num=99)
     with pytest.raises(ValueError):
         model.log_lift(topic_num="a")
+
+
+@pytest.mark.parametrize("seed,advance,log2_blocks", [(42, 0, 0), (42, 1000, 1), (7, 5000, 3), (123, 700, 11), (5, 624, 17)])
+def test_mt19937_block_jump_matches_numpy(seed, advance, log2_blocks):
+    """csrc/mt_jump.hpp: the characteristic polynomial recovered by Berlekamp-Massey and the jump
+    polynomials x^(624 * 2^b) mod phi move a RandomState key exactly as generating the outputs does."""
+    import ctypes as C
+    from enstop_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(seed)
+    if advance:
+        rs.bytes(4 * advance)
+    state = rs.get_state()
+    key = np.array(state[1], dtype=np.uint32)
+    assert lib.plsa_host_mt19937_jump(key.ctypes.data_as(C.POINTER(C.c_uint32)), log2_blocks) == 0
+    chunk = 624 * 4 * 4096
+    left = 624 * 4 * (1 << log2_blocks)
+    while left:
+        take = min(left, chunk)
+        rs.bytes(take)
+        left -= take
+    after = rs.get_state()
+    assert after[2] == state[2]
+    want = np.array(after[1], dtype=np.uint32)
+    np.testing.assert_array_equal(key[1:], want[1:])
+    assert (key[0] ^ want[0]) & 0x80000000 == 0        # only the top bit of word 0 is generator state
+    assert lib.plsa_host_mt19937_jump(key.ctypes.data_as(C.POINTER(C.c_uint32)), 41) == 1

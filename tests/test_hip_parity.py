@@ -633,6 +633,27 @@ def test_device_mt19937_init_is_bit_identical_to_numpy(amd, n_m_k):
         np.testing.assert_array_equal(rng_h.rand(5), rng_d.rand(5))      # same continuation
 
 
+@pytest.mark.parametrize("streams", [2, 5, 16, 128])
+def test_device_mt19937_jump_ahead_streams_are_bit_identical(amd, monkeypatch, streams):
+    """The init stream cut into pieces by MT19937 jump-ahead (csrc/mt_jump.hpp, k_mt_jump) is the one
+    sequential NumPy stream: same factors, same generator state afterwards."""
+    monkeypatch.setenv("PLSA_MT_STREAMS", str(streams))
+    monkeypatch.setenv("PLSA_MT_MIN_BLOCKS", "1")
+    for (n, m, k), prime in (((5000, 3000, 64), 0), ((333, 1000, 20), 700), ((20000, 5000, 33), 3)):
+        X = _corpus(n, m, 0.002 if n > 10000 else 0.02, seed=n + k)
+        rng_h, rng_d = np.random.RandomState(k + prime), np.random.RandomState(k + prime)
+        rng_h.randint(0, 10, size=prime); rng_d.randint(0, 10, size=prime)
+        Uh, Vh = amd.plsa_init(X, k, rng=rng_h)
+        with amd.Engine() as eng:
+            eng.upload_csr(X)
+            eng.init_factors_numpy_stream(k, rng_d)
+            Ud, Vd = eng.get_factors()
+        np.testing.assert_array_equal(Ud, Uh.astype(np.float32))
+        np.testing.assert_array_equal(Vd, Vh.astype(np.float32))
+        np.testing.assert_array_equal(rng_h.rand(5), rng_d.rand(5))
+        assert rng_h.get_state()[2] == rng_d.get_state()[2]
+
+
 def test_host_and_device_init_paths_give_identical_fits(amd, monkeypatch):
     X = _corpus(800, 600, 0.05, seed=77)
     ones = np.ones(800, np.float32)
