@@ -74,6 +74,7 @@ struct plsa_ctx {
     DevBuf colptr, csc_row, csc_val, csc_pos, item_first, item_col, item_start, item_order, partial, heavy_cols;
     bool use_item_order = true, xcd_split = true;
     int chunks_per_lane = 2;
+    int e_rows = -1;               // E-step traversal: 1 document-owned, 0 one group per non-zero, -1 by size (PLSA_E_ROWS)
     int mt_streams = 256;          // pieces the MT19937 init stream is cut into (PLSA_MT_STREAMS; 1 = sequential)
     i64 mt_min_blocks = 4096;      // ... once it is at least this many 624-word blocks long (PLSA_MT_MIN_BLOCKS)
     int heavy_items = 32, n_heavy = 0;
@@ -493,7 +494,6 @@ int need_factors(plsa_ctx *c) {
 // kernel wrappers
 // ---------------------------------------------------------------------------------------------
 int run_e_step(plsa_ctx *c, float thresh) {
-    CHK(ensure_rowidx(c));
     {   // the materialised schedule needs the whole nnz x kp array: say so instead of a bare OOM
         const size_t need = sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp;
         size_t free_b = 0, total_b = 0;
@@ -509,14 +509,37 @@ int run_e_step(plsa_ctx *c, float thresh) {
         CHK(ensure_best_placement(c, c->P, sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp + std::max(slack, c->p_shift),
                                   c->placement_candidates, c->placement_gbps, &c->placement_tried));
     }
-    const i64 tiles = (c->nnz + 63) / 64;
-    const int grid = grid_for(c, tiles, 4);
-    CHK(dispatch_shape(c, [&](auto S) {
-        Scope s(c, "k_e_step");
-        hipLaunchKernelGGL((plsa::k_e_step<decltype(S)>), dim3(grid), dim3(256), 0, c->stream,
-                           c->rowidx.as<int>(), c->col, c->nnz, c->U[c->cu].as<float>(),
-                           c->Vt[c->cv].as<float>(), p_base(c), c->kp, thresh);
-    }));
+    // Two traversals.  Document-owned (a group keeps its document's P(z|d) row in registers, gathers
+    // only P(w|z) rows): config 3 5.4 ms against 6.3 ms, config 5 49 ms against 59 ms.  It needs many
+    // documents per resident group to average their lengths out; small corpora (config 2: 1.5
+    // documents per group slot, 0.36 ms against 0.33 ms) keep the perfectly balanced flat kernel.
+    CHK(ensure_ritems(c));
+    const bool items = c->use_ritems && c->n_ritems > 0;
+    const i64 owners = items ? c->n_ritems : c->n;
+    const i64 group_slots = (i64)c->prop.multiProcessorCount * 32 * (64 / c->lpn);
+    const bool e_rows = c->e_rows < 0 ? owners >= 16 * group_slots : c->e_rows != 0;
+    if (e_rows) {
+        const int grid = grid_for(c, items ? c->n_ritems : c->n, 256 / c->lpn);
+        const int *order = nullptr;
+        if (!items) CHK(ensure_roworder(c, &order));
+        CHK(dispatch_shape(c, [&](auto S) {
+            Scope s(c, "k_e_step");
+            hipLaunchKernelGGL((plsa::k_e_step_rows<decltype(S)>), dim3(grid), dim3(256), 0, c->stream,
+                               c->indptr, c->col, (int)c->n, order, c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
+                               p_base(c), c->kp, thresh, items ? c->ritem_row.as<int>() : nullptr,
+                               items ? c->ritem_start.as<int>() : nullptr, c->rseg, c->n_ritems);
+        }));
+    } else {
+        CHK(ensure_rowidx(c));
+        const i64 tiles = (c->nnz + 63) / 64;
+        const int grid = grid_for(c, tiles, 4);
+        CHK(dispatch_shape(c, [&](auto S) {
+            Scope s(c, "k_e_step");
+            hipLaunchKernelGGL((plsa::k_e_step<decltype(S)>), dim3(grid), dim3(256), 0, c->stream,
+                               c->rowidx.as<int>(), c->col, c->nnz, c->U[c->cu].as<float>(),
+                               c->Vt[c->cv].as<float>(), p_base(c), c->kp, thresh);
+        }));
+    }
     CHK(launch_check(c, "k_e_step"));
     c->p_valid = true;
     return 0;
@@ -596,16 +619,12 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh) {
             }
         }
         {
+            // heavy columns (one block each) and the rest share one launch
             Scope s(c, "k_col_reduce");
-            hipLaunchKernelGGL((plsa::k_col_reduce<Sh>), dim3(grid2), dim3(256), 0, c->ls,
-                               c->item_first.as<int>(), (int)c->m, c->heavy_items,
+            hipLaunchKernelGGL((plsa::k_col_reduce<Sh>), dim3(grid2 + c->n_heavy), dim3(256),
+                               c->n_heavy > 0 ? (256 / LPN) * c->kp * sizeof(float) : 0, c->ls,
+                               c->item_first.as<int>(), (int)c->m, c->heavy_items, c->heavy_cols.as<int>(), c->n_heavy,
                                c->partial.as<float>(), c->Vacc.as<float>(), c->kp);
-        }
-        if (c->n_heavy > 0) {
-            Scope s(c, "k_col_reduce_heavy");
-            hipLaunchKernelGGL((plsa::k_col_reduce_heavy<Sh>), dim3(c->n_heavy), dim3(256),
-                               (256 / LPN) * c->kp * sizeof(float), c->ls, c->heavy_cols.as<int>(),
-                               c->item_first.as<int>(), c->partial.as<float>(), c->Vacc.as<float>(), c->kp);
         }
     }));
     CHK(launch_check(c, "k_col_pass"));
@@ -745,6 +764,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_ITEM_ORDER")) c->use_item_order = atoi(s) != 0;
     if (const char *s = getenv("PLSA_XCD_SPLIT")) c->xcd_split = atoi(s) != 0;
     if (const char *s = getenv("PLSA_CHUNKS_PER_LANE")) c->chunks_per_lane = atoi(s);
+    if (const char *s = getenv("PLSA_E_ROWS")) c->e_rows = atoi(s);
     if (const char *s = getenv("PLSA_MT_STREAMS")) c->mt_streams = std::max(1, std::min(4096, atoi(s)));
     if (const char *s = getenv("PLSA_MT_MIN_BLOCKS")) c->mt_min_blocks = std::max(1, atoi(s));
     *out = c;
@@ -1389,7 +1409,7 @@ int plsa_timing_report(plsa_ctx *c, char *buf, int64_t cap) {
 
 int plsa_measure_stream_bandwidth(plsa_ctx *c, int64_t bytes, int32_t kind, int32_t reps, double *gbps) {
     HIPCHK(c, hipSetDevice(c->device));
-    if (bytes < (1 << 20) || reps < 1 || kind < 0 || kind > 3) return fail(c, "plsa_measure_stream_bandwidth: bad arguments");
+    if (bytes < (1 << 20) || reps < 1 || kind < 0 || kind > 6) return fail(c, "plsa_measure_stream_bandwidth: bad arguments");
     DevBuf a, b;
     const i64 n4 = bytes / 16;
     int rc = ensure(c, a, (size_t)n4 * 16);
@@ -1402,6 +1422,7 @@ int plsa_measure_stream_bandwidth(plsa_ctx *c, int64_t bytes, int32_t kind, int3
         if (r == 0) (void)hipEventRecord(e0, c->stream);
         if (kind == 0) hipLaunchKernelGGL((plsa::k_probe_fill<true>), dim3(grid), dim3(256), 0, c->stream, a.as<float>(), n4);
         else if (kind == 1) hipLaunchKernelGGL((plsa::k_probe_fill<false>), dim3(grid), dim3(256), 0, c->stream, a.as<float>(), n4);
+        else if (kind >= 4) hipLaunchKernelGGL(plsa::k_probe_fill_tiled, dim3(grid_for(c, n4, 256 * (kind == 4 ? 16 : kind == 5 ? 4 : 64))), dim3(256), 0, c->stream, a.as<float>(), n4, kind == 4 ? 16 : kind == 5 ? 4 : 64);
         else if (kind == 3) hipLaunchKernelGGL(plsa::k_probe_read, dim3(grid), dim3(256), 0, c->stream, a.as<float>(), a.as<float>(), n4);
         else hipLaunchKernelGGL(plsa::k_probe_copy, dim3(grid), dim3(256), 0, c->stream, a.as<float>(), b.as<float>(), n4);
     }

@@ -29,7 +29,7 @@
                             // passes and -14 % on the E-step (U rows are re-used from L1 by ~100 nnz)
 #endif
 #ifndef PLSA_UNR_E
-#define PLSA_UNR_E PLSA_UNR   // E-step: steps (of 64/LPN non-zeros each) per gather batch
+#define PLSA_UNR_E 16   // E-step: float4 gathers per lane and burst (divided by the chunks per lane)
 #endif
 #ifndef PLSA_WAVES
 #define PLSA_WAVES 1    // min waves per SIMD requested from the register allocator for the hot kernels
@@ -89,7 +89,11 @@ struct Shape {
     static constexpr bool FULL = FULL_;
     static constexpr int UNR = (LPN_ < PLSA_UNR) ? LPN_ : PLSA_UNR;
     static constexpr int UNR_COL = (LPN_ < PLSA_UNR_COL) ? LPN_ : PLSA_UNR_COL;
-    static constexpr int UNR_E = (LPN_ < PLSA_UNR_E) ? LPN_ : PLSA_UNR_E;
+    // E-step: gathers per burst, ideally the whole index batch (LPN entries) so that a wave alternates
+    // between one long run of loads and one long run of stores (measured: 4 -> 5.81 ms, 16 -> 5.43 ms at k = 64)
+    static constexpr int UNR_EF = (LPN_ < 4) ? LPN_ : 4;   // flat (per-non-zero) E-step kernel
+    static constexpr int UNR_E_CAP = (PLSA_UNR_E / CH_ > 0) ? PLSA_UNR_E / CH_ : 1;
+    static constexpr int UNR_E = (LPN_ < UNR_E_CAP) ? LPN_ : UNR_E_CAP;
     __device__ static __forceinline__ int kp(int kp_rt) { return FULL_ ? 4 * LPN_ * CH_ : kp_rt; }
     // offset of chunk j for lane li, and whether it lies inside the row
     __device__ static __forceinline__ int c4(int li, int j) { return 4 * (li + LPN_ * j); }
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step(const int *__restric
                                                 const float *__restrict__ U,
                                                 const float *__restrict__ Vt, float *__restrict__ P,
                                                 int kp_rt, float thresh) {
-    constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR_E;
+    constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR_EF;
     constexpr int GPW = 64 / LPN;  // groups (= non-zeros per step) per wave
     const int kp = S::kp(kp_rt);
     const int lane = threadIdx.x & 63;
@@ -197,6 +201,68 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step(const int *__restric
                         p.x = keep[j].x * inv; p.y = keep[j].y * inv;
                         p.z = keep[j].z * inv; p.w = keep[j].w * inv;
                         st4_nt(prow + S::c4(li, j), p);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Document-owned E-step: a group keeps its document's P(z|d) row in registers and walks the
+// document's non-zeros (same traversal as k_row_pass: rows in descending-length order, or row items
+// for corpora with few long documents), so the only gathers are the P(w|z) rows and the (doc) index
+// stream is not read at all.  Measured against the flat kernel above on config 3: the P(z|d) row
+// loads are L1/L2 hits there but still cost a tenth of the kernel (tools/experiments/README.md).
+template <class S>
+__global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step_rows(const int *__restrict__ indptr,
+                                                     const int *__restrict__ colidx, int n,
+                                                     const int *__restrict__ row_order,
+                                                     const float *__restrict__ U,
+                                                     const float *__restrict__ Vt, float *__restrict__ P,
+                                                     int kp_rt, float thresh,
+                                                     const int *__restrict__ ritem_row,
+                                                     const int *__restrict__ ritem_start, int rseg,
+                                                     i64 n_ritems) {
+    constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR_E;
+    constexpr int GPB = 256 / LPN;
+    const int kp = S::kp(kp_rt);
+    const int li = threadIdx.x % LPN;
+    const int gid = threadIdx.x / LPN;
+    const bool items = ritem_row != nullptr;
+    const i64 n_work = items ? n_ritems : (i64)n;
+    for (i64 r = (i64)blockIdx.x * GPB + gid; r < n_work; r += (i64)gridDim.x * GPB) {
+        const int d = items ? ritem_row[r] : (row_order ? row_order[r] : (int)r);
+        const int j0 = items ? ritem_start[r] : indptr[d];
+        const int j1 = items ? min(j0 + rseg, indptr[d + 1]) : indptr[d + 1];
+        float4 u[CH];
+        load_row<S, true, PLSA_NT_STREAMS>(U + (i64)d * kp, li, kp, u);
+        int w_n = (j0 + li < j1) ? ldi(colidx + j0 + li) : 0;
+        for (int jb = j0; jb < j1; jb += LPN) {
+            const int w_l = w_n;
+            const int jn = jb + LPN + li;
+            w_n = jn < j1 ? ldi(colidx + jn) : 0;
+            const int cnt = min(LPN, j1 - jb);
+            for (int s0 = 0; s0 < cnt; s0 += UNR) {
+                float4 vt[UNR][CH];
+#pragma unroll
+                for (int q = 0; q < UNR; ++q)
+                    load_row<S, false>(Vt + (i64)__shfl(w_l, s0 + q, LPN) * kp, li, kp, vt[q]);
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) {
+                    float4 keep[CH];
+                    float unth;
+                    const float inv = inv_norm(group_sum<LPN>(products<CH, false>(u, vt[q], thresh, keep, unth)));
+                    if (s0 + q < cnt) {
+                        float *prow = P + (i64)(jb + s0 + q) * kp;
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) {
+                            if (S::ok(li, j, kp)) {
+                                float4 p;
+                                p.x = keep[j].x * inv; p.y = keep[j].y * inv;
+                                p.z = keep[j].z * inv; p.w = keep[j].w * inv;
+                                st4_nt(prow + S::c4(li, j), p);
+                            }
+                        }
                     }
                 }
             }
@@ -491,22 +557,63 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int *__restr
     }
 }
 
-// adds the item partials of each column (fixed order) into the un-normalised Vt_new.  Columns with
-// more than `heavy_items` items (the Zipf head) are left to k_col_reduce_heavy.
+// adds the item partials of each column (fixed order) into the un-normalised Vt_new.
+// Blocks [0, n_heavy) each take one column with more than `heavy_items` items (the Zipf head): the
+// block's groups stride over the column's items (fixed assignment, loads batched four deep, added in
+// item order), then their sums are added in group order through LDS -> bit-reproducible.  The other
+// blocks give one group to each of the remaining columns.
 template <class S>
 __global__ __launch_bounds__(256) void k_col_reduce(const int *__restrict__ item_first, int m,
-                                                    int heavy_items,
-                                                    const float *__restrict__ partial,
+                                                    int heavy_items, const int *__restrict__ heavy_cols,
+                                                    int n_heavy, const float *__restrict__ partial,
                                                     float *__restrict__ Vt_new, int kp_rt) {
     constexpr int LPN = S::LPN, CH = S::CH;
     constexpr int GPB = 256 / LPN;
+    extern __shared__ float sacc[];  // [GPB][kp], heavy blocks only
     const int kp = S::kp(kp_rt);
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
-    for (i64 c = (i64)blockIdx.x * GPB + gid; c < m; c += (i64)gridDim.x * GPB) {
+    float4 acc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] = zero4();
+    if ((int)blockIdx.x < n_heavy) {
+        const int c = heavy_cols[blockIdx.x];
+        const int i0 = item_first[c], i1 = item_first[c + 1];
+        constexpr int B = 4;
+        for (int it = i0 + gid; it < i1; it += GPB * B) {
+            float4 p[B][CH];
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                const int iu = it + u * GPB;
+                if (iu < i1) {
+                    load_row<S, true>(partial + (i64)iu * kp, li, kp, p[u]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) p[u][j] = zero4();
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < B; ++u)
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    acc[j].x += p[u][j].x; acc[j].y += p[u][j].y; acc[j].z += p[u][j].z; acc[j].w += p[u][j].w;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (S::ok(li, j, kp)) st4(sacc + gid * kp + S::c4(li, j), acc[j]);
+        __syncthreads();
+        for (int z = threadIdx.x; z < kp; z += 256) {
+            float t = 0.f;
+            for (int g = 0; g < GPB; ++g) t += sacc[g * kp + z];
+            Vt_new[(i64)c * kp + z] = t;
+        }
+        return;
+    }
+    const i64 nb = (i64)gridDim.x - n_heavy;
+    for (i64 c = ((i64)blockIdx.x - n_heavy) * GPB + gid; c < m; c += nb * GPB) {
         const int i0 = item_first[c], i1 = item_first[c + 1];
         if (i1 - i0 > heavy_items) continue;
-        float4 acc[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) acc[j] = zero4();
         for (int it = i0; it < i1; ++it) {
@@ -520,43 +627,6 @@ __global__ __launch_bounds__(256) void k_col_reduce(const int *__restrict__ item
 #pragma unroll
         for (int j = 0; j < CH; ++j)
             if (S::ok(li, j, kp)) st4(Vt_new + c * kp + S::c4(li, j), acc[j]);
-    }
-}
-
-// one block per heavy column: the block's groups stride over the column's items (fixed assignment),
-// then their sums are added in group order through LDS -> bit-reproducible.
-template <class S>
-__global__ __launch_bounds__(256) void k_col_reduce_heavy(const int *__restrict__ heavy_cols,
-                                                          const int *__restrict__ item_first,
-                                                          const float *__restrict__ partial,
-                                                          float *__restrict__ Vt_new, int kp_rt) {
-    constexpr int LPN = S::LPN, CH = S::CH;
-    constexpr int GPB = 256 / LPN;
-    extern __shared__ float sacc[];  // [GPB][kp]
-    const int kp = S::kp(kp_rt);
-    const int li = threadIdx.x % LPN;
-    const int gid = threadIdx.x / LPN;
-    const int c = heavy_cols[blockIdx.x];
-    const int i0 = item_first[c], i1 = item_first[c + 1];
-    float4 acc[CH];
-#pragma unroll
-    for (int j = 0; j < CH; ++j) acc[j] = zero4();
-    for (int it = i0 + gid; it < i1; it += GPB) {
-        float4 p[CH];
-        load_row<S, true>(partial + (i64)it * kp, li, kp, p);
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            acc[j].x += p[j].x; acc[j].y += p[j].y; acc[j].z += p[j].z; acc[j].w += p[j].w;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < CH; ++j)
-        if (S::ok(li, j, kp)) st4(sacc + gid * kp + S::c4(li, j), acc[j]);
-    __syncthreads();
-    for (int z = threadIdx.x; z < kp; z += 256) {
-        float t = 0.f;
-        for (int g = 0; g < GPB; ++g) t += sacc[g * kp + z];
-        Vt_new[(i64)c * kp + z] = t;
     }
 }
 
@@ -1114,6 +1184,17 @@ __global__ __launch_bounds__(256) void k_probe_fill(float *__restrict__ p, i64 n
     const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n4; i += (i64)gridDim.x * 256) {
         if (NT) st4_nt(p + i * 4, v); else st4(p + i * 4, v);
+    }
+}
+// the E-step's store order: each wave writes `rows` consecutive 1-KB rows (one 16-B store per lane
+// and row) before moving to its next tile
+__global__ __launch_bounds__(256) void k_probe_fill_tiled(float *__restrict__ p, i64 n4, int rows) {
+    const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 tiles = n4 / (64 * (i64)rows);
+    for (i64 t = (i64)blockIdx.x * 4 + wave; t < tiles; t += (i64)gridDim.x * 4) {
+        float *base = p + (t * rows * 64 + lane) * 4;
+        for (int r = 0; r < rows; ++r) st4_nt(base + (i64)r * 256, v);
     }
 }
 // read-only stream: every lane accumulates its float4s, one store per thread at the end

@@ -256,6 +256,52 @@ def test_kernels_vs_oracle_midsize(amd, oracle, k):
              np.array([oracle.log_likelihood(r, c, v, Vo, Uo, ones)]))
 
 
+@pytest.mark.parametrize("traversal", ["flat", "documents", "document_items"])
+def test_e_step_traversals_agree_with_reference_and_oracle(amd, oracle, monkeypatch, traversal):
+    """The E-step has two traversals, picked by corpus size (one group per non-zero; one group per
+    document or document piece).  Both are forced here on the reference goldens and on seeded
+    shapes with empty, single-entry and very long documents; the two must agree bit for bit."""
+    monkeypatch.setenv("PLSA_E_ROWS", "0" if traversal == "flat" else "1")
+    if traversal == "document_items":
+        monkeypatch.setenv("PLSA_ROW_ITEMS", "1")
+        monkeypatch.setenv("PLSA_ROW_SEG", "16")
+    results = []
+    with amd.Engine() as eng:
+        for case in KERNEL_CASES:
+            g = load_golden(case)
+            eng.upload_csr(golden_csr(g))
+            eng.set_factors(g["U"], g["V"])
+            P = eng.e_step(g["thresh"])
+            np.testing.assert_array_equal(P == 0.0, g["P"] == 0.0)
+            np.testing.assert_allclose(P, g["P"], rtol=2e-6, atol=1e-9)
+        rs = np.random.RandomState(11)
+        for n, m, k, thresh in ((700, 900, 64, 1e-32), (300, 500, 20, 1e-6), (1200, 300, 33, 1e-32),
+                                (50, 4000, 128, 1e-32), (2000, 100, 3, 1e-4), (400, 600, 200, 1e-32)):
+            X = _corpus(n, m, 0.03, seed=n + k, empty_rows=min(5, n // 10)).tolil()
+            X[1, :] = 1.0                                  # a document holding the whole vocabulary
+            X[2, :] = 0.0; X[2, m // 2] = 3.0              # a single-entry document
+            X = X.tocsr().astype(np.float32); X.sort_indices()
+            V = rs.rand(k, m); V /= V.sum(1, keepdims=True)
+            U = rs.rand(n, k); U /= U.sum(1, keepdims=True)
+            V = V.astype(np.float32); U = U.astype(np.float32)
+            U[7] = 0.0
+            r, c, v = coo_arrays(X)
+            Po = oracle.plsa_e_step(r, c, v, V, U, np.zeros((r.shape[0], k), np.float32), thresh)
+            eng.upload_csr(X)
+            eng.set_factors(U, V)
+            P = eng.e_step(thresh)
+            np.testing.assert_array_equal(P == 0.0, Po == 0.0)
+            np.testing.assert_allclose(P, Po, rtol=3e-6, atol=1e-10)
+            results.append(P)
+    _E_STEP_TRAVERSAL_RESULTS[traversal] = results
+    first = next(iter(_E_STEP_TRAVERSAL_RESULTS.values()))
+    for a, b in zip(first, results):
+        np.testing.assert_array_equal(a, b)               # same arithmetic per non-zero in every traversal
+
+
+_E_STEP_TRAVERSAL_RESULTS = {}
+
+
 # ------------------------------------------------------------------------------------------------
 # size-independent properties at sizes the oracle cannot reach in seconds
 # ------------------------------------------------------------------------------------------------
