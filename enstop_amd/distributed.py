@@ -3,14 +3,17 @@ rendezvous, RCCL ("nccl" backend on ROCm) for the single exchange step -- the al
 members' topic matrices that replaces np.vstack over thread results (enstop/enstop_.py:231).
 No collective sits on the EM data path: members are independent."""
 import os
+import sys
 
 import numpy as np
 
 
 def _dist():
-    try:
-        import torch.distributed as dist
-    except Exception:          # torch absent: single process
+    # a process group can only have been initialised by code that imported torch.distributed itself:
+    # look it up instead of importing it (importing torch costs seconds, minutes on a cold box, and
+    # the single-process ensemble does not need it)
+    dist = sys.modules.get("torch.distributed")
+    if dist is None:
         return None
     return dist if dist.is_available() and dist.is_initialized() else None
 
