@@ -40,6 +40,8 @@ SIGNATURES = {
     "plsa_get_factors": (C.c_int, [_ctx, _vp, _vp]),
     "plsa_init_factors_device": (C.c_int, [_ctx, _i32, C.c_uint64]),
     "plsa_init_factors_mt19937": (C.c_int, [_ctx, _i32, np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]),
+    "plsa_refit_init_mt19937": (C.c_int, [_ctx, C.c_void_p, _i64, _i32,
+                                          np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]),
     "plsa_copy_components_to_device": (C.c_int, [_ctx, _vp]),
     "plsa_e_step": (C.c_int, [_ctx, C.c_float, _vp]),
     "plsa_set_p": (C.c_int, [_ctx, _f32p]),

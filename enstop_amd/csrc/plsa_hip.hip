@@ -988,7 +988,9 @@ int plsa_init_factors_device(plsa_ctx *c, int32_t k, uint64_t seed) {
 // plsa_init(X, k, init="random", rng) + the float32 casts of plsa_fit (plsa.py:455-456, 510-511,
 // 709-710) with the reference's own MT19937 stream, evaluated on the device.  state_io: the 624 key
 // words + position of numpy.random.RandomState.get_state(); on return it holds the advanced state.
-int plsa_init_factors_mt19937(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/) {
+// V_host == nullptr: plsa_init (topics drawn first, then the document rows).  V_host != nullptr: the
+// refit initialisation (plsa.py:979-981) -- only rand(n, k) is drawn, the topics are the given ones.
+static int mt_init(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/, const float *V_host) {
     HIPCHK(c, hipSetDevice(c->device));
     if (c->n <= 0) return fail(c, "plsa_init_factors_mt19937: upload a corpus first");
     if (k <= 0 || k > 1024) return fail(c, "plsa_init_factors_mt19937: k=%d outside [1,1024]", k);
@@ -1008,7 +1010,8 @@ int plsa_init_factors_mt19937(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->Vt[i], sizeof(float) * (size_t)m * kp));
     CHK(ensure(c, c->Vacc, sizeof(float) * (size_t)m * kp));
     c->p_valid = false; c->cu = 0; c->cv = 0;
-    const i64 n_doubles = (i64)k * m + n * (i64)k;
+    const i64 v_doubles = V_host ? 0 : (i64)k * m;
+    const i64 n_doubles = v_doubles + n * (i64)k;
     const i64 n_words = 2 * n_doubles;
     // Split the stream into pieces that start 2^b blocks apart (csrc/mt_jump.hpp) once it is long
     // enough to pay for the jumps; the words produced are those of the one sequential stream.
@@ -1050,7 +1053,13 @@ int plsa_init_factors_mt19937(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]
         { Scope s(c, "k_mt19937_fill");
           hipLaunchKernelGGL(plsa::k_mt19937_fill, dim3((unsigned)n_streams), dim3(PLSA_MT_THREADS), 0, c->stream,
                              st.as<unsigned>(), words.as<unsigned>(), pos0, per_stream, n_words, n_streams, fin.as<unsigned>()); }
-        {
+        if (V_host) {
+            float *Vtmp = reinterpret_cast<float *>(c->Vt[1].p);     // [m*kp] floats >= k*m: free scratch here
+            e = hipMemcpyAsync(Vtmp, V_host, sizeof(float) * (size_t)k * m, hipMemcpyHostToDevice, c->stream);
+            dim3 grid((unsigned)((m + 31) / 32), (unsigned)((kp + 31) / 32));
+            if (e == hipSuccess)
+                hipLaunchKernelGGL(plsa::k_v_to_vt, grid, dim3(256), 0, c->stream, Vtmp, c->Vt[0].as<float>(), k, (int)m, kp);
+        } else {
             // V[k, m] in the reference layout (words are consumed in that order), then the layout transpose
             float *Vtmp = reinterpret_cast<float *>(c->Vt[1].p);     // [m*kp] floats >= k*m: free scratch here
             double *marg = reinterpret_cast<double *>(fin.as<unsigned>() + 632) ;   // k <= 1024 doubles behind the state
@@ -1061,14 +1070,25 @@ int plsa_init_factors_mt19937(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]
             hipLaunchKernelGGL(plsa::k_v_to_vt, grid, dim3(256), 0, c->stream, Vtmp, c->Vt[0].as<float>(), k, (int)m, kp);
         }
         hipLaunchKernelGGL(plsa::k_mt_init_u, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream,
-                           words.as<unsigned>(), (i64)k * m, n, k, kp, c->U[0].as<float>());
-        e = hipGetLastError();
+                           words.as<unsigned>(), v_doubles, n, k, kp, c->U[0].as<float>());
+        if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(state_io, fin.p, sizeof(unsigned) * 625, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     release(words); release(st); release(fin); release(gp);
     if (e != hipSuccess) return fail(c, "plsa_init_factors_mt19937: %s", hipGetErrorString(e));
     return 0;
+}
+
+int plsa_init_factors_mt19937(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/) {
+    if (!state_io) return fail(c, "plsa_init_factors_mt19937: state_io is NULL");
+    return mt_init(c, k, state_io, nullptr);
+}
+
+int plsa_refit_init_mt19937(plsa_ctx *c, const float *V, int64_t m, int32_t k, uint32_t *state_io /*[625]*/) {
+    if (!state_io || !V) return fail(c, "plsa_refit_init_mt19937: NULL argument");
+    if (m != c->m) return fail(c, "plsa_refit_init_mt19937: topics have %lld words, the active matrix %lld", (long long)m, (long long)c->m);
+    return mt_init(c, k, state_io, V);
 }
 
 int plsa_get_factors(plsa_ctx *c, float *U, float *V) {

@@ -142,17 +142,24 @@ class Engine:
         self.k = int(k)
         return self
 
-    def init_factors_numpy_stream(self, k, rng):
+    def init_factors_numpy_stream(self, k, rng, topics=None):
         """plsa_init(random) + float32 casts on the device, drawing from `rng` (a legacy
         numpy.random.RandomState, MT19937) exactly as rng.rand(k, m); rng.rand(n, k) would; `rng`
-        is left in the state the host path would leave it in."""
+        is left in the state the host path would leave it in.  With `topics` ([k, m], fixed) only
+        rng.rand(n, k) is drawn: the initialisation of plsa_refit (plsa.py:979-981)."""
         kind, key, pos, has_gauss, cached = rng.get_state()
         if kind != "MT19937":
             raise ValueError("not an MT19937 RandomState")
         state = np.empty(625, np.uint32)
         state[:624] = key
         state[624] = pos
-        self._ok(self._L.plsa_init_factors_mt19937(self._h, int(k), state))
+        if topics is None:
+            self._ok(self._L.plsa_init_factors_mt19937(self._h, int(k), state))
+        else:
+            V = _f32(topics)
+            if V.shape[0] != int(k):
+                raise ValueError("topics have %d rows, expected k=%d" % (V.shape[0], int(k)))
+            self._ok(self._L.plsa_refit_init_mt19937(self._h, ptr(V), V.shape[1], int(k), state))
         rng.set_state((kind, state[:624].copy(), int(state[624]), has_gauss, cached))
         self.k = int(k)
         return self

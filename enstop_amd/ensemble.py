@@ -193,7 +193,7 @@ class EnsembleTopics(_TopicMetricsMixin, BaseEstimator, TransformerMixin):
     def transform(self, X, y=None):
         X = check_array(X, accept_sparse="csr")
         random_state = check_random_state(self.transform_random_seed)
-        X = coo_matrix(X) if not issparse(X) else X.tocoo()
+        X = csr_matrix(X) if not issparse(X) else X.tocsr()
         sample_weight = _check_sample_weight(None, X, dtype=np.float32)
         return plsa_refit(X, self.components_, sample_weight, n_iter=50, n_iter_per_test=5,
                           tolerance=0.001, random_state=random_state, device=self.device)

@@ -274,12 +274,19 @@ def plsa_refit(X, topics, sample_weight, n_iter=50, n_iter_per_test=10, toleranc
     topics = np.asarray(topics)
     k = topics.shape[0]
     rng = check_random_state(random_state)
-    p_z_given_d = rng.rand(X.shape[0], k)                    # plsa.py:979
-    normalize(p_z_given_d, axis=1)
-    p_z_given_d = p_z_given_d.astype(np.float32)
     eng = get_engine(device)
     eng.upload_csr(X)
-    eng.set_factors(p_z_given_d, topics.astype(np.float32))
+    device_init = os.environ.get("ENSTOP_AMD_HOST_INIT", "auto")
+    if isinstance(rng, np.random.RandomState) and (
+            device_init == "0" or (device_init == "auto" and k * X.shape[0] >= 262_144)):
+        # rng.rand(n, k), float64 row normalisation, float32 cast (plsa.py:979-981) on the device
+        # from rng's own stream: bit-identical, 0.22 s of host draws saved at 1 M documents x 64
+        eng.init_factors_numpy_stream(k, rng, topics=topics)
+    else:
+        p_z_given_d = rng.rand(X.shape[0], k)                # plsa.py:979
+        normalize(p_z_given_d, axis=1)
+        p_z_given_d = p_z_given_d.astype(np.float32)
+        eng.set_factors(p_z_given_d, topics.astype(np.float32))
     sw = None
     if sample_weight is not None and np.any(np.asarray(sample_weight) != 1.0):
         sw = np.asarray(sample_weight, np.float32)
@@ -375,7 +382,9 @@ class PLSA(_TopicMetricsMixin, BaseEstimator, TransformerMixin):
         X = check_array(X, accept_sparse="csr")
         random_state = check_random_state(self.transform_random_seed)
         sample_weight = _check_sample_weight(None, X, dtype=np.float32)
-        X = coo_matrix(X) if not issparse(X) else X.tocoo()
+        # the reference converts to COO here (plsa.py:1208); the engine consumes the CSR arrays in the
+        # same entry order directly (and, unlike a COO -> CSR round trip, never merges duplicates)
+        X = csr_matrix(X) if not issparse(X) else X.tocsr()
         # plsa.py:1210-1218: fixed n_iter=50, n_iter_per_test=5, tolerance=0.001
         return plsa_refit(X, self.components_, sample_weight, n_iter=50, n_iter_per_test=5,
                           tolerance=0.001, random_state=random_state, device=self.device,

@@ -80,6 +80,10 @@ int plsa_init_factors_device(plsa_ctx *ctx, int32_t k, uint64_t seed);
  * back (set_state it to leave the host generator where the reference would).  Bit-identical to
  * the host path, ~7x faster at config 3.                                                        */
 int plsa_init_factors_mt19937(plsa_ctx *ctx, int32_t k, uint32_t *state_io);
+/* The initialisation of plsa_refit (enstop/plsa.py:979-981): p_z_given_d = rng.rand(n, k), L1 row
+ * normalised in float64, cast to float32 -- drawn on the device from the same stream -- against the
+ * given fixed topics V [k, m] (host, float32).                                                      */
+int plsa_refit_init_mt19937(plsa_ctx *ctx, const float *V, int64_t m, int32_t k, uint32_t *state_io /*[625]*/);
 int plsa_copy_components_to_device(plsa_ctx *ctx, void *dst_device_km);
 
 /* ---- kernel-level operators ---------------------------------------------------------------------

@@ -711,6 +711,30 @@ def test_host_and_device_init_paths_give_identical_fits(amd, monkeypatch):
     np.testing.assert_array_equal(U1, U2); np.testing.assert_array_equal(V1, V2)
 
 
+def test_host_and_device_refit_init_paths_give_identical_vectors(amd, monkeypatch):
+    """plsa_refit's rng.rand(n, k) initialisation drawn on the device (plsa_refit_init_mt19937) equals
+    the host draws bit for bit, and leaves the generator where the host path leaves it."""
+    X = _corpus(3000, 700, 0.03, seed=9)
+    rs = np.random.RandomState(2)
+    topics = rs.rand(33, 700); topics /= topics.sum(1, keepdims=True)
+    topics = topics.astype(np.float32)
+    ones = np.ones(3000, np.float32)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ENSTOP_AMD_HOST_INIT", mode)
+        rng = np.random.RandomState(42)
+        rng.rand(17)                                           # start inside a 624-word block
+        out[mode] = (amd.plsa_refit(X, topics, ones, n_iter=7, n_iter_per_test=3, random_state=rng), rng.rand(4))
+    np.testing.assert_array_equal(out["0"][0], out["1"][0])
+    np.testing.assert_array_equal(out["0"][1], out["1"][1])
+    g = load_golden("refit_k6")                                # and against the reference's own refit
+    monkeypatch.setenv("ENSTOP_AMD_HOST_INIT", "0")
+    U = amd.plsa_refit(golden_csr(g), g["topics"], g["sw"], n_iter=int(g["n_iter"]),
+                       n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+                       random_state=np.random.RandomState(42))
+    close_factors(U, g["U"])
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """The boundary is a real C ABI: a gcc-built C program drives a fit through include/plsa_hip.h."""
     import os, subprocess
