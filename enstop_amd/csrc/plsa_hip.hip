@@ -591,7 +591,8 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, floa
 }
 
 // vocabulary-owned pass (no atomics): partial k-vectors per column item, then per-column sums -> Vacc
-int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh) {
+// parts: 1 = the column pass itself, 2 = the per-column sums of its partials, 3 = both
+int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int parts = 3) {
     CHK(ensure_csc(c));
     CHK(ensure(c, c->partial, sizeof(float) * (size_t)std::max<i64>(c->n_items, 1) * c->kp));
     CHK(dispatch_shape(c, [&](auto S) {
@@ -601,7 +602,7 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh) {
         const int grid2 = grid_for(c, c->m, 256 / LPN);
         const int *order = c->use_item_order ? c->item_order.as<int>() : nullptr;
         const int xcd_split = (c->xcd_split && grid >= 64) ? 1 : 0;
-        if (c->n_items > 0) {
+        if (c->n_items > 0 && (parts & 1)) {
             if (from_p) {
                 Scope s(c, "k_col_pass<P>");
                 hipLaunchKernelGGL((plsa::k_col_pass<Sh, true>), dim3(grid), dim3(256), 0, c->ls, order,
@@ -618,7 +619,7 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh) {
                                    p_base(c), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split);
             }
         }
-        {
+        if (parts & 2) {
             // heavy columns (one block each) and the rest share one launch
             Scope s(c, "k_col_reduce");
             hipLaunchKernelGGL((plsa::k_col_reduce<Sh>), dim3(grid2 + c->n_heavy), dim3(256),
@@ -1225,6 +1226,22 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
                 c->ls = c->stream2;
                 int rc = run_col_pass(c, false, d_sw, thresh);
+                if (!rc) rc = run_v_normalise(c);
+                c->ls = c->stream;
+                if (rc) return rc;
+                HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+                CHK(run_row_pass(c, false, pending, d_sw, thresh, nullptr, &blocks));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            } else if (c->overlap) {
+                // large problems: both passes saturate the memory system on their own (running them
+                // side by side is neutral at config 3, -6 % at config 5), but the short chain of
+                // column sums / normalisation after the column pass leaves the chip nearly idle --
+                // it runs on the second stream underneath the document pass
+                CHK(run_col_pass(c, false, d_sw, thresh, 1));
+                HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+                c->ls = c->stream2;
+                int rc = run_col_pass(c, false, d_sw, thresh, 2);
                 if (!rc) rc = run_v_normalise(c);
                 c->ls = c->stream;
                 if (rc) return rc;
