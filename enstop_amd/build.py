@@ -9,7 +9,11 @@ DEPS = [SRC, os.path.join(HERE, "csrc", "plsa_kernels.hpp"), os.path.join(HERE, 
         os.path.join(os.path.dirname(HERE), "include", "plsa_hip.h")]
 OUT = os.path.join(HERE, "libplsa_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: the SLP vectoriser pairs the per-topic multiplies/adds into v_pk_*_f32, which then
+# need register-pair shuffles and keep the DPP moves of the group sums from folding into their adds;
+# without it the fused document pass is 9 % faster (1.68 -> 1.52 ms at config 3), everything else equal
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared", "-Wall",
+         "-Wno-unused-function", "-Wno-pass-failed"]
 
 
 def build(force=False, verbose=True):
