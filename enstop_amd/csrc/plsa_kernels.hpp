@@ -129,12 +129,12 @@ __device__ __forceinline__ float products(const float4 (&u)[CH], const float4 (&
     for (int j = 0; j < CH; ++j) {
         float4 v;
         v.x = vt[j].x * u[j].x; v.y = vt[j].y * u[j].y; v.z = vt[j].z * u[j].z; v.w = vt[j].w * u[j].w;
-        if (WANT_UNTH) unth += hsum(v);
+        if (WANT_UNTH) unth = j ? unth + hsum(v) : hsum(v);
         keep[j].x = v.x > thresh ? v.x : 0.f;
         keep[j].y = v.y > thresh ? v.y : 0.f;
         keep[j].z = v.z > thresh ? v.z : 0.f;
         keep[j].w = v.w > thresh ? v.w : 0.f;
-        part += hsum(keep[j]);
+        part = j ? part + hsum(keep[j]) : hsum(keep[j]);   // no "0 + x" (it survives as an instruction: -0 + 0)
     }
     return part;
 }
