@@ -296,6 +296,14 @@ def get_engine(device=None):
     return eng
 
 
+def reset_engines():
+    """Close the cached per-device engines (tools / tests that change PLSA_* knobs, which a context
+    reads when it is created)."""
+    for eng in list(_engines.values()):
+        eng.close()
+    _engines.clear()
+
+
 def host_normalize_rows(a):
     """enstop/utils.py:8-41 normalize(a, axis=1), in place on a C-contiguous float64 array."""
     L = _lib.load()
