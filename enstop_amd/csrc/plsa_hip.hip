@@ -53,6 +53,7 @@ struct plsa_ctx {
     hipStream_t ls = nullptr;        // stream the kernel wrappers currently launch on
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = true;
+    double overlap_full_limit = 2e9;   // nnz * kp below which both passes run side by side (PLSA_OVERLAP_FULL_LIMIT)
     std::string err;
     hipDeviceProp_t prop;
     int grid_cap = 2048;
@@ -752,6 +753,7 @@ int plsa_create(int device, plsa_ctx **out) {
     }
     c->ls = c->stream;
     if (const char *s = getenv("PLSA_OVERLAP")) c->overlap = atoi(s) != 0;
+    if (const char *s = getenv("PLSA_OVERLAP_FULL_LIMIT")) c->overlap_full_limit = atof(s);
     if (const char *s = getenv("PLSA_ROW_ITEMS")) c->ritems_mode = atoi(s);
     if (const char *s = getenv("PLSA_ROW_SEG")) c->rseg = std::max(1, atoi(s));
     int mult = 128;  // blocks per CU a grid may hold: large (but bounded) grids measured best
@@ -1212,7 +1214,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
         bool stopped = false;
         for (int i = 0; i < n_iter; ++i) {
             int blocks = 0;
-            if (c->overlap && (double)c->nnz * c->kp < 2e9) {
+            if (c->overlap && (double)c->nnz * c->kp < c->overlap_full_limit) {
                 // small problems leave CUs idle inside each kernel (measured: config 1 0.50 -> 0.37 ms,
                 // config 2 0.43 -> 0.37 ms per iteration; neutral at config 3, -6 % at config 5):
                 // the document pass (VALU-heavy, gathers the small topic table) and the column chain
