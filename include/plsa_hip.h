@@ -156,7 +156,9 @@ int plsa_timing_get(plsa_ctx *ctx, const char *prefix, double *total_ms, int64_t
 int plsa_timing_report(plsa_ctx *ctx, char *buf, int64_t cap);
 /* achievable streaming bandwidth of this device, GB/s, over `bytes` of scratch HBM:
  * kind 0 = fill with non-temporal stores, 1 = fill with plain stores, 2 = copy (bytes read + bytes
- * written counted), 3 = read-only stream (small sizes probe the L2 / Infinity-Cache service rate).
+ * written counted), 3 = read-only stream (small sizes probe the L2 / Infinity-Cache service rate),
+ * 4 / 5 / 6 = non-temporal fill in the E-step's store order (each wave writes 16 / 4 / 64 consecutive
+ * 1-KB rows before moving on).
  * The practical ceiling the E-step's P write is compared with.   */
 int plsa_measure_stream_bandwidth(plsa_ctx *ctx, int64_t bytes, int32_t kind, int32_t reps, double *gbps);
 
