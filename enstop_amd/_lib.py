@@ -63,6 +63,7 @@ SIGNATURES = {
     "plsa_timing_get": (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "plsa_timing_report": (C.c_int, [_ctx, C.c_char_p, _i64]),
     "plsa_measure_stream_bandwidth": (C.c_int, [_ctx, _i64, _i32, _i32, C.POINTER(C.c_double)]),
+    "plsa_all_pairs_hellinger": (C.c_int, [_ctx, C.c_void_p, _i64, _i64, _f64p]),
     "plsa_host_normalize_rows": (None, [_f64p, _i64, _i64]),
     "plsa_host_mt19937_jump": (C.c_int, [C.POINTER(C.c_uint32), _i32]),
     "plsa_generate_synthetic": (C.c_int, [_ctx, _i64, _i64, _i64, C.c_double, C.c_uint64,

@@ -1488,6 +1488,46 @@ void plsa_host_normalize_rows(double *a, int64_t rows, int64_t cols) {
     }
 }
 
+// enstop/enstop_.py:258-266 (pairwise umap.distances.hellinger over the stacked topics) on the device
+int plsa_all_pairs_hellinger(plsa_ctx *c, const float *topics, int64_t t, int64_t m, double *D) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!topics || !D || t <= 0 || m <= 0 || t > 65536) return fail(c, "plsa_all_pairs_hellinger: bad arguments");
+    const int nt = (int)((t + plsa::HELL_TILE - 1) / plsa::HELL_TILE);
+    std::vector<int> ti, tj;
+    for (int i = 0; i < nt; ++i) for (int j = i; j < nt; ++j) { ti.push_back(i); tj.push_back(j); }
+    // enough vocabulary slices to fill the chip, each a multiple of the staging step
+    int slices = (int)std::max<i64>(1, std::min<i64>(64, (4 * (i64)c->prop.multiProcessorCount + (i64)ti.size() - 1) / (i64)ti.size()));
+    i64 slice = ((m + slices - 1) / slices + plsa::HELL_KSTEP - 1) / plsa::HELL_KSTEP * plsa::HELL_KSTEP;
+    slices = (int)((m + slice - 1) / slice);
+    DevBuf R, l1, part, dD, dt;
+    int rc = ensure(c, R, sizeof(float) * (size_t)t * m);
+    if (!rc) rc = ensure(c, l1, sizeof(double) * (size_t)t);
+    if (!rc) rc = ensure(c, part, sizeof(double) * (size_t)slices * t * t);
+    if (!rc) rc = ensure(c, dD, sizeof(double) * (size_t)t * t);
+    if (!rc) rc = ensure(c, dt, sizeof(int) * 2 * ti.size());
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpyAsync(R.p, topics, sizeof(float) * (size_t)t * m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dt.p, ti.data(), sizeof(int) * ti.size(), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dt.as<int>() + ti.size(), tj.data(), sizeof(int) * tj.size(), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(plsa::k_hell_prepare, dim3((unsigned)t), dim3(256), 0, c->stream, R.as<float>(), (int)t, (i64)m, l1.as<double>());
+            { Scope s(c, "k_hell_gram");
+              hipLaunchKernelGGL(plsa::k_hell_gram, dim3((unsigned)ti.size(), (unsigned)slices), dim3(256), 0, c->stream,
+                                 R.as<float>(), (int)t, (i64)m, slice, dt.as<int>(), dt.as<int>() + ti.size(), part.as<double>()); }
+            hipLaunchKernelGGL(plsa::k_hell_finish, dim3((unsigned)((t * t + 255) / 256)), dim3(256), 0, c->stream,
+                               part.as<double>(), slices, (int)t, l1.as<double>(), dD.as<double>());
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(D, dD.p, sizeof(double) * (size_t)t * t, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    release(R); release(l1); release(part); release(dD); release(dt);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(c, "plsa_all_pairs_hellinger: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int plsa_host_mt19937_jump(uint32_t *key, int32_t log2_blocks) {
     if (!key || log2_blocks < 0 || log2_blocks > 40) return 1;
     uint32_t g[624];

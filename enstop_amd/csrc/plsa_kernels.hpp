@@ -1211,4 +1211,104 @@ __global__ __launch_bounds__(256) void k_probe_copy(const float *__restrict__ a,
         st4(b + i * 4, ld4(a + i * 4));
 }
 
+// ------------------------------------------------------------------------------------------------
+// All-pairs Hellinger distance between topic vectors (the precomputed metric of the ensemble's topic
+// combination, enstop/enstop_.py:258-266):  D_ij = sqrt(1 - sum_w sqrt(p_i[w] p_j[w]) / sqrt(|p_i|_1 |p_j|_1)).
+//   k_hell_prepare : per topic, |p|_1 in float64 and sqrt() in place
+//   k_hell_gram    : 64 x 64 tile of R R^T over one slice of the vocabulary (upper-triangular tiles
+//                    only); float32 products, flushed into float64 every 256 words
+//   k_hell_finish  : adds the slice partials in fixed order, forms the distance
+// A plain dense contraction on the vector ALUs: t = n_runs * k is a few hundred, the whole job is tens
+// of GFLOP -- milliseconds -- so no matrix-core path is warranted.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hell_prepare(float *__restrict__ R, int t, i64 m, double *__restrict__ l1) {
+    __shared__ double red[256];
+    const int i = blockIdx.x;
+    float *row = R + (i64)i * m;
+    double s = 0.0;
+    for (i64 w = threadIdx.x; w < m; w += 256) {
+        const float p = row[w];
+        s += (double)p;
+        row[w] = sqrtf(fmaxf(p, 0.f));
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) l1[i] = red[0];
+}
+
+constexpr int HELL_TILE = 64;      // rows / columns of the output tile
+constexpr int HELL_KSTEP = 32;     // words staged per step
+__global__ __launch_bounds__(256) void k_hell_gram(const float *__restrict__ R, int t, i64 m, i64 slice,
+                                                   const int *__restrict__ tile_i, const int *__restrict__ tile_j,
+                                                   double *__restrict__ partial /*[slices][t][t]*/) {
+    __shared__ float sa[HELL_KSTEP][HELL_TILE + 1], sb[HELL_KSTEP][HELL_TILE + 1];
+    const int bi = tile_i[blockIdx.x] * HELL_TILE, bj = tile_j[blockIdx.x] * HELL_TILE;
+    const i64 w0 = (i64)blockIdx.y * slice, w1 = min(m, w0 + slice);
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;          // 16 x 16 threads, 4 x 4 outputs each
+    double acc[4][4];
+    float facc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { acc[a][b] = 0.0; facc[a][b] = 0.f; }
+    int since_flush = 0;
+    for (i64 w = w0; w < w1; w += HELL_KSTEP) {
+        // stage 64 rows x 32 words of both operands (each row segment is 128 contiguous bytes)
+        for (int e = threadIdx.x; e < HELL_TILE * HELL_KSTEP; e += 256) {
+            const int r = e / HELL_KSTEP, kk = e % HELL_KSTEP;
+            const i64 ww = w + kk;
+            sa[kk][r] = (bi + r < t && ww < w1) ? R[(i64)(bi + r) * m + ww] : 0.f;
+            sb[kk][r] = (bj + r < t && ww < w1) ? R[(i64)(bj + r) * m + ww] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < HELL_KSTEP; ++kk) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { av[a] = sa[kk][ty * 4 + a]; bv[a] = sb[kk][tx * 4 + a]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) facc[a][b] += av[a] * bv[b];
+        }
+        __syncthreads();
+        since_flush += HELL_KSTEP;
+        if (since_flush >= 256) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { acc[a][b] += (double)facc[a][b]; facc[a][b] = 0.f; }
+            since_flush = 0;
+        }
+    }
+    double *out = partial + (i64)blockIdx.y * t * t;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = bi + ty * 4 + a, j = bj + tx * 4 + b;
+            if (i < t && j < t) out[(i64)i * t + j] = acc[a][b] + (double)facc[a][b];
+        }
+}
+
+__global__ __launch_bounds__(256) void k_hell_finish(const double *__restrict__ partial, int slices, int t,
+                                                     const double *__restrict__ l1, double *__restrict__ D) {
+    const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (i64)t * t) return;
+    const int i = (int)(e / t), j = (int)(e % t);
+    const int a = min(i, j), b = max(i, j);                // only the upper triangle was computed
+    double g = 0.0;
+    for (int s = 0; s < slices; ++s) g += partial[(i64)s * t * t + (i64)a * t + b];
+    const double li = l1[i], lj = l1[j];
+    double d;
+    if (i == j || (li == 0.0 && lj == 0.0)) d = 0.0;
+    else if (li == 0.0 || lj == 0.0) d = 1.0;
+    else d = sqrt(fmax(1.0 - g / sqrt(li * lj), 0.0));
+    D[e] = d;
+}
+
 }  // namespace plsa

@@ -247,6 +247,16 @@ class Engine:
     def accumulator_set(self, a):
         self._ok(self._L.plsa_accumulator_set(self._h, _f32(a)))
 
+    def all_pairs_hellinger(self, topics):
+        """[t, t] float64 Hellinger distances between the rows of `topics` [t, m] (enstop_.py:258-266)."""
+        T = _f32(topics)
+        if T.ndim != 2:
+            raise ValueError("topics must be a 2-D array")
+        t, m = T.shape
+        D = np.empty((t, t), np.float64)
+        self._ok(self._L.plsa_all_pairs_hellinger(self._h, ptr(T), t, m, D))
+        return D
+
     def placement_info(self):
         n, a, b = C.c_int32(0), C.c_double(0.0), C.c_double(0.0)
         self._ok(self._L.plsa_placement_info(self._h, C.byref(n), C.byref(a), C.byref(b)))

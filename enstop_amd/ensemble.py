@@ -1,8 +1,9 @@
 """EnsembleTopics on top of the GPU ensemble path (a "next" row).
 
-The expensive stages -- the bootstrapped pLSA fits (`ensemble_of_topics`) and the final refit of the
-document vectors (`plsa_refit`) -- run on the MI355X engine.  The topic *combination* stage in
-between works on a few hundred topic vectors and stays on the host.
+The expensive stages -- the bootstrapped pLSA fits (`ensemble_of_topics`), the all-pairs Hellinger
+distance matrix of the stacked topics (`plsa_all_pairs_hellinger`) and the final refit of the document
+vectors (`plsa_refit`) -- run on the MI355X engine.  The clustering of the few hundred topic vectors
+(HDBSCAN) and the cluster representatives stay on the host.
 
 Parity status of this module: **unpinned**.  The reference clusters with the third-party `hdbscan`
 and `umap` packages (enstop/enstop_.py:234-414), neither of which is available in the build image, so
@@ -79,8 +80,11 @@ def generate_combined_topics_kl(all_topics, min_samples=5, min_cluster_size=5):
     return _cluster_representatives(np.asarray(all_topics), labels)
 
 
-def generate_combined_topics_hellinger(all_topics, min_samples=5, min_cluster_size=5):
-    D = all_pairs_hellinger_distance(all_topics)
+def generate_combined_topics_hellinger(all_topics, min_samples=5, min_cluster_size=5, distance_fn=None):
+    """`distance_fn`: all-pairs Hellinger implementation; `ensemble_fit` passes the engine's device
+    kernel (`Engine.all_pairs_hellinger`: 32 x 20 topics over 174 k words take 0.8 s in NumPy float64,
+    milliseconds on the GPU), standalone calls on host arrays use the NumPy definition above."""
+    D = (distance_fn or all_pairs_hellinger_distance)(all_topics)
     labels = _hdbscan_precomputed(D, min_samples, min_cluster_size).labels_
     return _cluster_representatives(np.asarray(all_topics), labels)
 
@@ -124,7 +128,12 @@ def ensemble_fit(X, estimated_n_topics=10, model="plsa", init="random", min_samp
                                     init=init, n_iter=n_iter, n_iter_per_test=n_iter_per_test,
                                     tolerance=tolerance, e_step_thresh=e_step_thresh, bootstrap=bootstrap,
                                     random_state=random_state, device=device)
-    stable_topics = _topic_combiner[topic_combination](all_topics, min_samples, min_cluster_size)
+    if topic_combination == "hellinger":
+        from .engine import get_engine
+        stable_topics = generate_combined_topics_hellinger(all_topics, min_samples, min_cluster_size,
+                                                           distance_fn=get_engine(device).all_pairs_hellinger)
+    else:
+        stable_topics = _topic_combiner[topic_combination](all_topics, min_samples, min_cluster_size)
     if stable_topics.shape[0] == 0:
         raise ValueError("topic combination found no stable topic cluster; lower min_samples / "
                          "min_cluster_size or raise n_starts")

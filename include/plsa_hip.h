@@ -162,6 +162,12 @@ int plsa_timing_report(plsa_ctx *ctx, char *buf, int64_t cap);
  * The practical ceiling the E-step's P write is compared with.   */
 int plsa_measure_stream_bandwidth(plsa_ctx *ctx, int64_t bytes, int32_t kind, int32_t reps, double *gbps);
 
+/* ---- topic combination --------------------------------------------------
+ * plsa_all_pairs_hellinger <- enstop/enstop_.py:258-266: the all-pairs Hellinger distance matrix of the
+ *   stacked ensemble topics (umap.distances.hellinger's definition), topics [t, m] float32 on the host,
+ *   D [t, t] float64 on the host.  Rows with zero mass: distance 1 to any other row, 0 to each other.  */
+int plsa_all_pairs_hellinger(plsa_ctx *ctx, const float *topics, int64_t t, int64_t m, double *D);
+
 /* ---- host helper ---------------------------------------------------------------------------------
  * plsa_host_normalize_rows <- enstop/utils.py:8-41 normalize(ndarray, axis=1): float64, in place,
  *   sequential marginal, used by the factor initialisation (enstop/plsa.py:510-511, 980).          */

@@ -735,6 +735,31 @@ def test_host_and_device_refit_init_paths_give_identical_vectors(amd, monkeypatc
     close_factors(U, g["U"])
 
 
+def test_device_all_pairs_hellinger_matches_definition(amd):
+    """plsa_all_pairs_hellinger against the float64 definition (umap.distances.hellinger pairwise,
+    enstop_.py:258-266), including zero-mass rows, identical rows and ragged sizes."""
+    from enstop_amd.ensemble import all_pairs_hellinger_distance
+    rs = np.random.RandomState(4)
+    with amd.Engine() as eng:
+        for t, m in ((5, 7), (64, 1000), (130, 4097), (321, 25000)):
+            T = rs.rand(t, m).astype(np.float32) ** 3
+            T /= T.sum(1, keepdims=True)
+            T[1] = T[0]                                            # identical topics: distance 0
+            if t > 4:
+                T[3] = 0.0                                         # a topic without mass
+                T[4, : m // 2] = 0.0
+            D = eng.all_pairs_hellinger(T)
+            want = all_pairs_hellinger_distance(T.astype(np.float64))
+            assert D.shape == (t, t) and D.dtype == np.float64
+            np.testing.assert_array_equal(D, D.T)
+            np.testing.assert_array_equal(np.diag(D), 0.0)
+            # sqrt(1 - x) amplifies the float32 rounding of x near x = 1 (identical topics)
+            np.testing.assert_allclose(D ** 2, want ** 2, atol=2e-6)
+            np.testing.assert_allclose(D, want, atol=2e-3)
+            far = want > 0.05
+            np.testing.assert_allclose(D[far], want[far], rtol=2e-5)
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """The boundary is a real C ABI: a gcc-built C program drives a fit through include/plsa_hip.h."""
     import os, subprocess
