@@ -660,6 +660,55 @@ def test_sharded_fit_over_rccl_single_rank(tmp_path):
     assert out.returncode == 0 and "sharded-rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_sharded_fit_two_ranks_sharing_one_gpu(tmp_path):
+    """Two torch.distributed ranks (gloo: RCCL refuses two ranks on one device), each owning half of the
+    documents on its own engine of the same GPU: the real multi-process control flow of the
+    doc-sharded fit -- row ranges by rank, host all-reduce of the P(w|z) accumulator, scalar
+    all-reduce of the likelihood, assembly of P(z|d) on every rank -- against the single-engine fit,
+    including the ensemble gather of `ensemble_of_topics` across the two ranks."""
+    import os, subprocess, sys, textwrap
+    from conftest import ROOT
+    script = tmp_path / "w2.py"
+    script.write_text(textwrap.dedent('''
+        import os, sys
+        import numpy as np, scipy.sparse as sp
+        import torch, torch.distributed as dist
+        sys.path.insert(0, os.environ["REPO_ROOT"])
+        rank = int(os.environ["RANK"])
+        dist.init_process_group("gloo", rank=rank, world_size=2)
+        import enstop_amd
+        rs = np.random.RandomState(0)
+        X = sp.random(2500, 1500, density=0.02, format="csr", random_state=rs, dtype=np.float32)
+        X.data = np.ceil(X.data * 5).astype(np.float32)
+        sw = (0.5 + rs.rand(2500)).astype(np.float32)
+        kw = dict(n_iter=9, n_iter_per_test=2, tolerance=1e-4, random_state=1)
+        U2, V2, i2 = enstop_amd.sharded_plsa_fit(X, 20, sw, device=0, return_info=True, **kw)
+        U1, V1, i1 = enstop_amd.plsa_fit(X, 20, sw, device=0, return_info=True, **kw)
+        assert i1["n_iter"] == i2["n_iter"], (i1["n_iter"], i2["n_iter"])
+        np.testing.assert_allclose(i2["log_likelihood_trace"], i1["log_likelihood_trace"], rtol=1e-6)
+        assert np.abs(U1 - U2).max() <= 2e-5 * U1.max() and np.abs(V1 - V2).max() <= 2e-5 * V1.max()
+        T = enstop_amd.ensemble_of_topics(X, 6, n_runs=5, n_iter=5, random_state=3, device=0)
+        ref = [enstop_amd.plsa_topics(X, 6, n_iter=5, random_state=np.random.RandomState(3 + r), device=0) for r in range(5)]
+        np.testing.assert_array_equal(T, np.vstack(ref))
+        dist.barrier()
+        dist.destroy_process_group()
+        print("rank %d two-rank ok" % rank)
+    '''))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29588", REPO_ROOT=ROOT, RANK=str(r), WORLD_SIZE="2",
+                   LOCAL_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for r, p_ in enumerate(procs):
+        try:
+            out, err = p_.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p_.returncode == 0 and "two-rank ok" in out, out[-2000:] + err[-3000:]
+
+
 @pytest.mark.parametrize("n_m_k", [(40, 50, 6), (333, 1000, 20), (5000, 3000, 64), (17, 9, 33)])
 def test_device_mt19937_init_is_bit_identical_to_numpy(amd, n_m_k):
     """plsa_init(random) evaluated on the GPU from the RandomState's own MT19937 state: identical
