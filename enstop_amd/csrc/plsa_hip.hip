@@ -1497,6 +1497,7 @@ int plsa_all_pairs_hellinger(plsa_ctx *c, const float *topics, int64_t t, int64_
     for (int i = 0; i < nt; ++i) for (int j = i; j < nt; ++j) { ti.push_back(i); tj.push_back(j); }
     // enough vocabulary slices to fill the chip, each a multiple of the staging step
     int slices = (int)std::max<i64>(1, std::min<i64>(64, (4 * (i64)c->prop.multiProcessorCount + (i64)ti.size() - 1) / (i64)ti.size()));
+    while (slices > 1 && (double)slices * (double)t * (double)t * 8.0 > 4e9) --slices;   // bound the partial buffer
     i64 slice = ((m + slices - 1) / slices + plsa::HELL_KSTEP - 1) / plsa::HELL_KSTEP * plsa::HELL_KSTEP;
     slices = (int)((m + slice - 1) / slice);
     DevBuf R, l1, part, dD, dt;
