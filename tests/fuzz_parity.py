@@ -3,7 +3,7 @@
 columns, thresholds, sample weights, refit -- under several structure knobs (E-step traversal, row
 items, column item length), each against the pinned CPU oracle.  A superset of
 tests/test_hip_parity.py::test_randomised_shapes_vs_oracle, kept out of the suite for its run time.
-usage: python tools/fuzz_parity.py [cases] [seed]"""
+usage: python tests/fuzz_parity.py [cases] [seed]"""
 import os
 import sys
 import time
