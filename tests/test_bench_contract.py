@@ -1,0 +1,62 @@
+"""bench.py's static contract, checked without a GPU: the algorithmic-byte formulas reproduce the figures
+SURVEY.md section 8d quotes, the config table is BASELINE.json's, the argument defaults are the ones the
+driver relies on, and the module can be imported without touching the oracle or the device."""
+import ast
+import importlib.util
+import json
+import os
+
+from conftest import ROOT
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                      # defines functions only; main() is guarded
+    return mod
+
+
+def test_algorithmic_bytes_match_survey_section_8d():
+    b = _bench()
+    n, m, nnz, k = 1_000_000, 100_000, 100_000_000, 64         # config 3 at the nominal nnz
+    gb = lambda kind: b.algorithmic_bytes(kind, n, m, nnz, k) / 1e9
+    assert abs(gb("e_step") - 26.29) < 0.01                   # "B_E 26.29 GB (3.29 ms at 8 TB/s)"
+    assert abs(gb("m_step_p") - 26.69) < 0.01                 # "B_M 26.69 GB"
+    assert abs(gb("fused") - 1.37) < 0.01                     # "B_EM 1.37 GB"
+    n, m, nnz, k = 100_000, 50_000, 10_000_000, 32            # config 2
+    assert abs(b.algorithmic_bytes("e_step", n, m, nnz, k) / 1e9 - 1.34) < 0.005
+    assert abs(b.algorithmic_bytes("fused", n, m, nnz, k) / 1e9 - 0.119) < 0.001
+    n, m, nnz, k = 5_000_000, 200_000, 500_000_000, 128       # config 5
+    assert abs(b.algorithmic_bytes("e_step", n, m, nnz, k) / 1e9 - 260.7) < 0.1
+    assert b.HBM_PEAK_GBS == 8000.0
+    assert set(b.KERNEL_KIND.values()) <= {"e_step", "m_step_p", "loglik", "fused", "fused_col"}
+
+
+def test_config_table_is_baseline_json():
+    b = _bench()
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert b.CONFIGS[2]["n"] == 100_000 and b.CONFIGS[2]["m"] == 50_000 and b.CONFIGS[2]["nnz"] == 10_000_000 and b.CONFIGS[2]["k"] == 32
+    assert b.CONFIGS[3]["n"] == 1_000_000 and b.CONFIGS[3]["m"] == 100_000 and b.CONFIGS[3]["nnz"] == 100_000_000 and b.CONFIGS[3]["k"] == 64
+    assert b.CONFIGS[5]["n"] == 5_000_000 and b.CONFIGS[5]["m"] == 200_000 and b.CONFIGS[5]["nnz"] == 500_000_000 and b.CONFIGS[5]["k"] == 128
+    assert "100k docs" in base["configs"][1] and "1M docs" in base["configs"][2] and "5M docs" in base["configs"][4]
+    assert base["metric"].startswith("EM iterations/sec")
+
+
+def test_defaults_and_oracle_usage():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    defaults = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Call) and getattr(node.func, "attr", "") == "add_argument" and node.args:
+            name = node.args[0].value if isinstance(node.args[0], ast.Constant) else None
+            for kw in node.keywords:
+                if kw.arg == "default" and isinstance(kw.value, ast.Constant):
+                    defaults[name] = kw.value.value
+    assert defaults["--gpus"] == 1 and defaults["--steps"] == 50 and defaults["--warmup"] == 5 and defaults["--config"] == 3
+    # the oracle is only ever touched inside cpu_baseline()
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "cpu_baseline")
+    inside = ast.get_source_segment(src, fn)
+    assert "oracle" in inside
+    outside = src.replace(inside, "")
+    code_lines = [l for l in outside.splitlines() if "import" in l and "oracle" in l]
+    assert not code_lines, code_lines
