@@ -347,6 +347,11 @@ class PLSA(_TopicMetricsMixin, BaseEstimator, TransformerMixin):
         from .engine import default_flags
         return default_flags()
 
+    def _fit_factors(self, X, sample_weight):
+        return plsa_fit(X, self.n_components, sample_weight, self.init, self.n_iter, self.n_iter_per_test,
+                        self.tolerance, self.e_step_thresh, self.random_state, device=self.device,
+                        flags=self._flags(), return_info=True)
+
     def fit(self, X, y=None, sample_weight=None):
         self.fit_transform(X, sample_weight=sample_weight)
         return self
@@ -364,10 +369,7 @@ class PLSA(_TopicMetricsMixin, BaseEstimator, TransformerMixin):
         all_good = bool(np.all(good_rows))
         data_for_fitting = X if all_good else X[good_rows]
         weights = sample_weight if all_good else sample_weight[good_rows]
-        U, V, info = plsa_fit(data_for_fitting, self.n_components, weights, self.init, self.n_iter,
-                              self.n_iter_per_test, self.tolerance, self.e_step_thresh,
-                              self.random_state, device=self.device, flags=self._flags(),
-                              return_info=True)
+        U, V, info = self._fit_factors(data_for_fitting, weights)
         if all_good:
             self.embedding_ = U
         else:                                    # float64 zeros, like plsa.py:1174
@@ -429,3 +431,35 @@ class BlockParallelPLSA(PLSA):
                          random_state=random_state, device=device)
         self.n_row_blocks = n_row_blocks
         self.n_col_blocks = n_col_blocks
+
+
+class GPUPLSA(BlockParallelPLSA):
+    """Drop-in name for enstop.cuda_plsa.GPUPLSA (cuda_plsa.py:356-470), the reference's own accelerator
+    estimator (numba-CUDA kernels over n_row_blocks x n_col_blocks tiles).  Nothing of that file is
+    ported: this IS the MI355X engine under the same constructor, so code written against `GPUPLSA`
+    keeps running; the tiling parameters are accepted and ignored."""
+
+
+class DistributedPLSA(BlockParallelPLSA):
+    """Drop-in name for enstop.distributed_plsa.DistributedPLSA (distributed_plsa.py:374-460).  The
+    reference takes a dask array and sums per-tile partial factors with a dask graph
+    (distributed_plsa.py:99-131).  Here the distribution unit is the GPU: when torch.distributed is
+    initialised with more than one rank (one process per GPU), every rank passes the same X and the
+    documents are sharded over the ranks -- one all-reduce of the P(w|z) accumulator per EM iteration
+    (`sharded_plsa_fit`) -- and every rank receives the full result; in a single
+    process it is `PLSA`.  Dask arrays are materialised with `.compute()` first."""
+
+    def fit_transform(self, X, y=None, sample_weight=None):
+        if hasattr(X, "compute") and not issparse(X):
+            X = X.compute()
+        return super().fit_transform(X, y, sample_weight=sample_weight)
+
+    def _fit_factors(self, X, sample_weight):
+        from . import distributed
+        _, world = distributed.rank_world()
+        if world <= 1:
+            return super()._fit_factors(X, sample_weight)
+        from .sharded import sharded_plsa_fit
+        return sharded_plsa_fit(X, self.n_components, sample_weight, self.init, self.n_iter,
+                                self.n_iter_per_test, self.tolerance, self.e_step_thresh, self.random_state,
+                                device=self.device, return_info=True)

@@ -442,7 +442,8 @@ def test_api_compatible_class_names(amd):
     shape = tuple(int(s) for s in g["shape"])
     X = sp.csr_matrix((g["data"], g["indices"], g["indptr"]), shape=shape)
     kw = dict(n_components=int(g["k"]), n_iter=30, n_iter_per_test=10, tolerance=0.0, random_state=11)
-    for cls, extra in ((amd.StreamedPLSA, dict(block_size=1024)), (amd.BlockParallelPLSA, dict(n_row_blocks=4, n_col_blocks=2))):
+    for cls, extra in ((amd.StreamedPLSA, dict(block_size=1024)), (amd.BlockParallelPLSA, dict(n_row_blocks=4, n_col_blocks=2)),
+                       (amd.GPUPLSA, dict(n_row_blocks=2, n_col_blocks=2)), (amd.DistributedPLSA, dict(n_row_blocks=8, n_col_blocks=8))):
         model = cls(**kw, **extra).fit(X)
         close_factors(model.embedding_, g["embedding"])
         close_factors(model.components_, g["components"])
@@ -687,6 +688,13 @@ def test_sharded_fit_two_ranks_sharing_one_gpu(tmp_path):
         assert i1["n_iter"] == i2["n_iter"], (i1["n_iter"], i2["n_iter"])
         np.testing.assert_allclose(i2["log_likelihood_trace"], i1["log_likelihood_trace"], rtol=1e-6)
         assert np.abs(U1 - U2).max() <= 2e-5 * U1.max() and np.abs(V1 - V2).max() <= 2e-5 * V1.max()
+        Xi = X.astype(np.int64)
+        est = dict(n_components=12, n_iter=6, n_iter_per_test=2, tolerance=0.0, random_state=4, device=0)
+        d = enstop_amd.DistributedPLSA(**est).fit(Xi)            # documents sharded over the two ranks
+        s_ = enstop_amd.PLSA(**est).fit(Xi)
+        assert d.n_iter_ == s_.n_iter_
+        assert np.abs(d.embedding_ - s_.embedding_).max() <= 2e-5 * s_.embedding_.max()
+        assert np.abs(d.components_ - s_.components_).max() <= 2e-5 * s_.components_.max()
         T = enstop_amd.ensemble_of_topics(X, 6, n_runs=5, n_iter=5, random_state=3, device=0)
         ref = [enstop_amd.plsa_topics(X, 6, n_iter=5, random_state=np.random.RandomState(3 + r), device=0) for r in range(5)]
         np.testing.assert_array_equal(T, np.vstack(ref))
