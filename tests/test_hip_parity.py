@@ -817,6 +817,26 @@ def test_device_all_pairs_hellinger_matches_definition(amd):
             np.testing.assert_allclose(D[far], want[far], rtol=2e-5)
 
 
+def test_integration_md_ctypes_stub_runs(amd):
+    """The reference-side binding printed in INTEGRATION.md section 2 is real code: executed here (with
+    the reference's plsa_init swapped for the package's identical one and the library path made absolute)
+    it reproduces the reference's own fit."""
+    import os, re
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n# enstop/hip_plsa.py.*?```", text, re.S).group(0)
+    code = block[len("```python\n"):-3]
+    code = code.replace("from enstop.plsa import plsa_init", "from enstop_amd.plsa import plsa_init")
+    code = code.replace('C.CDLL("libplsa_hip.so")', 'C.CDLL(%r)' % os.path.join(ROOT, "enstop_amd", "libplsa_hip.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    assert ns["is_available"]()
+    g = load_golden("fit_k8_tol0")
+    U, V = ns["plsa_fit"](golden_csr(g), int(g["k"]), n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]),
+                          tolerance=float(g["tol"]), e_step_thresh=float(g["thresh"]), random_state=int(g["fit_seed"]))
+    close_factors(U, g["U"]); close_factors(V, g["V"])
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """The boundary is a real C ABI: a gcc-built C program drives a fit through include/plsa_hip.h."""
     import os, subprocess
