@@ -337,10 +337,12 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):        # HBM bytes per launch from committed rocprofv3 --pmc passes
         try:
-            rec = json.load(open(pmc)).get("config%d" % args.config, {}).get("k_e_step")
-            if rec:
-                out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = rec["source"]
+            table = json.load(open(pmc)).get("config%d" % args.config, {})
+            for key in ("roofline", "roofline_dominant_fused"):
+                rec = table.get(out[key]["kernel"])
+                if rec:
+                    out[key]["traffic"] = rec["hbm_bytes_per_launch"]
+                    out[key]["traffic_source"] = rec["source"]
         except Exception:
             pass
     if rank == 0:
