@@ -83,7 +83,9 @@ def main():
                 worst["ll"] = max(worst["ll"], e_ll)
             # a threshold as large as 1e-6 sits inside the range of the products P(w|z) P(z|d): entries flip
             # in and out on last-bit differences (in the reference itself, between thread schedules)
-            tol = 1e-4 if thresh <= 1e-16 and X.nnz < 50_000 else 1e-3
+            # (each flip moves one responsibility by ~thresh / norm: with k = 200-300 topics and a handful of
+            # non-zeros per document that is up to 5e-3 of the largest P(z|d) entry after a few iterations)
+            tol = 1e-4 if thresh <= 1e-16 and X.nnz < 50_000 else (1e-3 if thresh <= 1e-16 else 2e-2)
             if eu > tol or ev > tol:
                 print("FACTOR MISMATCH %.2e %.2e" % (eu, ev), msg); bad += 1
         if k <= 64 and case % 4 == 0:                          # refit against the oracle
