@@ -1190,10 +1190,16 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
     CHK(upload_sw(c, sw, &d_sw));
     int nll = 0, iters = 0;
     double ll = 0.0;
-    CHK(run_loglik(c, d_sw, &ll));                                   // plsa.py:591
-    float prev = (float)ll;
-    if (ll_trace) ll_trace[nll] = prev;
-    nll++;
+    float prev = 0.f;
+    // plsa.py:591: the likelihood of the initial factors.  The fused schedule gets it for free from the
+    // first iteration's document pass (which reads exactly those factors) instead of a separate launch.
+    bool first_ll_in_pass = fused && n_iter > 0;
+    if (!first_ll_in_pass) {
+        CHK(run_loglik(c, d_sw, &ll));
+        prev = (float)ll;
+        if (ll_trace) ll_trace[nll] = prev;
+        nll++;
+    }
 
     if (!fused) {
         for (int i = 0; i < n_iter; ++i) {
@@ -1232,7 +1238,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 c->ls = c->stream;
                 if (rc) return rc;
                 HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
-                CHK(run_row_pass(c, false, pending, d_sw, thresh, nullptr, &blocks));
+                CHK(run_row_pass(c, false, pending || first_ll_in_pass, d_sw, thresh, nullptr, &blocks));
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
             } else if (c->overlap) {
                 // large problems: both passes saturate the memory system on their own (running them
@@ -1248,14 +1254,20 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 c->ls = c->stream;
                 if (rc) return rc;
                 HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
-                CHK(run_row_pass(c, false, pending, d_sw, thresh, nullptr, &blocks));
+                CHK(run_row_pass(c, false, pending || first_ll_in_pass, d_sw, thresh, nullptr, &blocks));
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
             } else {
-                CHK(run_row_pass(c, false, pending, d_sw, thresh, nullptr, &blocks));
+                CHK(run_row_pass(c, false, pending || first_ll_in_pass, d_sw, thresh, nullptr, &blocks));
                 CHK(run_col_pass(c, false, d_sw, thresh));
                 CHK(run_v_normalise(c));
             }
-            if (pending) {
+            if (first_ll_in_pass) {
+                CHK(finish_ll(c, blocks, &ll));
+                prev = (float)ll;
+                if (ll_trace) ll_trace[nll] = prev;
+                nll++;
+                first_ll_in_pass = false;
+            } else if (pending) {
                 CHK(finish_ll(c, blocks, &ll));
                 const float cur = (float)ll;
                 if (ll_trace) ll_trace[nll] = cur;
