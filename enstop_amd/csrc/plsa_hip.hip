@@ -1301,10 +1301,14 @@ int plsa_refit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_
     CHK(upload_sw(c, sw, &d_sw));
     int nll = 0, iters = 0;
     double ll = 0.0;
-    CHK(run_loglik(c, d_sw, &ll));
-    float prev = (float)ll;
-    if (ll_trace) ll_trace[nll] = prev;
-    nll++;
+    float prev = 0.f;
+    bool first_ll_in_pass = fused && n_iter > 0;       // as in plsa_fit: the initial likelihood rides on pass 0
+    if (!first_ll_in_pass) {
+        CHK(run_loglik(c, d_sw, &ll));
+        prev = (float)ll;
+        if (ll_trace) ll_trace[nll] = prev;
+        nll++;
+    }
     // plsa.py:913-918: the test only acts on a positive log-likelihood
     auto refit_stop = [&](float cur) {
         if (cur > 0.0f) {
@@ -1334,8 +1338,14 @@ int plsa_refit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_
             int blocks = 0;
             // the refit M-step ignores sample weights for P(z|d) (plsa.py:806-809); they only enter
             // the log-likelihood, which this pass accumulates when a test is pending
-            CHK(run_row_pass(c, false, pending, d_sw, thresh, nullptr, &blocks));
-            if (pending) {
+            CHK(run_row_pass(c, false, pending || first_ll_in_pass, d_sw, thresh, nullptr, &blocks));
+            if (first_ll_in_pass) {
+                CHK(finish_ll(c, blocks, &ll));
+                prev = (float)ll;
+                if (ll_trace) ll_trace[nll] = prev;
+                nll++;
+                first_ll_in_pass = false;
+            } else if (pending) {
                 CHK(finish_ll(c, blocks, &ll));
                 const float cur = (float)ll;
                 if (ll_trace) ll_trace[nll] = cur;
