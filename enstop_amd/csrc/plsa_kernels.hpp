@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_row_pass(const int *__restr
                     if (FROM_P) load_row<S, false>(P + (i64)min(jb + s0 + q, j1 - 1) * kp, li, kp, a[q]);
                     else load_row<S, false>(Vt + (i64)w * kp, li, kp, a[q]);
                 }
+                float my_dot = 1.f, my_x = 0.f;   // WANT_LL: lane q of the group takes non-zero q of the batch
 #pragma unroll
                 for (int q = 0; q < UNR; ++q) {
                     float4 pz[CH];
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_row_pass(const int *__restr
                         const float norm = group_sum<LPN>(part);
                         if (WANT_LL) {
                             const float dot = group_sum<LPN>(unth);
-                            if (li == 0 && s0 + q < cnt) ll += (double)(x[q] * logf(dot) * swd);
+                            if (li == q && s0 + q < cnt) { my_dot = dot; my_x = x[q]; }
                         }
                         x[q] *= inv_norm(norm);   // s = x * (v / norm) evaluated as v * (x / norm)
                     }
@@ -357,6 +358,9 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_row_pass(const int *__restr
                         acc[j].z += x[q] * pz[j].z; acc[j].w += x[q] * pz[j].w;
                     }
                 }
+                // x * log(sum_z P(w|z) P(z|d)) * sample_weight, plsa.py:380-383: one logf sequence per batch
+                // (lanes 0 .. UNR-1 each hold one non-zero; padded slots keep x = 0, dot = 1 -> exactly 0)
+                if (WANT_LL && !FROM_P && li < UNR) ll += (double)(my_x * logf(my_dot) * swd);
             }
         }
         if (items) {
