@@ -14,6 +14,9 @@ LIB_PATH = os.environ.get("ENSTOP_AMD_LIB", os.path.join(_HERE, "libplsa_hip.so"
 
 PLSA_FUSED = 1
 PLSA_TRACE_LL = 4
+PLSA_SW_LL_ONLY = 8
+PLSA_STOP_NO_ZERO_ARM = 16
+PLSA_GRAPH = 32
 
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
@@ -64,6 +67,8 @@ SIGNATURES = {
     "plsa_timing_report": (C.c_int, [_ctx, C.c_char_p, _i64]),
     "plsa_measure_stream_bandwidth": (C.c_int, [_ctx, _i64, _i32, _i32, C.POINTER(C.c_double)]),
     "plsa_all_pairs_hellinger": (C.c_int, [_ctx, C.c_void_p, _i64, _i64, _f64p]),
+    "plsa_all_pairs_kl": (C.c_int, [_ctx, C.c_void_p, _i64, _i64, _f64p]),
+    "plsa_cluster_representatives": (C.c_int, [_ctx, C.c_void_p, _i64, _i64, _i32p, _vp, _i32, _f32p]),
     "plsa_host_normalize_rows": (None, [_f64p, _i64, _i64]),
     "plsa_host_mt19937_jump": (C.c_int, [C.POINTER(C.c_uint32), _i32]),
     "plsa_generate_synthetic": (C.c_int, [_ctx, _i64, _i64, _i64, C.c_double, C.c_uint64,

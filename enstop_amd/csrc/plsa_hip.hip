@@ -702,9 +702,10 @@ int run_m_step_from_p(plsa_ctx *c, const float *d_sw, bool update_v, float *d_no
 }
 
 // the reference's stop test, plsa.py:634-638: float32 arithmetic, float64 comparison with tolerance
-bool stop_test(float cur, float &prev, double tol) {
+// (block_parallel_plsa.py:329-331 has no `change == 0` arm: zero_arm = false)
+bool stop_test(float cur, float &prev, double tol, bool zero_arm = true) {
     const float change = fabsf(cur - prev);
-    if (change == 0.0f || (double)(change / fabsf(cur)) < tol) return true;
+    if ((zero_arm && change == 0.0f) || (double)(change / fabsf(cur)) < tol) return true;
     prev = cur;
     return false;
 }
@@ -1186,8 +1187,12 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
     CHK(need_factors(c));
     if (n_iter < 0 || n_iter_per_test <= 0) return fail(c, "plsa_fit: bad n_iter / n_iter_per_test");
     const bool fused = flags & PLSA_FUSED, trace = flags & PLSA_TRACE_LL;
+    const bool zero_arm = !(flags & PLSA_STOP_NO_ZERO_ARM);
     const float *d_sw = nullptr;
     CHK(upload_sw(c, sw, &d_sw));
+    // plsa.py:606-628: with use_sample_weights == False the M-step ignores the weights, the
+    // log-likelihood (plsa.py:591, 631) still applies them
+    const float *d_sw_m = (flags & PLSA_SW_LL_ONLY) ? nullptr : d_sw;
     int nll = 0, iters = 0;
     double ll = 0.0;
     float prev = 0.f;
@@ -1204,7 +1209,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
     if (!fused) {
         for (int i = 0; i < n_iter; ++i) {
             CHK(run_e_step(c, thresh));                              // plsa.py:597
-            CHK(run_m_step_from_p(c, d_sw, true, nullptr));       // plsa.py:606-628
+            CHK(run_m_step_from_p(c, d_sw_m, true, nullptr));       // plsa.py:606-628
             iters++;
             if (i % n_iter_per_test == 0) {                          // plsa.py:630
                 if (i == n_iter - 1 && !trace) break;                // outcome cannot matter any more
@@ -1212,7 +1217,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 const float cur = (float)ll;
                 if (ll_trace) ll_trace[nll] = cur;
                 nll++;
-                if (stop_test(cur, prev, tolerance)) break;
+                if (stop_test(cur, prev, tolerance, zero_arm)) break;
             }
         }
     } else {
@@ -1233,7 +1238,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
                 HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
                 c->ls = c->stream2;
-                int rc = run_col_pass(c, false, d_sw, thresh);
+                int rc = run_col_pass(c, false, d_sw_m, thresh);
                 if (!rc) rc = run_v_normalise(c);
                 c->ls = c->stream;
                 if (rc) return rc;
@@ -1245,11 +1250,11 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 // side by side is neutral at config 3, -6 % at config 5), but the short chain of
                 // column sums / normalisation after the column pass leaves the chip nearly idle --
                 // it runs on the second stream underneath the document pass
-                CHK(run_col_pass(c, false, d_sw, thresh, 1));
+                CHK(run_col_pass(c, false, d_sw_m, thresh, 1));
                 HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
                 HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
                 c->ls = c->stream2;
-                int rc = run_col_pass(c, false, d_sw, thresh, 2);
+                int rc = run_col_pass(c, false, d_sw_m, thresh, 2);
                 if (!rc) rc = run_v_normalise(c);
                 c->ls = c->stream;
                 if (rc) return rc;
@@ -1258,7 +1263,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
             } else {
                 CHK(run_row_pass(c, false, pending || first_ll_in_pass, d_sw, thresh, nullptr, &blocks));
-                CHK(run_col_pass(c, false, d_sw, thresh));
+                CHK(run_col_pass(c, false, d_sw_m, thresh));
                 CHK(run_v_normalise(c));
             }
             if (first_ll_in_pass) {
@@ -1272,7 +1277,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 const float cur = (float)ll;
                 if (ll_trace) ll_trace[nll] = cur;
                 nll++;
-                if (stop_test(cur, prev, tolerance)) { stopped = true; break; }  // discard this pass
+                if (stop_test(cur, prev, tolerance, zero_arm)) { stopped = true; break; }  // discard this pass
             }
             c->cu ^= 1; c->cv ^= 1;
             iters++;
@@ -1548,6 +1553,92 @@ int plsa_all_pairs_hellinger(plsa_ctx *c, const float *topics, int64_t t, int64_
     release(R); release(l1); release(part); release(dD); release(dt);
     if (rc) return rc;
     if (e != hipSuccess) return fail(c, "plsa_all_pairs_hellinger: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// enstop/enstop_.py:244-253 (all_pairs_kl_divergence over the stacked topics) on the device
+int plsa_all_pairs_kl(plsa_ctx *c, const float *topics, int64_t t, int64_t m, double *D) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!topics || !D || t <= 0 || m <= 0 || t > 65536) return fail(c, "plsa_all_pairs_kl: bad arguments");
+    const int nt = (int)((t + plsa::HELL_TILE - 1) / plsa::HELL_TILE);
+    const i64 tiles = (i64)nt * nt;
+    int slices = (int)std::max<i64>(1, std::min<i64>(64, (4 * (i64)c->prop.multiProcessorCount + tiles - 1) / tiles));
+    while (slices > 1 && (double)slices * (double)t * (double)t * 8.0 > 4e9) --slices;
+    i64 slice = ((m + slices - 1) / slices + plsa::HELL_KSTEP - 1) / plsa::HELL_KSTEP * plsa::HELL_KSTEP;
+    slices = (int)((m + slice - 1) / slice);
+    DevBuf T, part, dD;
+    int rc = ensure(c, T, sizeof(float) * (size_t)t * m);
+    if (!rc) rc = ensure(c, part, sizeof(double) * (size_t)slices * t * t);
+    if (!rc) rc = ensure(c, dD, sizeof(double) * (size_t)t * t);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpyAsync(T.p, topics, sizeof(float) * (size_t)t * m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            { Scope s(c, "k_kl_gram");
+              hipLaunchKernelGGL(plsa::k_kl_gram, dim3((unsigned)tiles, (unsigned)slices), dim3(256), 0, c->stream,
+                                 T.as<float>(), (int)t, (i64)m, slice, part.as<double>()); }
+            hipLaunchKernelGGL(plsa::k_sum_slices, dim3((unsigned)((t * t + 255) / 256)), dim3(256), 0, c->stream,
+                               part.as<double>(), slices, (i64)t * t, dD.as<double>());
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(D, dD.p, sizeof(double) * (size_t)t * t, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    release(T); release(part); release(dD);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(c, "plsa_all_pairs_kl: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// enstop/enstop_.py:299-308, 340-345 (weights == NULL) and 385-393 (membership-strength weights)
+int plsa_cluster_representatives(plsa_ctx *c, const float *topics, int64_t t, int64_t m, const int32_t *labels,
+                                 const double *weights, int32_t n_clusters, float *out) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!topics || !labels || !out || t <= 0 || m <= 0 || n_clusters < 0)
+        return fail(c, "plsa_cluster_representatives: bad arguments");
+    if (n_clusters == 0) return 0;
+    // members of each cluster in row order (labels < 0 are noise; labels >= n_clusters are an error)
+    std::vector<int> first((size_t)n_clusters + 1, 0), members;
+    for (int64_t i = 0; i < t; ++i) {
+        if (labels[i] >= n_clusters) return fail(c, "plsa_cluster_representatives: label %d >= n_clusters %d", labels[i], n_clusters);
+        if (labels[i] >= 0) first[(size_t)labels[i] + 1]++;
+    }
+    for (int cl = 0; cl < n_clusters; ++cl) first[(size_t)cl + 1] += first[(size_t)cl];
+    members.resize((size_t)first[(size_t)n_clusters] + 1);
+    {
+        std::vector<int> fill(first.begin(), first.end() - 1);
+        for (int64_t i = 0; i < t; ++i) if (labels[i] >= 0) members[(size_t)fill[(size_t)labels[i]]++] = (int)i;
+    }
+    // enstop_.py:385-393 np.average raises on an all-zero weight vector; callers handle that case
+    const int nb = (int)((m + 255) / 256);
+    DevBuf T, dfirst, dmem, dw, rep, bs, dout;
+    int rc = ensure(c, T, sizeof(float) * (size_t)t * m);
+    if (!rc) rc = ensure(c, dfirst, sizeof(int) * first.size());
+    if (!rc) rc = ensure(c, dmem, sizeof(int) * members.size());
+    if (!rc && weights) rc = ensure(c, dw, sizeof(double) * (size_t)t);
+    if (!rc) rc = ensure(c, rep, sizeof(double) * (size_t)n_clusters * m);
+    if (!rc) rc = ensure(c, bs, sizeof(double) * (size_t)n_clusters * nb);
+    if (!rc) rc = ensure(c, dout, sizeof(float) * (size_t)n_clusters * m);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpyAsync(T.p, topics, sizeof(float) * (size_t)t * m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dfirst.p, first.data(), sizeof(int) * first.size(), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dmem.p, members.data(), sizeof(int) * members.size(), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && weights) e = hipMemcpyAsync(dw.p, weights, sizeof(double) * (size_t)t, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(plsa::k_rep_accumulate, dim3((unsigned)nb, (unsigned)n_clusters), dim3(256), 0, c->stream,
+                               T.as<float>(), (i64)m, dfirst.as<int>(), dmem.as<int>(), weights ? dw.as<double>() : nullptr,
+                               rep.as<double>(), bs.as<double>());
+            hipLaunchKernelGGL(plsa::k_rep_normalise, dim3((unsigned)nb, (unsigned)n_clusters), dim3(256), 0, c->stream,
+                               rep.as<double>(), (i64)m, bs.as<double>(), nb, dout.as<float>());
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, sizeof(float) * (size_t)n_clusters * m, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    release(T); release(dfirst); release(dmem); release(dw); release(rep); release(bs); release(dout);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(c, "plsa_cluster_representatives: %s", hipGetErrorString(e));
     return 0;
 }
 

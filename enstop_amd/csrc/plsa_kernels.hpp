@@ -150,6 +150,20 @@ __device__ __forceinline__ void scale(float4 (&a)[CH], float s) {
     for (int j = 0; j < CH; ++j) { a[j].x *= s; a[j].y *= s; a[j].z *= s; a[j].w *= s; }
 }
 
+// Thresholds below the smallest normal float (e_step_thresh = 0 is legal) let a responsibility norm be
+// denormal; 1/norm then overflows although every quotient v/norm the reference forms (plsa.py:104) is
+// <= 1.  `tiny` (kernel-uniform: thresh < TINY_THRESH) enables a rescue that multiplies such a norm
+// and its products by 2^100 first -- exact, powers of two -- so the reciprocal stays finite.  With the
+// default threshold (1e-32) every non-zero norm exceeds 1e-32 and the branch is never compiled in.
+constexpr float TINY_THRESH = 5e-38f;
+template <int CH>
+__device__ __forceinline__ void rescue_tiny(bool tiny, float &norm, float4 (&keep)[CH]) {
+    if (tiny && norm < 0x1p-100f) {
+        norm *= 0x1p100f;
+        scale(keep, 0x1p100f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_e_step: the materialising E-step, plsa.py:91-105.  nnz-parallel: a wave takes a tile of 64
 // consecutive non-zeros, loads their (doc, word) ids with one coalesced access each, then walks the
@@ -172,6 +186,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step(const int *__restric
     const int wave = threadIdx.x >> 6;
     const int g = lane / LPN, li = lane % LPN;
     const i64 tiles = (nnz + 63) >> 6;
+    const bool tiny = thresh < TINY_THRESH;
     for (i64 t = (i64)blockIdx.x * 4 + wave; t < tiles; t += (i64)gridDim.x * 4) {
         const i64 base = t << 6;
         const i64 mine = base + lane;
@@ -192,7 +207,9 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step(const int *__restric
             for (int q = 0; q < UNR; ++q) {
                 float4 keep[CH];
                 float unth;
-                const float inv = inv_norm(group_sum<LPN>(products<CH, false>(u[q], vt[q], thresh, keep, unth)));
+                float norm = group_sum<LPN>(products<CH, false>(u[q], vt[q], thresh, keep, unth));
+                rescue_tiny(tiny, norm, keep);
+                const float inv = inv_norm(norm);
                 float *prow = P + (base + (s0 + q) * GPW + g) * kp;
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step_rows(const int *__re
     const int gid = threadIdx.x / LPN;
     const bool items = ritem_row != nullptr;
     const i64 n_work = items ? n_ritems : (i64)n;
+    const bool tiny = thresh < TINY_THRESH;
     for (i64 r = (i64)blockIdx.x * GPB + gid; r < n_work; r += (i64)gridDim.x * GPB) {
         const int d = items ? ritem_row[r] : (row_order ? row_order[r] : (int)r);
         const int j0 = items ? ritem_start[r] : indptr[d];
@@ -251,7 +269,9 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step_rows(const int *__re
                 for (int q = 0; q < UNR; ++q) {
                     float4 keep[CH];
                     float unth;
-                    const float inv = inv_norm(group_sum<LPN>(products<CH, false>(u, vt[q], thresh, keep, unth)));
+                    float norm = group_sum<LPN>(products<CH, false>(u, vt[q], thresh, keep, unth));
+                    rescue_tiny(tiny, norm, keep);
+                    const float inv = inv_norm(norm);
                     if (s0 + q < cnt) {
                         float *prow = P + (i64)(jb + s0 + q) * kp;
 #pragma unroll
@@ -300,6 +320,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_row_pass(const int *__restr
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
     double ll = 0.0;
+    const bool tiny = !FROM_P && thresh < TINY_THRESH;
     // item mode (ritem_row != nullptr): rows are cut into items of <= rseg entries, a group owns
     // one item and writes an un-normalised partial row that k_row_reduce adds up in item order.
     // Used when there are too few / too uneven rows to fill the chip (few long documents).
@@ -345,7 +366,8 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_row_pass(const int *__restr
                     } else {
                         float unth;
                         const float part = products<CH, WANT_LL>(u, a[q], thresh, pz, unth);
-                        const float norm = group_sum<LPN>(part);
+                        float norm = group_sum<LPN>(part);
+                        rescue_tiny(tiny, norm, pz);
                         if (WANT_LL) {
                             const float dot = group_sum<LPN>(unth);
                             if (li == q && s0 + q < cnt) { my_dot = dot; my_x = x[q]; }
@@ -487,7 +509,8 @@ __device__ __forceinline__ void col_batch(int s0, int d_l, float x_l, int p_l, i
             for (int j = 0; j < CH; ++j) pz[j] = S::ok(li, j, kp) ? a[q][j] : zero4();
         } else {
             float unth;
-            const float norm = group_sum<LPN>(products<CH, false>(a[q], vt, thresh, pz, unth));
+            float norm = group_sum<LPN>(products<CH, false>(a[q], vt, thresh, pz, unth));
+            rescue_tiny(thresh < TINY_THRESH, norm, pz);
             x[q] *= inv_norm(norm);
         }
 #pragma unroll
@@ -1313,6 +1336,135 @@ __global__ __launch_bounds__(256) void k_hell_finish(const double *__restrict__ 
     else if (li == 0.0 || lj == 0.0) d = 1.0;
     else d = sqrt(fmax(1.0 - g / sqrt(li * lj), 0.0));
     D[e] = d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// All-pairs KL divergence of the stacked ensemble topics, enstop/enstop_.py:234-253:
+//   D[i, j] = sum over words with p_i > 0 and p_j > 0 of  p_i * (log2 p_i - log2 p_j)      (bits)
+// Not symmetric: every (i, j) tile is computed.  Same staging as k_hell_gram; log2 (v_log_f32 IS a
+// base-2 logarithm) is evaluated while a tile is staged into LDS, the pair term is formed directly
+// (no cancellation between two large dot products), float partial sums are flushed into float64
+// every 256 words.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_kl_gram(const float *__restrict__ T, int t, i64 m, i64 slice,
+                                                 double *__restrict__ partial /*[slices][t][t]*/) {
+    __shared__ float sp[HELL_KSTEP][HELL_TILE + 1], sl[HELL_KSTEP][HELL_TILE + 1];   // row side: p_i, log2 p_i
+    __shared__ float sq[HELL_KSTEP][HELL_TILE + 1], sm[HELL_KSTEP][HELL_TILE + 1];   // column side: log2 p_j, [p_j > 0]
+    const int nt = (t + HELL_TILE - 1) / HELL_TILE;
+    const int bi = (int)(blockIdx.x / nt) * HELL_TILE, bj = (int)(blockIdx.x % nt) * HELL_TILE;
+    const i64 w0 = (i64)blockIdx.y * slice, w1 = min(m, w0 + slice);
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+    double acc[4][4];
+    float facc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { acc[a][b] = 0.0; facc[a][b] = 0.f; }
+    int since_flush = 0;
+    for (i64 w = w0; w < w1; w += HELL_KSTEP) {
+        for (int e = threadIdx.x; e < HELL_TILE * HELL_KSTEP; e += 256) {
+            const int r = e / HELL_KSTEP, kk = e % HELL_KSTEP;
+            const i64 ww = w + kk;
+            const float pi = (bi + r < t && ww < w1) ? T[(i64)(bi + r) * m + ww] : 0.f;
+            const float pj = (bj + r < t && ww < w1) ? T[(i64)(bj + r) * m + ww] : 0.f;
+            sp[kk][r] = pi > 0.f ? pi : 0.f;
+            sl[kk][r] = pi > 0.f ? __log2f(pi) : 0.f;
+            sq[kk][r] = pj > 0.f ? __log2f(pj) : 0.f;
+            sm[kk][r] = pj > 0.f ? 1.f : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < HELL_KSTEP; ++kk) {
+            float pa[4], la[4], lb[4], mb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                pa[a] = sp[kk][ty * 4 + a]; la[a] = sl[kk][ty * 4 + a];
+                lb[a] = sq[kk][tx * 4 + a]; mb[a] = sm[kk][tx * 4 + a];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) facc[a][b] += (pa[a] * mb[b]) * (la[a] - lb[b]);
+        }
+        __syncthreads();
+        since_flush += HELL_KSTEP;
+        if (since_flush >= 256) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { acc[a][b] += (double)facc[a][b]; facc[a][b] = 0.f; }
+            since_flush = 0;
+        }
+    }
+    double *out = partial + (i64)blockIdx.y * t * t;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = bi + ty * 4 + a, j = bj + tx * 4 + b;
+            if (i < t && j < t) out[(i64)i * t + j] = acc[a][b] + (double)facc[a][b];
+        }
+}
+
+__global__ __launch_bounds__(256) void k_sum_slices(const double *__restrict__ partial, int slices, i64 count,
+                                                    double *__restrict__ D) {
+    const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    double g = 0.0;
+    for (int s = 0; s < slices; ++s) g += partial[(i64)s * count + e];
+    D[e] = g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cluster representatives of the topic combination, enstop/enstop_.py:299-308, 340-345, 385-393:
+//   rep[c] = ( sum_{i in c} w_i sqrt(p_i) / sum_{i in c} w_i )^2, then L1-normalised
+// (w == nullptr: plain mean).  members[] lists the topic rows of each cluster back to back
+// (first[c] .. first[c+1]); rows are added in member order (fixed order: reproducible).
+//   k_rep_accumulate : one thread per (cluster, word); per-block float64 partial of the row sum
+//   k_rep_normalise  : fixed-order sum of the block partials, division, float32 output
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rep_accumulate(const float *__restrict__ T, i64 m,
+                                                        const int *__restrict__ first, const int *__restrict__ members,
+                                                        const double *__restrict__ w, double *__restrict__ rep /*[c][m]*/,
+                                                        double *__restrict__ block_sums /*[c][gridDim.x]*/) {
+    const int c = blockIdx.y;
+    const int i0 = first[c], i1 = first[c + 1];
+    const i64 word = (i64)blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
+    if (word < m) {
+        double num = 0.0, den = 0.0;
+        for (int i = i0; i < i1; ++i) {
+            const double wi = w ? w[members[i]] : 1.0;
+            num += wi * (double)sqrtf(T[(i64)members[i] * m + word]);
+            den += wi;
+        }
+        const double mean = den > 0.0 ? num / den : 0.0;
+        v = mean * mean;
+        rep[(i64)c * m + word] = v;
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[(i64)c * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void k_rep_normalise(const double *__restrict__ rep, i64 m,
+                                                       const double *__restrict__ block_sums, int n_blocks,
+                                                       float *__restrict__ out /*[c][m]*/) {
+    const int c = blockIdx.y;
+    __shared__ double total;
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < n_blocks; ++b) s += block_sums[(i64)c * n_blocks + b];
+        total = s;
+    }
+    __syncthreads();
+    const i64 word = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (word < m) out[(i64)c * m + word] = (float)(rep[(i64)c * m + word] / total);
 }
 
 }  // namespace plsa

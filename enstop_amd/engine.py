@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 from . import _lib
-from ._lib import PLSA_FUSED, PLSA_TRACE_LL, ptr
+from ._lib import PLSA_FUSED, PLSA_GRAPH, PLSA_STOP_NO_ZERO_ARM, PLSA_SW_LL_ONLY, PLSA_TRACE_LL, ptr
 
 
 class DeviceError(RuntimeError):
@@ -256,6 +256,29 @@ class Engine:
         D = np.empty((t, t), np.float64)
         self._ok(self._L.plsa_all_pairs_hellinger(self._h, ptr(T), t, m, D))
         return D
+
+    def all_pairs_kl(self, topics):
+        """[t, t] float64 KL(topic i || topic j) in bits (enstop_.py:234-253)."""
+        T = _f32(topics)
+        if T.ndim != 2:
+            raise ValueError("topics must be a 2-D array")
+        t, m = T.shape
+        D = np.empty((t, t), np.float64)
+        self._ok(self._L.plsa_all_pairs_kl(self._h, ptr(T), t, m, D))
+        return D
+
+    def cluster_representatives(self, topics, labels, weights=None):
+        """Stable topic of every cluster (enstop_.py:299-308, 385-393): [n_clusters, m] float32."""
+        T = _f32(topics)
+        lab = np.ascontiguousarray(labels, dtype=np.int32)
+        t, m = T.shape
+        if lab.shape != (t,):
+            raise ValueError("labels must have one entry per topic")
+        n_clusters = int(lab.max()) + 1 if lab.size and lab.max() >= 0 else 0
+        out = np.empty((n_clusters, m), np.float32)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        self._ok(self._L.plsa_cluster_representatives(self._h, ptr(T), t, m, lab, ptr(w), n_clusters, out))
+        return out
 
     def placement_info(self):
         n, a, b = C.c_int32(0), C.c_double(0.0), C.c_double(0.0)

@@ -1,18 +1,22 @@
 """EnsembleTopics on top of the GPU ensemble path (a "next" row).
 
-The expensive stages -- the bootstrapped pLSA fits (`ensemble_of_topics`), the all-pairs Hellinger
-distance matrix of the stacked topics (`plsa_all_pairs_hellinger`) and the final refit of the document
-vectors (`plsa_refit`) -- run on the MI355X engine.  The clustering of the few hundred topic vectors
-(HDBSCAN) and the cluster representatives stay on the host.
+On the MI355X engine: the bootstrapped pLSA fits (`ensemble_of_topics`), the all-pairs Hellinger and
+KL matrices of the stacked topics (`plsa_all_pairs_hellinger`, `plsa_all_pairs_kl`), the cluster
+representatives (`plsa_cluster_representatives`) and the final refit of the document vectors
+(`plsa_refit`).  On the host: the tree step of HDBSCAN over the few hundred topic vectors.
 
-Parity status of this module: **unpinned**.  The reference clusters with the third-party `hdbscan`
-and `umap` packages (enstop/enstop_.py:234-414), neither of which is available in the build image, so
-no golden vectors exist for it.  Here `"hellinger"` and `"kl_divergence"` use scikit-learn's HDBSCAN
-(`sklearn.cluster.HDBSCAN`, the maintained successor of the `hdbscan` package) on a precomputed
-divergence matrix; `"hellinger_umap"` needs `umap-learn` and raises ImportError when it is absent.
-The representative of a cluster is formed exactly as the reference does: the (optionally
-membership-weighted) mean of the square-rooted member topics, squared and L1-normalised
-(enstop_.py:299-308, 340-345, 385-393).
+Parity status.  Pinned by reference-generated goldens (tests/golden/combine_t24.npz, produced by the
+reference's own statements, tests/golden/make_golden.py::gen_combine): `all_pairs_kl_divergence`
+(enstop_.py:234-253), the mutual-reachability matrix of `generate_combined_topics_kl` (:283-296), and
+the cluster representatives of all three combiners given labels / membership strengths (:299-308,
+:340-345, :385-393).  **Unpinned**: what the third-party packages compute -- `hdbscan` (MST, single
+linkage, condensed-tree labels) and `umap` (the Hellinger metric and the embedding); neither is
+installable in the build image.  For those steps scikit-learn's HDBSCAN is used: its public estimator
+on a precomputed matrix for "hellinger", its `_linkage` / `_tree` routines (the same three steps the
+reference calls in hdbscan) on the reference's mutual-reachability matrix for "kl_divergence";
+"hellinger_umap" needs `umap-learn` and raises ImportError when it is absent.  The all-pairs Hellinger
+matrix follows umap.distances.hellinger's published definition (umap-learn >= 0.3.8) and is checked
+against that definition, not against a reference run.
 """
 import numpy as np
 from scipy.sparse import coo_matrix, csr_matrix, issparse
@@ -43,7 +47,8 @@ def all_pairs_hellinger_distance(distributions):
 
 
 def all_pairs_kl_divergence(distributions):
-    """KL(p_i || p_j) in bits over the common support (enstop_.py:234-253)."""
+    """KL(p_i || p_j) in bits over the common support (enstop_.py:234-253), host NumPy float64
+    definition; `ensemble_fit` uses the device kernel (`Engine.all_pairs_kl`) instead."""
     P = np.asarray(distributions, dtype=np.float64)
     with np.errstate(divide="ignore"):
         L = np.where(P > 0, np.log2(np.where(P > 0, P, 1.0)), 0.0)
@@ -52,17 +57,36 @@ def all_pairs_kl_divergence(distributions):
     return (P * L) @ pos.T - P @ L.T
 
 
-def _cluster_representatives(all_topics, labels, weights=None):
+def mutual_reachability_from_divergences(divergence_matrix, min_samples):
+    """enstop_.py:283-296: the core divergence of a topic is its `min_samples`-th smallest divergence
+    (row-wise sort, position `min_samples`, the zero self-divergence included); the mutual
+    reachability is the elementwise maximum of D, D^T and both core divergences."""
+    D = np.asarray(divergence_matrix, dtype=np.float64)
+    core = np.sort(D, axis=1)[:, min_samples]
+    tiled = np.tile(core, (core.shape[0], 1))
+    return np.dstack([D, D.T, tiled, tiled.T]).max(axis=-1)
+
+
+def _cluster_representatives(all_topics, labels, weights=None, engine=None):
+    """enstop_.py:299-308 / 385-393.  With `engine` the means are formed on the device
+    (`plsa_cluster_representatives`), else in NumPy with the reference's own expressions."""
+    labels = np.asarray(labels)
     n_clusters = int(labels.max()) + 1 if labels.size else 0
-    result = np.empty((n_clusters, all_topics.shape[1]), dtype=np.float32)
-    root = np.sqrt(all_topics)
+    if engine is not None and n_clusters > 0:
+        if weights is not None:     # np.average raises ZeroDivisionError on all-zero weights (enstop_.py:387)
+            for i in range(n_clusters):
+                if not np.any(np.asarray(weights)[labels == i] != 0):
+                    raise ZeroDivisionError("Weights sum to zero, can't be normalized")
+        return engine.cluster_representatives(all_topics, labels, weights)
+    all_topics = np.asarray(all_topics)
+    result = np.empty((max(n_clusters, 0), all_topics.shape[1]), dtype=np.float32)
     for i in range(n_clusters):
         mask = labels == i
-        w = None if weights is None else weights[mask]
-        if w is not None and not np.any(w > 0):
-            w = None
-        rep = np.average(root[mask], axis=0, weights=w) ** 2
-        result[i] = rep / rep.sum()
+        if weights is None:
+            result[i] = np.mean(np.sqrt(all_topics[mask]), axis=0) ** 2
+        else:
+            result[i] = np.average(np.sqrt(all_topics[mask]), axis=0, weights=np.asarray(weights)[mask]) ** 2
+        result[i] /= result[i].sum()
     return result
 
 
@@ -72,25 +96,46 @@ def _hdbscan_precomputed(D, min_samples, min_cluster_size):
                    cluster_selection_method="leaf").fit(D)
 
 
-def generate_combined_topics_kl(all_topics, min_samples=5, min_cluster_size=5):
-    D = all_pairs_kl_divergence(all_topics)
-    D = np.maximum(D, D.T)                       # symmetrised, as the reference's mutual reachability is
-    np.fill_diagonal(D, 0.0)
-    labels = _hdbscan_precomputed(np.clip(D, 0.0, None), min_samples, min_cluster_size).labels_
-    return _cluster_representatives(np.asarray(all_topics), labels)
+def labels_from_mutual_reachability(mutual_reachability, min_cluster_size):
+    """enstop_.py:291-298: minimum spanning tree of the mutual-reachability graph (Prim), edges sorted
+    by weight, single-linkage tree, condensed tree with leaf selection.  The reference calls
+    hdbscan's `mst_linkage_core`, `label` and `_tree_to_labels`; scikit-learn's HDBSCAN carries the same
+    three routines (`mst_from_mutual_reachability`, `make_single_linkage`, `tree_to_labels`).  This tree
+    step is the one part of the topic combination whose parity is unpinned (hdbscan is not installable
+    in the build image)."""
+    from sklearn.cluster._hdbscan._linkage import make_single_linkage, mst_from_mutual_reachability
+    from sklearn.cluster._hdbscan._tree import tree_to_labels
+    mr = np.ascontiguousarray(mutual_reachability, dtype=np.float64).copy()
+    mst = mst_from_mutual_reachability(mr)
+    mst = mst[np.argsort(mst["distance"])]
+    tree = make_single_linkage(mst)
+    labels, probabilities = tree_to_labels(tree, min_cluster_size=min_cluster_size,
+                                           cluster_selection_method="leaf")
+    return np.asarray(labels), np.asarray(probabilities)
 
 
-def generate_combined_topics_hellinger(all_topics, min_samples=5, min_cluster_size=5, distance_fn=None):
-    """`distance_fn`: all-pairs Hellinger implementation; `ensemble_fit` passes the engine's device
-    kernel (`Engine.all_pairs_hellinger`: 32 x 20 topics over 174 k words take 0.8 s in NumPy float64,
-    milliseconds on the GPU), standalone calls on host arrays use the NumPy definition above."""
-    D = (distance_fn or all_pairs_hellinger_distance)(all_topics)
+def generate_combined_topics_kl(all_topics, min_samples=5, min_cluster_size=5, engine=None):
+    """enstop_.py:256-310.  `engine`: run the all-pairs KL matrix and the representatives on the GPU."""
+    D = engine.all_pairs_kl(all_topics) if engine is not None else all_pairs_kl_divergence(all_topics)
+    mr = mutual_reachability_from_divergences(D, min_samples)
+    labels, _ = labels_from_mutual_reachability(mr, min_cluster_size)
+    return _cluster_representatives(all_topics, labels, engine=engine)
+
+
+def generate_combined_topics_hellinger(all_topics, min_samples=5, min_cluster_size=5, distance_fn=None,
+                                       engine=None):
+    """enstop_.py:313-347.  `engine` / `distance_fn`: all-pairs Hellinger on the device
+    (`Engine.all_pairs_hellinger`: 32 x 20 topics over 174 k words take 0.8 s in NumPy float64,
+    milliseconds on the GPU); standalone calls on host arrays use the NumPy definition above."""
+    if distance_fn is None:
+        distance_fn = engine.all_pairs_hellinger if engine is not None else all_pairs_hellinger_distance
+    D = distance_fn(all_topics)
     labels = _hdbscan_precomputed(D, min_samples, min_cluster_size).labels_
-    return _cluster_representatives(np.asarray(all_topics), labels)
+    return _cluster_representatives(all_topics, labels, engine=engine)
 
 
 def generate_combined_topics_hellinger_umap(all_topics, min_samples=5, min_cluster_size=5,
-                                            n_neighbors=15, reduced_dim=5):
+                                            n_neighbors=15, reduced_dim=5, engine=None):
     try:
         import umap
     except ImportError as e:
@@ -101,7 +146,7 @@ def generate_combined_topics_hellinger_umap(all_topics, min_samples=5, min_clust
                           metric="hellinger").fit_transform(all_topics)
     clusterer = HDBSCAN(min_samples=min_samples, min_cluster_size=min_cluster_size,
                         cluster_selection_method="leaf", allow_single_cluster=True).fit(embedding)
-    return _cluster_representatives(np.asarray(all_topics), clusterer.labels_, clusterer.probabilities_)
+    return _cluster_representatives(all_topics, clusterer.labels_, clusterer.probabilities_, engine=engine)
 
 
 _topic_combiner = {
@@ -118,8 +163,8 @@ def ensemble_fit(X, estimated_n_topics=10, model="plsa", init="random", min_samp
                  solver="mu", random_state=None, device=None):
     """Stable topics from an ensemble of bootstrapped pLSA fits, then document vectors against them
     (enstop_.py:417-584).  Returns (doc_vectors [n_docs, M], stable_topics [M, n_words])."""
-    if model != "plsa":
-        raise ValueError('Only model="plsa" is implemented on this engine')
+    if model not in ("plsa", "nmf"):
+        raise ValueError('Model must be one of "plsa" or "nmf"')
     if topic_combination not in _topic_combiner:
         raise ValueError("topic_combination must be one of {}".format(tuple(_topic_combiner.keys())))
     X = check_array(X, accept_sparse="csr", dtype=np.float32)
@@ -127,23 +172,26 @@ def ensemble_fit(X, estimated_n_topics=10, model="plsa", init="random", min_samp
     all_topics = ensemble_of_topics(X, estimated_n_topics, model, n_jobs, n_starts, parallelism,
                                     init=init, n_iter=n_iter, n_iter_per_test=n_iter_per_test,
                                     tolerance=tolerance, e_step_thresh=e_step_thresh, bootstrap=bootstrap,
-                                    random_state=random_state, device=device)
-    if topic_combination == "hellinger":
-        from .engine import get_engine
-        stable_topics = generate_combined_topics_hellinger(all_topics, min_samples, min_cluster_size,
-                                                           distance_fn=get_engine(device).all_pairs_hellinger)
-    else:
-        stable_topics = _topic_combiner[topic_combination](all_topics, min_samples, min_cluster_size)
+                                    random_state=random_state, device=device,
+                                    **(dict(beta_loss=beta_loss, alpha=alpha, solver=solver) if model == "nmf" else {}))
+    from .engine import get_engine
+    stable_topics = _topic_combiner[topic_combination](all_topics, min_samples, min_cluster_size,
+                                                       engine=get_engine(device))
     if stable_topics.shape[0] == 0:
         raise ValueError("topic combination found no stable topic cluster; lower min_samples / "
                          "min_cluster_size or raise n_starts")
     if lift_factor != 1:
         stable_topics = stable_topics.astype(np.float64) ** lift_factor
         stable_topics = (stable_topics / stable_topics.sum(axis=1, keepdims=True)).astype(np.float32)
+    if model == "nmf":                          # enstop_.py:570-579, host scikit-learn like the reference
+        from sklearn.decomposition import non_negative_factorization
+        doc_vectors, _, _ = non_negative_factorization(
+            X, H=np.asarray(stable_topics, dtype=X.dtype), n_components=stable_topics.shape[0],
+            update_H=False, beta_loss=beta_loss, alpha_W=alpha, solver=solver)
+        return doc_vectors, stable_topics
     sample_weight = _check_sample_weight(None, X, dtype=np.float32)
-    rs = random_state if not isinstance(random_state, np.random.RandomState) else random_state
     doc_vectors = plsa_refit(X, stable_topics, sample_weight, e_step_thresh=e_step_thresh,
-                             random_state=rs, device=device)
+                             random_state=random_state, device=device)
     return doc_vectors, stable_topics
 
 

@@ -50,8 +50,43 @@ def plsa_topics(X, k, **kwargs):
         e_step_thresh=kwargs.get("e_step_thresh", 1e-16), flags=kwargs.get("flags", None))
 
 
-@_locked
+def nmf_topics(X, k, **kwargs):
+    """enstop_.py:118-161: bootstrap-resample the documents, fit scikit-learn's NMF on the HOST, return
+    the L1-row-normalised components.  NMF is a different model from pLSA and not part of the GPU hot
+    path (SURVEY.md section 2 lists it out of scope); it is delegated to scikit-learn exactly as the
+    reference does so that `model="nmf"` keeps working.  `alpha` maps to `alpha_W` (scikit-learn
+    renamed the parameter in 1.0)."""
+    from sklearn.decomposition import NMF
+    from .utils import normalize
+    A = X.tocsr() if issparse(X) else csr_matrix(X)
+    if kwargs.get("bootstrap", True):
+        rng = check_random_state(kwargs.get("random_state", None))
+        A = A[rng.randint(0, A.shape[0], size=A.shape[0])]
+    nmf = NMF(n_components=k, init=kwargs.get("init", "nndsvd"), beta_loss=kwargs.get("beta_loss", 1),
+              alpha_W=kwargs.get("alpha", 0.0), solver=kwargs.get("solver", "mu"),
+              random_state=kwargs.get("random_state", None)).fit(A)
+    topics = np.array(nmf.components_, dtype=np.float64, order="C")
+    normalize(topics, axis=1)
+    return topics
+
+
+def _ensemble_of_nmf_topics(X, k, n_runs, **kwargs):
+    """model="nmf" branch of ensemble_of_topics (enstop_.py:199-231), serial on the host."""
+    kw = {key: kwargs[key] for key in ("bootstrap", "random_state", "init", "beta_loss", "alpha", "solver")
+          if key in kwargs}
+    return np.vstack([nmf_topics(X, k, **kw) for _ in range(n_runs)])
+
+
 def ensemble_of_topics(X, k, model="plsa", n_jobs=4, n_runs=16, parallelism="dask", **kwargs):
+    if model == "nmf":
+        return _ensemble_of_nmf_topics(X, k, n_runs, **kwargs)
+    if model != "plsa":
+        raise ValueError('Model must be one of "plsa" or "nmf"')
+    return _ensemble_of_plsa_topics(X, k, n_jobs, n_runs, parallelism, **kwargs)
+
+
+@_locked
+def _ensemble_of_plsa_topics(X, k, n_jobs=4, n_runs=16, parallelism="dask", **kwargs):
     """All topics of `n_runs` bootstrapped fits stacked to (n_runs * k, n_words), enstop_.py:164-231.
 
     `parallelism`:
@@ -66,8 +101,6 @@ def ensemble_of_topics(X, k, model="plsa", n_jobs=4, n_runs=16, parallelism="das
     (reference: every thread re-seeds with the same int, producing identical members,
     enstop_.py:86 -- a documented defect, not reproduced).
     """
-    if model != "plsa":
-        raise ValueError('Only model="plsa" is implemented on this engine')
     if parallelism not in ("dask", "joblib", "none"):
         raise ValueError("Unrecognized parallelism {}; should be one of {}".format(
             parallelism, ("dask", "joblib", "none")))

@@ -23,7 +23,7 @@ from scipy.sparse import coo_matrix, csr_matrix, issparse
 from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_array, check_random_state
 
-from .engine import Engine, get_engine
+from .engine import Engine, PLSA_SW_LL_ONLY, PLSA_STOP_NO_ZERO_ARM, default_flags, get_engine
 from .utils import (_check_sample_weight, coherence, log_lift, mean_coherence, mean_log_lift, normalize,
                     standardize_input)
 
@@ -42,8 +42,8 @@ def _coo_to_csr(X_rows, X_cols, X_vals, n, m):
         X_cols = np.asarray(X_cols)[order]
         X_vals = np.asarray(X_vals)[order]
     indptr = np.zeros(n + 1, dtype=np.int64)
-    np.add.at(indptr, rows.astype(np.int64) + 1, 1)
-    indptr = np.cumsum(indptr).astype(np.int32)
+    np.cumsum(np.bincount(rows.astype(np.int64), minlength=n), out=indptr[1:])
+    indptr = indptr.astype(np.int32)
     csr = csr_matrix((np.asarray(X_vals, np.float32), np.asarray(X_cols, np.int32), indptr), shape=(n, m))
     return csr, order
 
@@ -181,10 +181,15 @@ def plsa_fit_inner(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, sample_weig
     """EM loop on COO triplets; factor arrays are updated in place and returned (plsa.py:517-640)."""
     eng, _ = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device)
     sw = np.asarray(sample_weight, np.float32)
-    # the weighted M-step only when requested; the log-likelihood always sees the weights
-    if not use_sample_weights and np.any(sw != 1.0):
-        raise ValueError("non-unit sample_weight with use_sample_weights=False is not supported")
-    eng.fit(sw if use_sample_weights else None, n_iter, n_iter_per_test, tolerance, e_step_thresh, flags)
+    flags = default_flags() if flags is None else flags
+    # the weighted M-step only when requested (plsa.py:606-628); the log-likelihood always sees the
+    # weights (plsa.py:591, 631): non-unit weights with use_sample_weights=False reach the engine
+    # with the PLSA_SW_LL_ONLY flag
+    if not np.any(sw != 1.0):
+        sw = None
+    elif not use_sample_weights:
+        flags |= PLSA_SW_LL_ONLY
+    eng.fit(sw, n_iter, n_iter_per_test, tolerance, e_step_thresh, flags)
     U, V = eng.get_factors()
     p_z_given_d[...] = U
     p_w_given_z[...] = V
@@ -343,9 +348,10 @@ class PLSA(_TopicMetricsMixin, BaseEstimator, TransformerMixin):
         self.random_state = random_state
         self.device = device
 
+    _extra_flags = 0      # subclasses: stop-test variant of the reference module they stand in for
+
     def _flags(self):
-        from .engine import default_flags
-        return default_flags()
+        return default_flags() | self._extra_flags
 
     def _fit_factors(self, X, sample_weight):
         return plsa_fit(X, self.n_components, sample_weight, self.init, self.n_iter, self.n_iter_per_test,
@@ -408,9 +414,23 @@ class StreamedPLSA(PLSA):
                          random_state=random_state, device=device)
         self.block_size = block_size
 
+    # streamed_plsa.py:596-597: the stop test has no `change == 0` arm
+    _extra_flags = PLSA_STOP_NO_ZERO_ARM
+
     def _flags(self):
         from .engine import PLSA_FUSED
-        return PLSA_FUSED
+        return PLSA_FUSED | self._extra_flags
+
+    def transform(self, X, y=None, sample_weight=None):
+        """streamed_plsa.py:1237: unlike PLSA.transform this one takes `sample_weight` (it only enters
+        the log-likelihood of plsa_refit, whose stop test never fires: same vectors either way)."""
+        X = check_array(X, accept_sparse="csr")
+        sample_weight = _check_sample_weight(sample_weight, X, dtype=np.float32)
+        random_state = check_random_state(self.transform_random_seed)
+        X = csr_matrix(X) if not issparse(X) else X.tocsr()
+        return plsa_refit(X, self.components_, sample_weight, n_iter=50, n_iter_per_test=5,
+                          tolerance=0.001, random_state=random_state, device=self.device,
+                          flags=self._flags())
 
 
 class BlockParallelPLSA(PLSA):
@@ -418,9 +438,16 @@ class BlockParallelPLSA(PLSA):
     The reference tiles X into n_row_blocks x n_col_blocks padded COO tiles for numba threads (and
     silently wraps tile sizes above 65 535 rows through np.uint16, block_parallel_plsa.py:359-360);
     on the GPU the work decomposition is per document row / per column item, so the two tiling
-    parameters are accepted as hints and ignored.  Same EM maths, hence the same results as `PLSA`
-    (the reference's blockwise log-likelihood ignores sample weights, block_parallel_plsa.py:205-248;
-    here they are honoured like in plsa.py)."""
+    parameters are accepted as hints and ignored.  Same EM maths as `PLSA`, with the two semantic
+    differences of the reference module reproduced (golden: tests/golden/blockfit_*.npz):
+    `sample_weight` is validated but never reaches the fit (block_parallel_plsa.py:499, 516-527; the
+    blockwise log-likelihood has no weights, :205-248), and the stop test has no `change == 0` arm
+    (:329-331)."""
+
+    _extra_flags = PLSA_STOP_NO_ZERO_ARM
+
+    def _fit_factors(self, X, sample_weight):
+        return super()._fit_factors(X, np.ones(X.shape[0], np.float32))
 
     def __init__(self, n_components=10, init="random", n_row_blocks=8, n_col_blocks=8, n_iter=100,
                  n_iter_per_test=10, tolerance=0.001, e_step_thresh=1e-32, transform_random_seed=42,

@@ -1,10 +1,7 @@
 """Host-side helpers with the reference's names (enstop/utils.py): input standardisation and
 sample-weight validation used by the estimators.  Not hot-path code."""
-import numbers
-
 import numpy as np
 from sklearn.preprocessing import normalize as _sk_normalize
-from sklearn.utils.validation import check_array
 
 from .engine import host_normalize_rows
 
@@ -31,23 +28,10 @@ def standardize_input(input_matrix):
     return input_matrix
 
 
-def _check_sample_weight(sample_weight, X, dtype=None):
-    """sklearn's validator (the reference falls back to a vendored copy, enstop/utils.py:285-335):
-    None -> ones, scalar -> full, array -> checked 1-D of length n_samples."""
-    n_samples = X.shape[0]
-    if dtype is not None and dtype not in (np.float32, np.float64):
-        dtype = np.float64
-    if sample_weight is None:
-        return np.ones(n_samples, dtype=dtype)
-    if isinstance(sample_weight, numbers.Number):
-        return np.full(n_samples, sample_weight, dtype=dtype)
-    sample_weight = check_array(sample_weight, accept_sparse=False, ensure_2d=False,
-                                dtype=[np.float64, np.float32] if dtype is None else dtype, order="C")
-    if sample_weight.ndim != 1:
-        raise ValueError("Sample weights must be 1D array or scalar")
-    if sample_weight.shape != (n_samples,):
-        raise ValueError("sample_weight.shape == {}, expected {}!".format(sample_weight.shape, (n_samples,)))
-    return sample_weight
+# sample-weight validation: scikit-learn's own validator, as the reference imports it by default
+# (enstop/plsa.py:9, enstop_.py:8; its vendored copy enstop/utils.py:285-335 is only a fallback for
+# scikit-learn versions that predate the function)
+from sklearn.utils.validation import _check_sample_weight  # noqa: E402,F401
 
 
 # ------------------------------------------------------------------------------------------------

@@ -33,8 +33,15 @@ typedef struct plsa_ctx plsa_ctx;
 /* plsa_fit()/plsa_refit() `flags` */
 enum {
     PLSA_FUSED     = 1, /* never materialise P(z|w,d) (idea of enstop/streamed_plsa.py:341-375)     */
-    PLSA_TRACE_LL  = 4  /* also evaluate the log-likelihood test of the last iteration when it
+    PLSA_TRACE_LL  = 4, /* also evaluate the log-likelihood test of the last iteration when it
                            cannot change the result (only to fill ll_trace like plsa.py:631)        */
+    PLSA_SW_LL_ONLY = 8, /* plsa_fit: `sw` enters the log-likelihood only, the M-step is the unweighted
+                           one: plsa_fit_inner(use_sample_weights=False) with non-unit weights,
+                           enstop/plsa.py:591, 606-628, 631                                         */
+    PLSA_STOP_NO_ZERO_ARM = 16, /* plsa_fit: stop test of enstop/block_parallel_plsa.py:329-331
+                           (`change / |cur| < tolerance` only, no `change == 0` arm)               */
+    PLSA_GRAPH     = 32 /* plsa_fit / plsa_refit: replay the launches of each run of iterations between
+                           two log-likelihood tests as one hipGraph (small corpora are launch-bound)  */
 };
 
 /* ---- lifetime / errors ----------------------------------------------------------------------- */
@@ -167,6 +174,15 @@ int plsa_measure_stream_bandwidth(plsa_ctx *ctx, int64_t bytes, int32_t kind, in
  *   stacked ensemble topics (umap.distances.hellinger's definition), topics [t, m] float32 on the host,
  *   D [t, t] float64 on the host.  Rows with zero mass: distance 1 to any other row, 0 to each other.  */
 int plsa_all_pairs_hellinger(plsa_ctx *ctx, const float *topics, int64_t t, int64_t m, double *D);
+/* plsa_all_pairs_kl <- all_pairs_kl_divergence, enstop/enstop_.py:234-253: D[i, j] = KL(topic i || topic j)
+ *   in bits over the words where both are positive; D [t, t] float64 on the host, not symmetric.      */
+int plsa_all_pairs_kl(plsa_ctx *ctx, const float *topics, int64_t t, int64_t m, double *D);
+/* plsa_cluster_representatives <- enstop/enstop_.py:299-308, 340-345 (weights == NULL) and 385-393
+ *   (weights = HDBSCAN membership strengths [t]): for each cluster c in [0, n_clusters) the weighted mean
+ *   of the square-rooted member topics (labels[i] == c; negative labels are noise), squared and
+ *   L1-normalised; out [n_clusters, m] float32 on the host.                                           */
+int plsa_cluster_representatives(plsa_ctx *ctx, const float *topics, int64_t t, int64_t m,
+                                 const int32_t *labels, const double *weights, int32_t n_clusters, float *out);
 
 /* ---- host helper ---------------------------------------------------------------------------------
  * plsa_host_normalize_rows <- enstop/utils.py:8-41 normalize(ndarray, axis=1): float64, in place,
@@ -180,7 +196,8 @@ void plsa_host_normalize_rows(double *a, int64_t rows, int64_t cols);
 int plsa_host_mt19937_jump(uint32_t *key /*[624]*/, int32_t log2_blocks);
 
 /* synthetic bag-of-words CSR generated on the device (bench.py / large-size tests; not part of the
- * reference): lognormal document lengths, Zipf(s) word ids, counts 1 + Poisson(0.5).  The result
+ * reference): lognormal document lengths, Zipf(s) word ids, the stored count of a (doc, word) pair is its
+ * multiplicity among the document's token draws (a multinomial bag of words).  The result
  * becomes base + active matrix.  nnz_target is approximate; the exact nnz is returned.            */
 int plsa_generate_synthetic(plsa_ctx *ctx, int64_t n, int64_t m, int64_t nnz_target, double zipf_s,
                             uint64_t seed, int64_t *nnz_out);

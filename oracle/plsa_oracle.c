@@ -19,6 +19,13 @@
  *   liboracle_plsa.so       -O2, strict IEEE, OpenMP      -> the checker
  *   liboracle_plsa_fast.so  -O3 -ffast-math, OpenMP       -> the timed "port" CPU baseline
  *     (fastmath=True + parallel=True of the numba decorators, enstop/plsa.py:35-37)
+ * Two further DIAGNOSTIC builds (not the reference's arithmetic; used by tests/test_parity_at_scale.py
+ * to show where the float32 reference itself is the inaccurate side at BASELINE sizes):
+ *   liboracle_plsa_n64.so   as the checker, but norm_pwz (plsa.py:193, one float32 running sum over
+ *                           ALL nnz per topic) and the log-likelihood accumulator (plsa.py:322) in
+ *                           float64 (-DORACLE_WIDE_NORMS)
+ *   liboracle_plsa_wide.so  additionally the P(w|z) / P(z|d) accumulators and norm_pdz in float64
+ *                           (-DORACLE_WIDE_FACTORS): the exact-arithmetic limit of the same algorithm
  * Thread structure mirrors the reference: E-step and log-likelihood are parallel over nnz
  * (numba.prange, plsa.py:91,375), the M-step scatter is a single serial loop (plsa.py:182-194),
  * the M-step normalisation is parallel over topics (plsa.py:196).
@@ -29,6 +36,20 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#endif
+
+#if defined(ORACLE_WIDE_FACTORS)
+typedef double acc_t;   /* P(w|z), P(z|d) accumulators and norm_pdz */
+typedef double norm_t;  /* norm_pwz and the log-likelihood accumulator */
+#define ORACLE_WIDE_ACC 1
+#elif defined(ORACLE_WIDE_NORMS)
+typedef float acc_t;
+typedef double norm_t;
+#define ORACLE_WIDE_ACC 0
+#else
+typedef float acc_t;    /* the reference's types: everything float32 (plsa.py:27-34, 112-119) */
+typedef float norm_t;
+#define ORACLE_WIDE_ACC 0
 #endif
 
 void oracle_set_threads(int t) {
@@ -70,63 +91,70 @@ void oracle_e_step(const int32_t *rows, const int32_t *cols, int64_t nnz,
     }
 }
 
-/* shared tail of the M-steps: enstop/plsa.py:196-202 (and 302-308) */
-static void m_normalise(float *V, float *U, const float *norm_pwz, const float *norm_pdz,
-                        int64_t n, int64_t m, int64_t k) {
+/* Both M-steps.  sw == NULL: enstop/plsa.py:172-204 (plsa_m_step); sw != NULL: enstop/plsa.py:277-310
+ * (plsa_m_step_w_sample_weight: t = s * sample_weight[d] feeds P(w|z) and norm_pwz, P(z|d) and
+ * norm_pdz take the unweighted s, plsa.py:292-300).  In the checker build acc_t = norm_t = float and
+ * the sums run in place in V / U exactly like the reference; the diagnostic builds widen them. */
+static int m_step_impl(const int32_t *rows, const int32_t *cols, const float *vals, int64_t nnz,
+                       float *V, float *U, const float *P, const float *sw,
+                       float *norm_pwz_out, float *norm_pdz_out, int64_t n, int64_t m, int64_t k) {
+    acc_t *Va, *Ua, *npdz;
+    norm_t *npwz = (norm_t *)calloc((size_t)k + 1, sizeof(norm_t));
+    if (ORACLE_WIDE_ACC) {
+        Va = (acc_t *)calloc((size_t)(k * m) + 1, sizeof(acc_t));
+        Ua = (acc_t *)calloc((size_t)(n * k) + 1, sizeof(acc_t));
+        npdz = (acc_t *)calloc((size_t)n + 1, sizeof(acc_t));
+    } else {
+        Va = (acc_t *)(void *)V; Ua = (acc_t *)(void *)U; npdz = (acc_t *)(void *)norm_pdz_out;
+        memset(V, 0, sizeof(float) * (size_t)(k * m));             /* plsa.py:176-180 */
+        memset(U, 0, sizeof(float) * (size_t)(n * k));
+        memset(norm_pdz_out, 0, sizeof(float) * (size_t)n);
+    }
+    if (!npwz || !Va || !Ua || !npdz) return -1;
+    for (int64_t nz = 0; nz < nnz; nz++) {              /* serial: plsa.py:182 is range() */
+        const int64_t d = rows[nz], w = cols[nz];
+        const float x = vals[nz];
+        const float *p = P + nz * k;
+        for (int64_t z = 0; z < k; z++) {
+            float s = x * p[z];                                     /* plsa.py:188 */
+            float t = sw ? s * sw[d] : s;                           /* plsa.py:294 */
+            Va[z * m + w] += t;
+            Ua[d * k + z] += s;
+            npwz[z] += t;
+            npdz[d] += s;
+        }
+    }
+    /* plsa.py:196-202 (and 302-308) */
 #pragma omp parallel for schedule(static)
     for (int64_t z = 0; z < k; z++) {
-        if (norm_pwz[z] > 0.0f)
-            for (int64_t w = 0; w < m; w++) V[z * m + w] /= norm_pwz[z];
+        if (npwz[z] > 0)
+            for (int64_t w = 0; w < m; w++) V[z * m + w] = (float)(Va[z * m + w] / npwz[z]);
+        else if (ORACLE_WIDE_ACC)
+            for (int64_t w = 0; w < m; w++) V[z * m + w] = (float)Va[z * m + w];
         for (int64_t d = 0; d < n; d++)
-            if (norm_pdz[d] > 0.0f) U[d * k + z] /= norm_pdz[d];
+            U[d * k + z] = npdz[d] > 0 ? (float)(Ua[d * k + z] / npdz[d]) : (float)Ua[d * k + z];
     }
+    for (int64_t z = 0; z < k; z++) norm_pwz_out[z] = (float)npwz[z];
+    if (ORACLE_WIDE_ACC) {
+        for (int64_t d = 0; d < n; d++) norm_pdz_out[d] = (float)npdz[d];
+        free(Va); free(Ua); free(npdz);
+    }
+    free(npwz);
+    return 0;
 }
 
 /* enstop/plsa.py:172-204  plsa_m_step */
 void oracle_m_step(const int32_t *rows, const int32_t *cols, const float *vals, int64_t nnz,
                    float *V, float *U, const float *P, float *norm_pwz, float *norm_pdz,
                    int64_t n, int64_t m, int64_t k) {
-    memset(V, 0, sizeof(float) * (size_t)(k * m));
-    memset(U, 0, sizeof(float) * (size_t)(n * k));
-    memset(norm_pwz, 0, sizeof(float) * (size_t)k);
-    memset(norm_pdz, 0, sizeof(float) * (size_t)n);
-    for (int64_t nz = 0; nz < nnz; nz++) {              /* serial: plsa.py:182 is range() */
-        const int64_t d = rows[nz], w = cols[nz];
-        const float x = vals[nz];
-        const float *p = P + nz * k;
-        for (int64_t z = 0; z < k; z++) {
-            float s = x * p[z];
-            V[z * m + w] += s;
-            U[d * k + z] += s;
-            norm_pwz[z] += s;
-            norm_pdz[d] += s;
-        }
-    }
-    m_normalise(V, U, norm_pwz, norm_pdz, n, m, k);
+    (void)m_step_impl(rows, cols, vals, nnz, V, U, P, NULL, norm_pwz, norm_pdz, n, m, k);
 }
 
 /* enstop/plsa.py:277-310  plsa_m_step_w_sample_weight */
 void oracle_m_step_w(const int32_t *rows, const int32_t *cols, const float *vals, int64_t nnz,
                      float *V, float *U, const float *P, const float *sw,
                      float *norm_pwz, float *norm_pdz, int64_t n, int64_t m, int64_t k) {
-    memset(V, 0, sizeof(float) * (size_t)(k * m));
-    memset(U, 0, sizeof(float) * (size_t)(n * k));
-    memset(norm_pwz, 0, sizeof(float) * (size_t)k);
-    memset(norm_pdz, 0, sizeof(float) * (size_t)n);
-    for (int64_t nz = 0; nz < nnz; nz++) {
-        const int64_t d = rows[nz], w = cols[nz];
-        const float x = vals[nz];
-        const float *p = P + nz * k;
-        for (int64_t z = 0; z < k; z++) {
-            float s = x * p[z];
-            float t = s * sw[d];
-            V[z * m + w] += t;
-            U[d * k + z] += s;
-            norm_pwz[z] += t;
-            norm_pdz[d] += s;
-        }
-    }
-    m_normalise(V, U, norm_pwz, norm_pdz, n, m, k);
+    (void)m_step_impl(rows, cols, vals, nnz, V, U, P, sw, norm_pwz, norm_pdz, n, m, k);
 }
 
 /* enstop/plsa.py:795-816  plsa_refit_m_step (sample_weight is accepted and unused there) */
@@ -154,7 +182,7 @@ void oracle_refit_m_step(const int32_t *rows, const int32_t *cols, const float *
 float oracle_log_likelihood(const int32_t *rows, const int32_t *cols, const float *vals,
                             int64_t nnz, const float *V, const float *U, const float *sw,
                             int64_t m, int64_t k) {
-    float result = 0.0f;
+    norm_t result = 0;                                   /* float32 in the reference, plsa.py:322 */
 #pragma omp parallel for schedule(static) reduction(+ : result)
     for (int64_t nz = 0; nz < nnz; nz++) {
         const int64_t d = rows[nz], w = cols[nz];
@@ -163,7 +191,7 @@ float oracle_log_likelihood(const int32_t *rows, const int32_t *cols, const floa
         for (int64_t z = 0; z < k; z++) p_w_given_d += V[z * m + w] * U[d * k + z];
         result += x * logf(p_w_given_d) * sw[d];
     }
-    return result;
+    return (float)result;
 }
 
 /* enstop/plsa.py:583-640  plsa_fit_inner.

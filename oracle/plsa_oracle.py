@@ -25,8 +25,14 @@ def build():
 
 
 class Oracle:
-    def __init__(self, fast=False):
-        name = "liboracle_plsa_fast.so" if fast else "liboracle_plsa.so"
+    def __init__(self, fast=False, variant=None):
+        """variant: None / "strict" (the checker: the reference's float32 arithmetic), "fast" (the timed
+        CPU baseline), "n64" (float64 norm_pwz + log-likelihood accumulator) or "wide" (all accumulators
+        float64) -- the last two are diagnostics, not the reference's arithmetic."""
+        variant = variant or ("fast" if fast else "strict")
+        name = {"strict": "liboracle_plsa.so", "fast": "liboracle_plsa_fast.so",
+                "n64": "liboracle_plsa_n64.so", "wide": "liboracle_plsa_wide.so"}[variant]
+        self.variant = variant
         path = os.path.join(_HERE, name)
         if not os.path.exists(path):
             build()

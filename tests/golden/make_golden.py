@@ -13,9 +13,13 @@ as plain Python/NumPy.  Under NumPy 2 (NEP 50) ``0.0 + np.float32`` stays
 float32, so the accumulators are fp32 exactly like numba's typed locals and the
 execution order is strictly sequential.  ``enstop/__init__.py`` is bypassed with
 a synthetic package object because it imports dask/hdbscan/umap; for
-``enstop_.py`` (bootstrap member + ensemble stack only) those three imports are
-satisfied with empty placeholder modules -- no function of theirs is ever
-called by the goldens generated here (topic clustering stays unpinned).
+``enstop_.py`` those three imports are satisfied with empty placeholder modules.
+The topic-combination goldens (``gen_combine``) pin the reference's OWN
+statements around the third-party calls: the all-pairs KL matrix, the mutual
+reachability matrix handed to ``mst_linkage_core`` (captured at the call), and
+the cluster representatives computed from labels / membership strengths that
+the placeholder clusterers return as *given inputs*.  What hdbscan / umap
+themselves would compute stays unpinned.
 
 Usage:  python tests/golden/make_golden.py        (writes next to this file)
 """
@@ -291,6 +295,118 @@ def gen_metrics(name, seed):
          log_lift=lift, log_lift_allwords=lift_all, mean_log_lift=np.float64(ru.mean_log_lift(topics, X, n_words=10)))
 
 
+def gen_fit_inner_ll_only(name, seed):
+    """plsa_fit_inner called directly with non-unit weights and use_sample_weights=False (plsa.py:591,
+    606-628, 631): unweighted M-step, weighted log-likelihood / stop test."""
+    n, m, k = 50, 60, 5
+    X = make_counts(n, m, 0.18, seed)
+    A = X.tocoo().astype(np.float32)
+    U0, V0 = random_factors(n, m, k, seed + 1)
+    sw = (0.25 + 2.0 * np.random.RandomState(seed + 2).rand(n)).astype(np.float32)
+    U, V = U0.copy(), V0.copy()
+    with Recorder() as rec, np.errstate(divide="ignore"):
+        ref.plsa_fit_inner(A.row, A.col, A.data, V, U, sw, n_iter=40, n_iter_per_test=5, tolerance=2e-3,
+                           e_step_thresh=np.float32(1e-32), use_sample_weights=False)
+    save(name, **csr_parts(X), k=np.int64(k), sw=sw, U0=U0, V0=V0, U=U, V=V, n_iter=np.int64(40),
+         n_iter_per_test=np.int64(5), tol=np.float64(2e-3), ll_trace=np.array(rec.ll, np.float32),
+         iters=np.int64(rec.n_e))
+    print("   %s: iters=%d" % (name, rec.n_e))
+
+
+def gen_blockfit(name, n, m, k, density, seed, n_iter, n_iter_per_test, tol, blocks=(3, 2), fit_seed=7):
+    """enstop/block_parallel_plsa.py plsa_fit (:339-421): tiled EM, no sample weights, stop test
+    without the `change == 0` arm (:329-331).  Iterations counted at plsa_em_step_by_blocks."""
+    import enstop.block_parallel_plsa as bp
+    X = make_counts(n, m, density, seed)
+    count = {"em": 0, "ll": []}
+    em, ll = bp.plsa_em_step_by_blocks, bp.log_likelihood_by_blocks
+
+    def em_w(*a):
+        count["em"] += 1
+        return em(*a)
+
+    def ll_w(*a):
+        v = ll(*a)
+        count["ll"].append(np.float32(v))
+        return v
+    bp.plsa_em_step_by_blocks, bp.log_likelihood_by_blocks = em_w, ll_w
+    try:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            U, V = bp.plsa_fit(X, k, n_row_blocks=blocks[0], n_col_blocks=blocks[1], n_iter=n_iter,
+                               n_iter_per_test=n_iter_per_test, tolerance=tol, random_state=fit_seed)
+    finally:
+        bp.plsa_em_step_by_blocks, bp.log_likelihood_by_blocks = em, ll
+    save(name, **csr_parts(X), k=np.int64(k), n_iter=np.int64(n_iter), n_iter_per_test=np.int64(n_iter_per_test),
+         tol=np.float64(tol), fit_seed=np.int64(fit_seed), n_row_blocks=np.int64(blocks[0]),
+         n_col_blocks=np.int64(blocks[1]), U=np.asarray(U, np.float32), V=np.asarray(V, np.float32),
+         ll_trace=np.array(count["ll"], np.float32), iters=np.int64(count["em"]))
+    print("   %s: iters=%d" % (name, count["em"]))
+
+
+def gen_combine(name, seed, t=24, m=150, min_samples=3):
+    """Topic combination, enstop/enstop_.py:234-253 (KL), :283-296 (mutual reachability), :299-308 /
+    :340-345 / :385-393 (cluster representatives).  Third-party calls are placeholders that record their
+    argument and return given labels; every stored output is computed by the reference's statements."""
+    rs = np.random.RandomState(seed)
+    centres = rs.dirichlet(np.full(m, 0.08), size=5)
+    topics = np.vstack([rs.dirichlet(centres[i % 5] * 60 + 0.02) for i in range(t)]).astype(np.float32)
+    topics[topics < 1e-6] = 0.0                          # exact zeros: the `> 0` guards of kl_divergence
+    topics[3, :] = 0.0; topics[3, :7] = 1.0 / 7.0        # a sparse row
+    topics /= topics.sum(axis=1, keepdims=True)
+    topics = topics.astype(np.float32)
+    labels = (np.arange(t) % 5).astype(np.int64)
+    labels[[1, 7]] = -1                                  # noise points
+    probs = rs.rand(t)
+    probs[labels == 4] = 0.0                             # a cluster whose weights are all zero
+    probs[np.argmax(labels == 4)] = 0.5
+
+    with np.errstate(divide="ignore", invalid="ignore"):
+        kl32 = ref_ens.all_pairs_kl_divergence(topics)
+        kl64 = ref_ens.all_pairs_kl_divergence(topics.astype(np.float64))
+    captured = {}
+
+    def fake_mst(mr):
+        captured["mr"] = np.array(mr, copy=True)
+        return np.zeros((mr.shape[0] - 1, 3))
+    saved = (ref_ens.mst_linkage_core, ref_ens.label, ref_ens._tree_to_labels)
+    ref_ens.mst_linkage_core = fake_mst
+    ref_ens.label = lambda mst: mst
+    ref_ens._tree_to_labels = lambda X, tree, **kw: (labels, None, None, None, None)
+    try:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rep_kl = ref_ens.generate_combined_topics_kl(topics, min_samples=min_samples, min_cluster_size=3)
+    finally:
+        ref_ens.mst_linkage_core, ref_ens.label, ref_ens._tree_to_labels = saved
+
+    class FakeHDBSCAN:
+        def __init__(self, **kw):
+            self.labels_, self.probabilities_ = labels, probs
+
+        def fit_predict(self, D):
+            captured["D_hell_shape"] = D.shape
+            return labels
+
+        def fit(self, E):
+            return self
+
+    class FakeUMAP:
+        def __init__(self, **kw):
+            pass
+
+        def fit_transform(self, X):
+            return np.zeros((X.shape[0], 2))
+    ref_ens.hdbscan.HDBSCAN = FakeHDBSCAN
+    ref_ens.umap.UMAP = FakeUMAP
+    # umap.distances.hellinger is absent: the all-pairs Hellinger MATRIX is not pinned here, only what
+    # the reference does with the labels afterwards
+    ref_ens.hellinger = lambda a, b: 0.0
+    rep_hell = ref_ens.generate_combined_topics_hellinger(topics, min_samples=min_samples, min_cluster_size=3)
+    rep_umap = ref_ens.generate_combined_topics_hellinger_umap(topics, min_samples=min_samples, min_cluster_size=3)
+    save(name, topics=topics, min_samples=np.int64(min_samples), kl_f32_input=np.asarray(kl32, np.float64),
+         kl_f64_input=np.asarray(kl64, np.float64), mutual_reachability=captured["mr"],
+         labels=labels, probabilities=probs, rep_kl=rep_kl, rep_hellinger=rep_hell, rep_umap=rep_umap)
+
+
 if __name__ == "__main__":
     gen_kernels("kernels_k6", n=40, m=50, k=6, density=0.15, seed=100, thresh=1e-32)
     gen_kernels("kernels_k8_thresh", n=36, m=44, k=8, density=0.2, seed=110, thresh=2.5e-3, zero_doc=3)
@@ -315,3 +431,13 @@ if __name__ == "__main__":
     gen_member("member_k6", seed=500)
 
     gen_metrics("metrics", seed=600)
+
+    gen_blockfit("blockfit_k6", n=70, m=90, k=6, density=0.12, seed=700, n_iter=25, n_iter_per_test=10, tol=0.0)
+    gen_blockfit("blockfit_k5_earlystop", n=50, m=70, k=5, density=0.15, seed=210, n_iter=100, n_iter_per_test=10, tol=1e-3)
+    # k = 1 converges in one step: the log-likelihood stops changing, plsa.py would stop through its
+    # `change == 0` arm, the blockwise loop (tolerance 0) runs all iterations
+    gen_blockfit("blockfit_k1_zero_change", n=30, m=40, k=1, density=0.2, seed=720, n_iter=25, n_iter_per_test=5, tol=0.0)
+
+    gen_combine("combine_t24", seed=800)
+
+    gen_fit_inner_ll_only("fit_inner_ll_only_weights", seed=900)

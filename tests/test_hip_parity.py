@@ -885,14 +885,156 @@ def test_randomised_shapes_vs_oracle(amd, oracle):
         for name, mode in MODES.items():
             U, V, info = amd.plsa_fit(X, k, sw, flags=mode, return_info=True, **kw)
             msg = "case %d (%s): n=%d m=%d k=%d dens=%g thresh=%g %r" % (case, name, n, m, k, dens, thresh, kw)
-            fin = np.isfinite(trace)
-            if not np.all(fin[:2]) or info["n_iter"] != iters:
-                # a -inf likelihood (thresholding) makes the stop test a comparison of infinities on
-                # both sides; the factors below are still compared
-                assert abs(info["n_iter"] - iters) <= kw["n_iter"], msg
+            # tolerance = 0: the loop can only stop through the `change == 0` arm (plsa.py:635), i.e. when
+            # two successive float32 log-likelihoods are bit-equal.  That decision must agree with the
+            # oracle's except for the cases listed in ZERO_CHANGE_FLIPS (converged fits whose likelihood
+            # sits on a float32 rounding boundary: HIP accumulates it in float64, the reference in
+            # float32); for those the converged factors must still agree.
+            if info["n_iter"] != iters:
+                assert (case, name) in ZERO_CHANGE_FLIPS, "iteration count %d != %d: %s" % (info["n_iter"], iters, msg)
             else:
-                q = min(len(trace), len(info["log_likelihood_trace"]))
-                close_ll(info["log_likelihood_trace"][:q], trace[:q])
-            if info["n_iter"] == iters:
-                assert np.abs(U - Uo).max() <= 1e-4 * max(Uo.max(), 1e-30), msg
-                assert np.abs(V - Vo).max() <= 1e-4 * max(Vo.max(), 1e-30), msg
+                assert (case, name) not in ZERO_CHANGE_FLIPS, "listed as a flip but agrees: " + msg
+                close_ll(info["log_likelihood_trace"], trace)
+            assert np.abs(U - Uo).max() <= 1e-4 * max(Uo.max(), 1e-30), msg
+            assert np.abs(V - Vo).max() <= 1e-4 * max(Vo.max(), 1e-30), msg
+
+
+# (case index, schedule) pairs of test_randomised_shapes_vs_oracle whose `change == 0` stop decision differs
+# from the float32 oracle's (see the comment there); established on MI355X, must stay short
+ZERO_CHANGE_FLIPS = set()
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: semantics of the reference's other fit loops, topic combination, edge cases
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("case", ["blockfit_k6", "blockfit_k5_earlystop", "blockfit_k1_zero_change"])
+def test_block_parallel_fit_vs_reference(amd, case, mode):
+    """enstop/block_parallel_plsa.py plsa_fit (:339-421) run by the reference itself on 3 x 2 tiles:
+    no sample weights, stop test without the `change == 0` arm (:329-331)."""
+    from enstop_amd.block_parallel_plsa import plsa_fit as block_fit
+    g = load_golden(case)
+    X = golden_csr(g)
+    U, V, info = block_fit(X, int(g["k"]), n_row_blocks=int(g["n_row_blocks"]), n_col_blocks=int(g["n_col_blocks"]),
+                           n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]),
+                           tolerance=float(g["tol"]), random_state=int(g["fit_seed"]), flags=MODES[mode],
+                           return_info=True)
+    assert info["n_iter"] == int(g["iters"])
+    close_factors(U, g["U"]); close_factors(V, g["V"])
+    close_ll(info["log_likelihood_trace"][:len(g["ll_trace"])], g["ll_trace"], rtol=2e-5)
+    if case == "blockfit_k1_zero_change":
+        # plsa.py's loop stops on the same corpus through its `change == 0` arm
+        _, _, info2 = amd.plsa_fit(X, 1, np.ones(X.shape[0], np.float32), n_iter=int(g["n_iter"]),
+                                   n_iter_per_test=int(g["n_iter_per_test"]), tolerance=0.0,
+                                   random_state=int(g["fit_seed"]), flags=MODES[mode], return_info=True)
+        assert info2["n_iter"] < info["n_iter"]
+
+
+def test_block_parallel_estimator_ignores_sample_weight(amd):
+    g = load_golden("blockfit_k6")
+    X = golden_csr(g).astype(np.int64)
+    kw = dict(n_components=int(g["k"]), n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]),
+              tolerance=float(g["tol"]), random_state=int(g["fit_seed"]))
+    sw = np.linspace(0.2, 3.0, X.shape[0])
+    a = amd.BlockParallelPLSA(**kw).fit(X, sample_weight=sw)
+    close_factors(a.embedding_, g["U"]); close_factors(a.components_, g["V"])
+    b = amd.PLSA(**kw).fit(X, sample_weight=sw)                     # plsa.py DOES use the weights
+    assert np.abs(b.components_ - a.components_).max() > 1e-3 * a.components_.max()
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_fit_inner_weights_in_likelihood_only(amd, mode):
+    """plsa_fit_inner(use_sample_weights=False) with non-unit weights (plsa.py:591, 606-628, 631)."""
+    g = load_golden("fit_inner_ll_only_weights")
+    r, c, v = coo_arrays(golden_csr(g))
+    U, V = g["U0"].copy(), g["V0"].copy()
+    amd.plsa_fit_inner(r, c, v, V, U, g["sw"], n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]),
+                       tolerance=float(g["tol"]), e_step_thresh=1e-32, use_sample_weights=False, flags=MODES[mode])
+    close_factors(U, g["U"]); close_factors(V, g["V"])
+    # the weighted likelihood decides the stop: the engine must report the reference's iteration count
+    eng = amd.engine.get_engine()
+    from enstop_amd.engine import PLSA_SW_LL_ONLY
+    eng.upload_csr(golden_csr(g)); eng.set_factors(g["U0"], g["V0"])
+    iters, trace = eng.fit(g["sw"], int(g["n_iter"]), int(g["n_iter_per_test"]), float(g["tol"]), 1e-32,
+                           MODES[mode] | PLSA_SW_LL_ONLY, trace=True)
+    assert iters == int(g["iters"])
+    close_ll(trace[:len(g["ll_trace"])], g["ll_trace"])
+
+
+def test_streamed_transform_takes_sample_weight(amd):
+    """streamed_plsa.py:1237 transform(X, y=None, sample_weight=None)."""
+    g = load_golden("estimator_int")
+    X = golden_csr(g).astype(np.int64)
+    model = amd.StreamedPLSA(n_components=int(g["k"]), n_iter=30, n_iter_per_test=10, tolerance=0.0, random_state=11).fit(X)
+    Xt = sp.csr_matrix((g["t_data"], g["t_indices"], g["t_indptr"]), shape=tuple(g["t_shape"]))
+    a = model.transform(Xt)
+    b = model.transform(Xt, sample_weight=np.linspace(0.5, 2.0, Xt.shape[0]))
+    close_factors(a, g["transformed"])
+    close_factors(b, g["transformed"])
+
+
+def test_device_all_pairs_kl_vs_reference(amd):
+    """plsa_all_pairs_kl against all_pairs_kl_divergence run by the reference (enstop_.py:234-253)."""
+    g = load_golden("combine_t24")
+    D = amd.engine.get_engine().all_pairs_kl(g["topics"])
+    scale = np.abs(g["kl_f64_input"]).max()
+    assert np.abs(D - g["kl_f64_input"]).max() <= 2e-6 * scale      # exact-arithmetic golden (float64 input)
+    assert np.abs(D - g["kl_f32_input"]).max() <= 1e-5 * scale      # the reference's float32-input result
+    assert np.all(np.diag(D) == 0.0)
+    # a bigger, ragged case against the float64 definition: t not a multiple of the tile, zero entries
+    rs = np.random.RandomState(5)
+    T = rs.dirichlet(np.full(3001, 0.05), size=150).astype(np.float32)
+    T[T < 1e-7] = 0.0
+    T[7] = 0.0
+    from enstop_amd.ensemble import all_pairs_kl_divergence
+    ref = all_pairs_kl_divergence(T)
+    got = amd.engine.get_engine().all_pairs_kl(T)
+    assert np.abs(got - ref).max() <= 5e-6 * np.abs(ref).max()
+
+
+def test_device_cluster_representatives_vs_reference(amd):
+    """plsa_cluster_representatives against the reference's statements (enstop_.py:299-308, 385-393)."""
+    g = load_golden("combine_t24")
+    eng = amd.engine.get_engine()
+    for key, w in (("rep_kl", None), ("rep_hellinger", None), ("rep_umap", g["probabilities"])):
+        R = eng.cluster_representatives(g["topics"], g["labels"], w)
+        assert R.shape == g[key].shape and R.dtype == np.float32
+        np.testing.assert_allclose(R, g[key], rtol=2e-6, atol=1e-12)
+
+
+def test_kl_topic_combination_follows_reference_pipeline(amd):
+    """generate_combined_topics_kl: device KL -> the reference's mutual reachability (golden) -> MST /
+    single linkage / leaf labels -> device representatives; agrees with the all-host evaluation."""
+    from enstop_amd import ensemble as E
+    g = load_golden("combine_t24")
+    eng = amd.engine.get_engine()
+    mr = E.mutual_reachability_from_divergences(g["kl_f32_input"], int(g["min_samples"]))
+    np.testing.assert_array_equal(mr, g["mutual_reachability"])
+    on_device = E.generate_combined_topics_kl(g["topics"], int(g["min_samples"]), 3, engine=eng)
+    on_host = E.generate_combined_topics_kl(g["topics"], int(g["min_samples"]), 3)
+    assert on_device.shape == on_host.shape and on_device.shape[0] >= 2
+    np.testing.assert_allclose(on_device, on_host, rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_zero_threshold_with_denormal_products(amd, oracle, mode):
+    """e_step_thresh = 0 keeps every positive product, so a responsibility norm can be denormal; the
+    reference divides (every quotient <= 1), a plain reciprocal would overflow (plsa.py:98-105)."""
+    rs = np.random.RandomState(3)
+    n, m, k = 40, 30, 8
+    X = sp.random(n, m, density=0.3, format="csr", random_state=rs, dtype=np.float32)
+    X.data = np.ceil(X.data * 3).astype(np.float32)
+    U0 = rs.rand(n, k).astype(np.float32); V0 = rs.rand(k, m).astype(np.float32)
+    U0[:10] *= np.float32(1e-24); V0[:, :8] *= np.float32(1e-20)    # products ~1e-44: denormal
+    U0[10:] /= U0[10:].sum(1, keepdims=True)
+    V0 /= V0.sum(1, keepdims=True)
+    r, c, v = coo_arrays(X)
+    ones = np.ones(n, np.float32)
+    Uo, Vo = U0.copy(), V0.copy()
+    with np.errstate(all="ignore"):
+        oracle.plsa_fit_inner(r, c, v, Vo, Uo, ones, n_iter=3, n_iter_per_test=10, tolerance=0.0, e_step_thresh=0.0)
+    U, V = U0.copy(), V0.copy()
+    amd.plsa_fit_inner(r, c, v, V, U, ones, n_iter=3, n_iter_per_test=10, tolerance=0.0, e_step_thresh=0.0,
+                       flags=MODES[mode])
+    assert np.all(np.isfinite(U)) and np.all(np.isfinite(V))
+    close_factors(U, Uo, tol=2e-4); close_factors(V, Vo, tol=2e-4)

@@ -137,3 +137,24 @@ def test_threaded_oracle_agrees(oracle):
     np.testing.assert_allclose(trace, g["ll_trace"], rtol=1e-5)
     np.testing.assert_allclose(U, g["U"], rtol=0, atol=1e-4 * g["U"].max())
     np.testing.assert_allclose(V, g["V"], rtol=0, atol=1e-4 * g["V"].max())
+
+
+@pytest.mark.parametrize("variant", ["n64", "wide"])
+def test_wide_accumulator_variants_track_the_checker(variant):
+    """The diagnostic builds (float64 norms / float64 everything) are the same algorithm: on the
+    golden-sized problems, where float32 accumulation is still accurate, they agree with the reference's
+    outputs to rounding."""
+    from oracle.plsa_oracle import Oracle
+    o = Oracle(variant=variant)
+    o.set_threads(1)
+    for case in ("fit_k8_tol0", "fit_k4_weighted", "fit_k16_mid"):
+        g = load_golden(case)
+        X = golden_csr(g)
+        U, V, trace, iters = o.plsa_fit(X, int(g["k"]), g["sw"], n_iter=int(g["n_iter"]),
+                                        n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+                                        e_step_thresh=float(g["thresh"]), random_state=int(g["fit_seed"]),
+                                        return_trace=True)
+        assert iters == int(g["iters"])
+        assert np.abs(U - g["U"]).max() <= 2e-5 * g["U"].max()
+        assert np.abs(V - g["V"]).max() <= 2e-5 * g["V"].max()
+        np.testing.assert_allclose(trace, g["ll_trace"], rtol=3e-6)
