@@ -5,10 +5,18 @@
 
 A "step" is one EM iteration (E-step + M-step, plus the log-likelihood test at the reference's
 schedule, plsa.py:630) over the whole synthetic corpus, driven through the C ABI (plsa_fit).
-N = 1 : one fit on the corpus.   N > 1 : the ensemble path -- one process per GPU (torchrun), rank r
-fits bootstrap member r of the same corpus (device-side row gather), no collective on the EM path,
-one RCCL all-gather of the topic matrices at the end (inside the timed region).  `value` is the
-whole-job aggregate: (N * K) EM iterations / max-over-ranks wall time.
+N = 1 : one fit on the corpus.   N > 1 : the ensemble path -- one process per GPU, rank r fits
+bootstrap member r of the same corpus (device-side row gather), no collective on the EM path, one RCCL
+all-gather of the topic matrices at the end (inside the timed region; ncclAllGather issued from the C
+ABI, plsa_comm_allgather_components -- no PyTorch in the process).  `value` is the whole-job aggregate:
+(N * K) EM iterations / max-over-ranks wall time.
+
+Launching N > 1: either an external launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (the driver's
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`), or plain
+`python bench.py --gpus N`, which spawns the N ranks itself.  Either way the ranks meet through a file
+that carries the 128-byte RCCL unique id (enstop_amd/comm.py).  If fewer than N GPUs are visible, or RCCL
+cannot be brought up, the run FAILS (non-zero exit status, no JSON line); `--exchange files` is a test
+mode for single-GPU boxes (ranks share the GPU, host-file exchange) and says so in the JSON.
 
 Inputs are generated in HBM before the timed region (plsa_generate_synthetic); factors are
 initialised on the host exactly as plsa_init does and uploaded before the timed region.
@@ -20,12 +28,21 @@ Extra objects in the JSON line:
                 the reference's own kernel sequence (E-step -> M-step -> LL) on the same data
   roofline_dominant_fused   same figures for the dominant kernel of the main (fused) timed region
   cpu_baseline  the CPU port (oracle/plsa_oracle.c, -O3 -ffast-math, OpenMP, reference thread
-                structure) timed on a bounded row-sample of the same corpus, rank 0 / N = 1 only
+                structure) timed on a bounded row-sample of the same corpus ("sampled": true), rank 0 /
+                N = 1 only; next to it `whole_config2`: the same port on the WHOLE of BASELINE configs[1]
+  roofline.traffic   HBM-side bytes per launch from rocprofv3 PMC passes run by this script itself
+                (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md)
+                when rocprofv3 is available; otherwise the committed profile's figure, labelled as such
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -75,8 +92,10 @@ def init_factors(n, m, k, seed):
     return U.astype(np.float32), V.astype(np.float32)
 
 
-def cpu_baseline(eng, cfg, k, budget_cells=1.2e9, iters=3):
-    """Reference-structure CPU port on the first rows of the same corpus, all host cores."""
+def cpu_baseline(eng, cfg, k, budget_cells=1.2e9, iters=3, whole=False):
+    """Reference-structure CPU port (the only place of this script that touches oracle/), all host cores.
+    whole=False: on the first rows of the corpus resident on `eng`, bounded to ~budget_cells cells per
+    iteration, scaled by the nnz fraction ("sampled": true).  whole=True: on the whole corpus, no scaling."""
     from oracle.plsa_oracle import Oracle
     o = Oracle(fast=True)
     cores = os.cpu_count() or 1
@@ -85,7 +104,7 @@ def cpu_baseline(eng, cfg, k, budget_cells=1.2e9, iters=3):
     n, m = A.shape
     nnz_full = A.nnz
     target_nnz = int(budget_cells / k)
-    rows = int(min(n, max(1000, np.searchsorted(A.indptr, target_nnz))))
+    rows = n if whole else int(min(n, max(1000, np.searchsorted(A.indptr, target_nnz))))
     S = A[:rows]
     Ac = S.tocoo()
     r, c, v = (np.ascontiguousarray(Ac.row, np.int32), np.ascontiguousarray(Ac.col, np.int32),
@@ -96,10 +115,14 @@ def cpu_baseline(eng, cfg, k, budget_cells=1.2e9, iters=3):
     _, _, _, done = o.plsa_fit_inner(r, c, v, V, U, sw, n_iter=iters, n_iter_per_test=10, tolerance=0.0,
                                      e_step_thresh=1e-32, use_sample_weights=False, return_trace=True)
     dt = time.perf_counter() - t0
+    if whole:
+        return {"value": round(done / dt, 4), "unit": "iter/s", "cores": cores, "kind": "port", "sampled": False,
+                "sample": "whole corpus (%d docs, %d nnz), %d EM iterations in %.2f s" % (n, A.nnz, done, dt),
+                "gcell_per_s": round(A.nnz * k * done / dt / 1e9, 4)}
     frac = S.nnz / nnz_full
     return {
         "value": round(done / dt * frac, 5), "unit": "iter/s (full-corpus equivalent)", "cores": cores,
-        "kind": "port",
+        "kind": "port", "sampled": True,
         "sample": "first %d docs (%d nnz = %.3f of the corpus, full %d-word vocabulary), %d EM iterations in %.2f s; "
                   "iterations/s on the sample x nnz fraction" % (rows, S.nnz, frac, m, done, dt),
         "sample_iter_per_s": round(done / dt, 4),
@@ -107,7 +130,7 @@ def cpu_baseline(eng, cfg, k, budget_cells=1.2e9, iters=3):
     }
 
 
-def quick_config(eng, cfg_id, steps, warmup, seed):
+def quick_config(eng, cfg_id, steps, warmup, seed, with_cpu=False):
     """Compact measurement of another BASELINE.json config on the same device (N = 1 only): fused EM
     iterations/s and the materialising E-step's roofline fraction, same method as the main legs."""
     from enstop_amd.engine import PLSA_FUSED
@@ -131,10 +154,126 @@ def quick_config(eng, cfg_id, steps, warmup, seed):
     ms, cnt = eng.timing_get("k_e_step")
     eng.timing(False)
     b = algorithmic_bytes("e_step", n, m, nnz, k)
-    return {"workload": cfg["name"], "nnz": nnz, "k": k, "steps": it, "value": round(it / dt, 2), "unit": "iter/s",
-            "ms_per_step": round(dt / it * 1e3, 4),
-            "e_step": {"avg_launch_ms": round(ms / cnt, 5), "achieved_GBps": round(b / 1e9 / (ms / cnt / 1e3), 1),
-                       "frac": round(b / 1e9 / (ms / cnt / 1e3) / HBM_PEAK_GBS, 4)}}
+    out = {"workload": cfg["name"], "nnz": nnz, "k": k, "steps": it, "value": round(it / dt, 2), "unit": "iter/s",
+           "ms_per_step": round(dt / it * 1e3, 4),
+           "e_step": {"avg_launch_ms": round(ms / cnt, 5), "achieved_GBps": round(b / 1e9 / (ms / cnt / 1e3), 1),
+                      "frac": round(b / 1e9 / (ms / cnt / 1e3) / HBM_PEAK_GBS, 4)}}
+    if with_cpu:
+        try:
+            out["cpu_baseline"] = cpu_baseline(eng, cfg, k, whole=True)
+        except Exception as e:
+            out["cpu_baseline"] = "failed: %r" % (e,)
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without an external launcher: start the N ranks ourselves (one process
+    per GPU), give them a private rendezvous file for the RCCL unique id, relay rank 0's JSON line."""
+    tmpdir = tempfile.mkdtemp(prefix="plsa_bench_")
+    base = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT="0",
+                PLSA_COMM_ID_FILE=os.path.join(tmpdir, "rccl.id"), PLSA_BENCH_FILES_DIR=os.path.join(tmpdir, "x"),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        deadline = time.time() + float(os.environ.get("PLSA_BENCH_SPAWN_TIMEOUT", "3000"))
+        pending = list(procs)
+        while pending:
+            for p_ in list(pending):
+                code = p_.poll()
+                if code is not None:
+                    pending.remove(p_)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        for q in pending:           # one rank died: the others would wait in a collective forever
+                            q.terminate()
+            if time.time() > deadline:
+                rc = rc or 124
+                for q in pending:
+                    q.kill()
+                break
+            time.sleep(0.05)
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    return rc
+
+
+def pmc_child(args):
+    """Short run for the counter passes (`rocprofv3 --pmc ... -- python bench.py --pmc-child`): the same
+    corpus and factors, two launches of the materialising E-step and two fused EM iterations."""
+    from enstop_amd.engine import Engine, PLSA_FUSED
+    cfg = CONFIGS[args.config]
+    eng = Engine(0)
+    eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], zipf_s=1.07, seed=args.seed)
+    U0, V0 = init_factors(cfg["n"], cfg["m"], cfg["k"], 42)
+    eng.set_factors(U0, V0)
+    eng.fit(None, n_iter=2, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=PLSA_FUSED)
+    for _ in range(2):
+        eng.e_step(1e-32, want_host_copy=False)
+    eng.synchronize()
+    eng.close()
+
+
+def short_kernel_name(k):
+    """rocprofv3 kernel name -> the engine's timing name (k_e_step_rows / k_e_step -> k_e_step, ...)."""
+    k = k.replace("void ", "")
+    if "k_e_step" in k:
+        return "k_e_step"
+    for base in ("k_row_pass", "k_col_pass"):
+        if base in k:
+            targs = k[k.index(base):]
+            if base == "k_col_pass":
+                return "k_col_pass<P>" if ", true>" in targs.split("(")[0] else "k_col_pass<fused>"
+            head = targs.split("(")[0]
+            if ", true, false>" in head:
+                return "k_row_pass<P>"
+            return "k_row_pass<fused,LL>" if ", false, true>" in head else "k_row_pass<fused>"
+    return None
+
+
+def measure_traffic(args):
+    """HBM-side bytes per launch of the hot kernels, measured now: two rocprofv3 passes (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots') over --pmc-child.
+    Returns {kernel: {fetch_size_kib_raw, write_size_kib_raw, hbm_bytes_per_launch}} or None."""
+    exe = shutil.which("rocprofv3")
+    if exe is None or os.environ.get("PLSA_BENCH_NO_PMC", "0") == "1":
+        return None
+    raw = {}
+    tmpdir = tempfile.mkdtemp(prefix="plsa_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmpdir, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "b", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(args.config),
+                   "--seed", str(args.seed)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=float(os.environ.get("PLSA_BENCH_PMC_TIMEOUT", "420")), check=True)
+            agg = {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = short_kernel_name(row.get("Kernel_Name", ""))
+                    if name is None or row.get("Counter_Name") != counter:
+                        continue
+                    n_, v_ = agg.get(name, (0, 0.0))
+                    agg[name] = (n_ + 1, v_ + float(row["Counter_Value"]))
+            for name, (n_, v_) in agg.items():
+                raw.setdefault(name, {})[counter] = v_ / n_
+    except Exception as e:                                # never cost the measurement
+        print("bench.py: PMC passes failed (%r); traffic falls back to the committed profile" % (e,), file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    table = {}
+    for name, d in raw.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            # FETCH_SIZE / WRITE_SIZE are reported in KiB; gfx950 tallies a 128-B read request as 64 B
+            table[name] = {"fetch_size_kib_raw": d["FETCH_SIZE"], "write_size_kib_raw": d["WRITE_SIZE"],
+                           "hbm_bytes_per_launch": int((2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)}
+    return table or None
 
 
 def main():
@@ -146,8 +285,17 @@ def main():
     ap.add_argument("--schedule", default=os.environ.get("PLSA_BENCH_SCHEDULE", "fused"),
                     choices=["fused", "materialised"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "files"],
+                    help="files: TEST MODE for boxes with fewer GPUs than ranks (host-file exchange, shared GPUs)")
+    ap.add_argument("--graph", action="store_true", help="replay each run of iterations as a hipGraph (PLSA_GRAPH)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     # Only the JSON line may reach stdout: route file descriptor 1 to stderr for the whole run (RCCL and
     # the HIP runtime print banners from C) and write the result to the saved descriptor at the end.
@@ -158,48 +306,45 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    torch = None
-    backend = None
-    force_dist = os.environ.get("PLSA_BENCH_FORCE_DIST", "0") == "1"   # exercise the RCCL path with 1 rank
-    if world > 1 or force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        # torch first: its HIP runtime / RCCL are then the ones libplsa_hip.so binds to
-        import torch
-        import torch.distributed as dist
-        if local_rank >= torch.cuda.device_count():      # launcher restricted the visible devices
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        try:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-            probe = torch.ones(1, device="cuda")
-            dist.all_reduce(probe)                        # forces communicator creation now
-            torch.cuda.synchronize()
-            backend = "nccl"
-        except Exception as e:                            # keep the measurement alive: control plane
-            print("bench.py: RCCL init failed (%r); falling back to gloo for barrier/gather" % (e,),
-                  file=sys.stderr)                        # over gloo, topics gathered through the host
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            backend = "gloo"
-    n_gpus = world if world > 1 else 1
-    if args.gpus != n_gpus and rank == 0:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torchrun for N > 1" % (args.gpus, world),
-              file=sys.stderr)
+    if args.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
 
-    from enstop_amd.engine import Engine, PLSA_FUSED
+    from enstop_amd import _lib, comm as plsa_comm
+    from enstop_amd.engine import Engine, PLSA_FUSED, PLSA_GRAPH
+    import ctypes
+    cnt = ctypes.c_int(0)
+    if _lib.load().plsa_device_count(ctypes.byref(cnt)) or cnt.value < 1:
+        print("bench.py: no HIP device visible", file=sys.stderr)
+        sys.exit(3)
+    n_dev = cnt.value
+    if world > 1 and args.exchange == "rccl" and n_dev < world and n_dev != 1:
+        print("bench.py: %d ranks but only %d GPUs visible" % (world, n_dev), file=sys.stderr)
+        sys.exit(3)
+    if world > 1 and args.exchange == "rccl" and n_dev == 1 and local_rank > 0 and "HIP_VISIBLE_DEVICES" not in os.environ \
+            and "ROCR_VISIBLE_DEVICES" not in os.environ:
+        print("bench.py: %d ranks need %d GPUs, 1 visible (use --exchange files to test on a shared GPU)"
+              % (world, world), file=sys.stderr)
+        sys.exit(3)
+    device = local_rank if local_rank < n_dev else local_rank % n_dev
+
     cfg = CONFIGS[args.config]
     n, m, k = cfg["n"], cfg["m"], cfg["k"]
-    flags = PLSA_FUSED if args.schedule == "fused" else 0
+    flags = (PLSA_FUSED if args.schedule == "fused" else 0) | (PLSA_GRAPH if args.graph else 0)
 
-    eng = Engine(local_rank)
+    eng = Engine(device)
     info = eng.device_info()
+    comm = plsa_comm.SingleComm()
+    if world > 1:
+        if args.exchange == "rccl":
+            # any failure here (duplicate GPU, bootstrap, ...) raises: non-zero exit status, no JSON line
+            comm = plsa_comm.init_from_env(eng)
+        else:
+            comm = plsa_comm.install(plsa_comm.FileComm(os.environ.get("PLSA_BENCH_FILES_DIR", "/tmp/plsa_bench_x"),
+                                                        rank, world))
     t_gen = time.perf_counter()
     nnz = eng.generate_synthetic(n, m, cfg["nnz"], zipf_s=1.07, seed=args.seed)
-    if dist is not None:  # ensemble member `rank`: bootstrap rows on the device (enstop_.py:87-88)
+    if world > 1:  # ensemble member `rank`: bootstrap rows on the device (enstop_.py:87-88)
         idx = np.random.RandomState(args.seed + 1000 + rank).randint(0, n, size=n)
         eng.bootstrap(idx)
     n_act, m_act, nnz_act = eng.shape
@@ -209,30 +354,16 @@ def main():
 
     def barrier():
         eng.synchronize()
-        if dist is not None:
-            if backend == "nccl":
-                torch.cuda.synchronize()
-            dist.barrier()
-
-    gather_buf = None
-    if dist is not None:
-        dev = "cuda" if backend == "nccl" else "cpu"
-        gather_buf = (torch.empty((k, m), dtype=torch.float32, device=dev),
-                      torch.empty((world, k, m), dtype=torch.float32, device=dev))
+        comm.barrier()
 
     def gather_components():
-        """the np.vstack of enstop_.py:231 as one all-gather of the (k, m) topic matrices"""
-        if dist is None:
-            return
-        send, recv = gather_buf
-        if backend == "nccl":
-            eng.copy_components_to_device(send.data_ptr())        # D2D into the RCCL send buffer
-            dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
-            torch.cuda.synchronize()
-        else:
-            _, V = eng.get_factors(want_u=False)
-            send.copy_(torch.from_numpy(V))
-            dist.all_gather(list(recv.unbind(0)), send)
+        """the np.vstack of enstop_.py:231 as one all-gather of the (k, m) topic matrices; the stack
+        lands in host memory on rank 0 (where the reference's single process holds it)"""
+        if world == 1:
+            return None
+        if isinstance(comm, plsa_comm.RcclComm):
+            return eng.comm_allgather_components(want_host=(rank == 0))
+        return comm.allgather_components(eng)
 
     # ---- warmup (untimed): W EM iterations + the collective --------------------------------------
     if args.warmup > 0:
@@ -246,33 +377,29 @@ def main():
     barrier()
     t0 = time.perf_counter()
     it, _ = eng.fit(None, n_iter=args.steps, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=flags)
-    gather_components()
+    stack = gather_components()
     barrier()
     dt = time.perf_counter() - t0
     assert it == args.steps, "early stop inside the timed region (%d of %d)" % (it, args.steps)
     report = eng.timing_report()
     eng.timing(False)
+    if stack is not None and rank == 0:
+        assert stack.shape == (world, k, m) and np.all(np.isfinite(stack))
+        _, V_mine = eng.get_factors(want_u=False)
+        assert np.array_equal(stack[0], V_mine), "all-gather slot 0 is not rank 0's topic matrix"
 
-    if dist is not None:
-        rdev = "cuda" if backend == "nccl" else "cpu"
-        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tot = torch.tensor([float(nnz_act)], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        nnz_total = float(tot.item())
-    else:
-        nnz_total = float(nnz_act)
+    dt = float(comm.allreduce_f64([dt], "max")[0])
+    nnz_total = float(comm.allreduce_f64([float(nnz_act)], "sum")[0])
 
     # ---- per-kernel roofline figures from the HIP events of the timed region ----------------------
     kernels = {}
-    for name, (cnt, ms) in report.items():
+    for name, (cnt_, ms) in report.items():
         kind = KERNEL_KIND.get(name)
-        entry = {"launches": cnt, "avg_ms": round(ms / cnt, 5), "total_ms": round(ms, 4)}
+        entry = {"launches": cnt_, "avg_ms": round(ms / cnt_, 5), "total_ms": round(ms, 4)}
         if kind:
             b = algorithmic_bytes(kind, n_act, m, nnz_act, k)
             entry["algorithmic_GB"] = round(b / 1e9, 4)
-            entry["GBps"] = round(b / 1e9 / (ms / cnt / 1e3), 1)
+            entry["GBps"] = round(b / 1e9 / (ms / cnt_ / 1e3), 1)
         kernels[name] = entry
     dom = max((kv for kv in kernels.items() if "GBps" in kv[1]), key=lambda kv: kv[1]["total_ms"])
 
@@ -301,28 +428,33 @@ def main():
         rep2 = eng.timing_report()
         eng.timing(False)
         kernels_mat = {}
-        for name, (cnt, ms) in rep2.items():
+        for name, (cnt_, ms) in rep2.items():
             kind = KERNEL_KIND.get(name)
-            entry = {"launches": cnt, "avg_ms": round(ms / cnt, 5), "total_ms": round(ms, 4)}
+            entry = {"launches": cnt_, "avg_ms": round(ms / cnt_, 5), "total_ms": round(ms, 4)}
             if kind:
                 bts = algorithmic_bytes(kind, n_act, m, nnz_act, k)
                 entry["algorithmic_GB"] = round(bts / 1e9, 4)
-                entry["GBps"] = round(bts / 1e9 / (ms / cnt / 1e3), 1)
+                entry["GBps"] = round(bts / 1e9 / (ms / cnt_ / 1e3), 1)
             kernels_mat[name] = entry
         e_entry = kernels_mat["k_e_step"]
         mat = {"schedule": "materialised (reference kernel sequence)", "steps": it2, "p_placement": eng.placement_info(),
                "value": round(it2 / dt2, 4), "ms_per_step": round(dt2 / it2 * 1e3, 4), "kernels": kernels_mat}
 
+    n_gpus = world
+    exchange = "none" if world == 1 else ("RCCL (C ABI, ncclAllGather)" if isinstance(comm, plsa_comm.RcclComm)
+                                          else "host files -- TEST MODE, ranks share %d GPU(s)" % n_dev)
     out = {
         "metric": "EM iterations/sec", "value": round(n_gpus * args.steps / dt, 4), "unit": "iter/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "n_docs": n, "n_vocab": m, "nnz": nnz, "k": k,
-                   "schedule": args.schedule,
+                   "schedule": args.schedule + (" + hipGraph" if args.graph else ""),
                    "parallelism": "single fit" if n_gpus == 1 else
-                   "ensemble: one bootstrap member per GPU x%d, %s all-gather of topics" % (n_gpus, "RCCL" if backend == "nccl" else "gloo(host)"),
+                   "ensemble: one bootstrap member per GPU x%d, all-gather of topics: %s" % (n_gpus, exchange),
                    "ll_test_every": 10, "tolerance": 0.0, "e_step_thresh": 1e-32},
+        "rccl_ranks": world if isinstance(comm, plsa_comm.RcclComm) else 0,
+        "exchange": exchange,
         "gcell_per_s": round(nnz_total * k * args.steps / dt / 1e9, 3),
         "ensemble_fits_per_min": round(n_gpus * args.steps / dt / FITS_ITERS * 60.0, 3),
         # north_star's roofline kernel: the per-nnz materialising E-step (HBM-bound)
@@ -334,17 +466,6 @@ def main():
         "materialised_leg": mat,
         "device": info["name"] or "AMD Instinct MI355X", "arch": info["arch"], "generate_s": round(t_gen, 2),
     }
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):        # HBM bytes per launch from committed rocprofv3 --pmc passes
-        try:
-            table = json.load(open(pmc)).get("config%d" % args.config, {})
-            for key in ("roofline", "roofline_dominant_fused"):
-                rec = table.get(out[key]["kernel"])
-                if rec:
-                    out[key]["traffic"] = rec["hbm_bytes_per_launch"]
-                    out[key]["traffic_source"] = rec["source"]
-        except Exception:
-            pass
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
@@ -352,17 +473,43 @@ def main():
             except Exception as e:       # the baseline must never cost the GPU measurement
                 out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-    if rank == 0 and n_gpus == 1 and dist is None and args.config == 3 and not args.no_cpu_baseline:
-        # BASELINE.json configs[1] (100k x 50k, 10M nnz, k=32) on the same device, compact form
+    if rank == 0 and n_gpus == 1 and args.config == 3 and not args.no_cpu_baseline:
+        # BASELINE.json configs[1] (100k x 50k, 10M nnz, k=32) on the same device, compact form, with the
+        # CPU port on the WHOLE of that corpus beside it
         try:
-            out["other_configs"] = {"config2": quick_config(eng, 2, args.steps, args.warmup, args.seed)}
+            c2 = quick_config(eng, 2, args.steps, args.warmup, args.seed, with_cpu=True)
+            if isinstance(out.get("cpu_baseline"), dict) and isinstance(c2.get("cpu_baseline"), dict):
+                out["cpu_baseline"]["whole_config2"] = c2["cpu_baseline"]
+            out["other_configs"] = {"config2": c2}
         except Exception as e:
             out["other_configs"] = {"config2": "failed: %r" % (e,)}
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if world > 1:
+        comm.barrier()
+        plsa_comm.shutdown()
     eng.close()
+    # ---- HBM-side traffic of the roofline kernels: PMC passes in this run, else the committed profile ----
     if rank == 0:
+        table = None
+        if n_gpus == 1 and not args.no_pmc:
+            table = measure_traffic(args)
+        source = "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over " \
+                 "`bench.py --pmc-child`; (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled per MI355X_MICROARCH.md"
+        if table is None:
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    table = json.load(open(pmc)).get("config%d" % args.config, {})
+                    source = "from_committed_profile"
+                except Exception:
+                    table = None
+        for key in ("roofline", "roofline_dominant_fused"):
+            rec = (table or {}).get(out[key]["kernel"])
+            if rec:
+                out[key]["traffic"] = rec["hbm_bytes_per_launch"]
+                out[key]["traffic_source"] = source if source != "from_committed_profile" else \
+                    "from_committed_profile: " + rec.get("source", "profiles/pmc_traffic.json")
+        if table and source != "from_committed_profile":
+            out["pmc_traffic"] = table
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

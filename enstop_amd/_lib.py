@@ -17,6 +17,7 @@ PLSA_TRACE_LL = 4
 PLSA_SW_LL_ONLY = 8
 PLSA_STOP_NO_ZERO_ARM = 16
 PLSA_GRAPH = 32
+PLSA_SHARDED = 64
 
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
@@ -59,6 +60,16 @@ SIGNATURES = {
     "plsa_accumulator_device": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(_i64)]),
     "plsa_accumulator_get": (C.c_int, [_ctx, _f32p]),
     "plsa_accumulator_set": (C.c_int, [_ctx, _f32p]),
+    "plsa_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "plsa_comm_init": (C.c_int, [_ctx, C.c_char_p, _i32, _i32]),
+    "plsa_comm_destroy": (C.c_int, [_ctx]),
+    "plsa_comm_info": (C.c_int, [_ctx, C.POINTER(_i32), C.POINTER(_i32)]),
+    "plsa_comm_barrier": (C.c_int, [_ctx]),
+    "plsa_comm_allgather_components": (C.c_int, [_ctx, _vp]),
+    "plsa_comm_allgather_host": (C.c_int, [_ctx, _vp, _i64, _vp]),
+    "plsa_comm_allreduce_f64": (C.c_int, [_ctx, _f64p, _i64, _i32]),
+    "plsa_comm_broadcast_host": (C.c_int, [_ctx, _vp, _i64, _i32]),
+    "plsa_allreduce_accumulator": (C.c_int, [_ctx]),
     "plsa_placement_info": (C.c_int, [_ctx, C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "plsa_release_scratch": (C.c_int, [_ctx]),
     "plsa_timing_enable": (C.c_int, [_ctx, _i32]),

@@ -21,7 +21,8 @@ def build(force=False, verbose=True):
     if (not force and os.path.exists(OUT)
             and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps)):
         return OUT
-    cmd = [HIPCC] + FLAGS + [SRC, "-o", OUT]
+    # RCCL is linked directly: the multi-GPU exchange (plsa_comm_*) is part of the C ABI
+    cmd = [HIPCC] + FLAGS + [SRC, "-o", OUT, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -12,6 +12,7 @@
 //   P            f32[nnz,kp] materialised responsibilities (only when not PLSA_FUSED)
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -105,6 +106,13 @@ struct plsa_ctx {
     DevBuf sw, ll_partials, ll_out, colsum_partials, norm_pwz, norm_pdz, tmp0, tmp1, tmp2, cubtmp;
     double *h_ll = nullptr;  // pinned
 
+    // multi-GPU exchange: one RCCL communicator per context (one process per GPU), collectives are
+    // enqueued on the context's own streams
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    bool sharded = false;            // PLSA_SHARDED fit in progress: accumulators / likelihoods are all-reduced
+    DevBuf comm_send, comm_recv, comm_small;
+
     // timing
     bool timing = false;
     std::vector<std::string> names;
@@ -140,6 +148,14 @@ int fail(plsa_ctx *c, const char *fmt, ...) {
     do {                                                                                           \
         int r_ = (expr);                                                                           \
         if (r_) return r_;                                                                         \
+    } while (0)
+
+#define NCCLCHK(c, expr)                                                                           \
+    do {                                                                                           \
+        ncclResult_t n_ = (expr);                                                                  \
+        if (n_ != ncclSuccess)                                                                     \
+            return fail((c), "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(n_), __FILE__,     \
+                        __LINE__);                                                                 \
     } while (0)
 
 int grid_for(plsa_ctx *c, i64 work_items, int items_per_block);
@@ -635,6 +651,13 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int 
 
 // Vacc -> normalised topics in Vt[1-cv]  (plsa.py:196-199)
 int run_v_normalise(plsa_ctx *c) {
+    if (c->sharded && c->comm) {
+        // doc-sharded fit: the un-normalised P(w|z) sums of the local rows become the global sums (the
+        // `.sum(axis=0)` over tiles of distributed_plsa.py:116-128 / block_parallel_plsa.py:182-185) --
+        // in place, on the stream this chain runs on (underneath the document pass when overlapped)
+        Scope s(c, "rccl_allreduce_accumulator");
+        NCCLCHK(c, ncclAllReduce(c->Vacc.p, c->Vacc.p, (size_t)c->m * c->kp, ncclFloat, ncclSum, c->comm, c->ls));
+    }
     const int nb = (int)std::min<i64>(plsa::NORM_BLOCKS, std::max<i64>(1, c->m));
     CHK(ensure(c, c->colsum_partials, sizeof(double) * (size_t)nb * c->kp));
     {
@@ -667,6 +690,8 @@ int finish_ll(plsa_ctx *c, int blocks, double *out) {
                            c->ll_partials.as<double>(), blocks, c->ll_out.as<double>());
     }
     CHK(launch_check(c, "k_ll_final"));
+    if (c->sharded && c->comm)      // log-likelihood of all shards: one scalar all-reduce per test
+        NCCLCHK(c, ncclAllReduce(c->ll_out.p, c->ll_out.p, 1, ncclDouble, ncclSum, c->comm, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_ll, c->ll_out.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *out = *c->h_ll;
@@ -779,6 +804,8 @@ void plsa_destroy(plsa_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    release(c->comm_send); release(c->comm_recv); release(c->comm_small);
     DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,
@@ -1188,6 +1215,11 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
     if (n_iter < 0 || n_iter_per_test <= 0) return fail(c, "plsa_fit: bad n_iter / n_iter_per_test");
     const bool fused = flags & PLSA_FUSED, trace = flags & PLSA_TRACE_LL;
     const bool zero_arm = !(flags & PLSA_STOP_NO_ZERO_ARM);
+    struct ShardedScope {           // PLSA_SHARDED: this context's rows are one shard of the corpus
+        plsa_ctx *c;
+        ShardedScope(plsa_ctx *c_, bool on) : c(c_) { c->sharded = on; }
+        ~ShardedScope() { c->sharded = false; }
+    } sharded_scope(c, (flags & PLSA_SHARDED) != 0);
     const float *d_sw = nullptr;
     CHK(upload_sw(c, sw, &d_sw));
     // plsa.py:606-628: with use_sample_weights == False the M-step ignores the weights, the
@@ -1382,8 +1414,7 @@ int plsa_em_accumulate(plsa_ctx *c, const float *sw, float thresh, double *ll_pa
     int blocks = 0;
     CHK(run_row_pass(c, false, ll_partial != nullptr, d_sw, thresh, nullptr, &blocks));
     CHK(run_col_pass(c, false, d_sw, thresh));
-    if (ll_partial) CHK(finish_ll(c, blocks, ll_partial));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ll_partial) CHK(finish_ll(c, blocks, ll_partial));    // (its scalar read-back is the only host wait)
     return 0;
 }
 
@@ -1392,8 +1423,7 @@ int plsa_em_finish(plsa_ctx *c) {
     CHK(need_factors(c));
     CHK(run_v_normalise(c));
     c->cu ^= 1; c->cv ^= 1;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return 0;                       // stream-ordered: no host synchronisation (readers synchronise)
 }
 
 int plsa_accumulator_device(plsa_ctx *c, void **ptr, int64_t *n_floats) {
@@ -1416,6 +1446,128 @@ int plsa_accumulator_set(plsa_ctx *c, const float *host) {
     CHK(need_factors(c));
     HIPCHK(c, hipMemcpyAsync(c->Vacc.p, host, sizeof(float) * (size_t)c->m * c->kp, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- multi-GPU exchange over RCCL (xGMI): one communicator per context ------------------------------
+int plsa_comm_unique_id(void *id128) {
+    if (!id128) return fail(nullptr, "plsa_comm_unique_id: NULL");
+    static_assert(sizeof(ncclUniqueId) == PLSA_COMM_ID_BYTES, "RCCL unique id size");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    memcpy(id128, &id, sizeof id);
+    return 0;
+}
+
+int plsa_comm_init(plsa_ctx *c, const void *id128, int32_t rank, int32_t world) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(c, "plsa_comm_init: bad arguments");
+    if (c->comm) return fail(c, "plsa_comm_init: this context already has a communicator");
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    NCCLCHK(c, ncclCommInitRank(&c->comm, world, id, rank));
+    c->comm_rank = rank; c->comm_world = world;
+    CHK(ensure(c, c->comm_small, 4096));
+    return 0;
+}
+
+int plsa_comm_destroy(plsa_ctx *c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        NCCLCHK(c, ncclCommDestroy(c->comm));
+        c->comm = nullptr;
+    }
+    c->comm_rank = 0; c->comm_world = 1;
+    return 0;
+}
+
+int plsa_comm_info(plsa_ctx *c, int32_t *rank, int32_t *world) {
+    if (rank) *rank = c->comm_rank;
+    if (world) *world = c->comm_world;
+    return 0;
+}
+
+int plsa_comm_barrier(plsa_ctx *c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm) {
+        HIPCHK(c, hipMemsetAsync(c->comm_small.p, 0, sizeof(int), c->stream));
+        NCCLCHK(c, ncclAllReduce(c->comm_small.p, c->comm_small.p, 1, ncclInt32, ncclSum, c->comm, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// the np.vstack of enstop_.py:231 across GPUs: every rank contributes its current P(w|z) [k, m]
+int plsa_comm_allgather_components(plsa_ctx *c, float *out_host) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    const size_t count = (size_t)c->k * c->m;
+    CHK(ensure(c, c->comm_send, sizeof(float) * count));
+    CHK(ensure(c, c->comm_recv, sizeof(float) * count * (size_t)c->comm_world));
+    dim3 grid((unsigned)((c->m + 31) / 32), (unsigned)((c->kp + 31) / 32));
+    float *dst = c->comm ? c->comm_send.as<float>() : c->comm_recv.as<float>();
+    hipLaunchKernelGGL(plsa::k_vt_to_v, grid, dim3(256), 0, c->stream, c->Vt[c->cv].as<float>(), dst, c->k, (int)c->m, c->kp);
+    CHK(launch_check(c, "k_vt_to_v"));
+    if (c->comm) {
+        Scope s(c, "rccl_allgather_components");
+        NCCLCHK(c, ncclAllGather(c->comm_send.p, c->comm_recv.p, count, ncclFloat, c->comm, c->stream));
+    }
+    if (out_host)
+        HIPCHK(c, hipMemcpyAsync(out_host, c->comm_recv.p, sizeof(float) * count * (size_t)c->comm_world,
+                                 hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_comm_allgather_host(plsa_ctx *c, const void *send, int64_t bytes, void *recv) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!send || !recv || bytes <= 0) return fail(c, "plsa_comm_allgather_host: bad arguments");
+    if (!c->comm) { memmove(recv, send, (size_t)bytes); return 0; }
+    CHK(ensure(c, c->comm_send, (size_t)bytes));
+    CHK(ensure(c, c->comm_recv, (size_t)bytes * (size_t)c->comm_world));
+    HIPCHK(c, hipMemcpyAsync(c->comm_send.p, send, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, ncclAllGather(c->comm_send.p, c->comm_recv.p, (size_t)bytes, ncclUint8, c->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(recv, c->comm_recv.p, (size_t)bytes * (size_t)c->comm_world, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_comm_allreduce_f64(plsa_ctx *c, double *inout, int64_t count, int32_t op) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!inout || count <= 0 || (op != 0 && op != 1)) return fail(c, "plsa_comm_allreduce_f64: bad arguments");
+    if (!c->comm) return 0;
+    CHK(ensure(c, c->comm_send, sizeof(double) * (size_t)count));
+    HIPCHK(c, hipMemcpyAsync(c->comm_send.p, inout, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, ncclAllReduce(c->comm_send.p, c->comm_send.p, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax,
+                             c->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(inout, c->comm_send.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int plsa_comm_broadcast_host(plsa_ctx *c, void *buf, int64_t bytes, int32_t root) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!buf || bytes <= 0 || root < 0 || root >= c->comm_world) return fail(c, "plsa_comm_broadcast_host: bad arguments");
+    if (!c->comm) return 0;
+    CHK(ensure(c, c->comm_send, (size_t)bytes));
+    if (c->comm_rank == root)
+        HIPCHK(c, hipMemcpyAsync(c->comm_send.p, buf, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, ncclBroadcast(c->comm_send.p, c->comm_send.p, (size_t)bytes, ncclUint8, root, c->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(buf, c->comm_send.p, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// in-place sum of the un-normalised P(w|z) accumulator over the communicator, enqueued on the context's
+// stream (no host synchronisation): the exchange step between plsa_em_accumulate and plsa_em_finish
+int plsa_allreduce_accumulator(plsa_ctx *c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    if (!c->comm) return 0;
+    NCCLCHK(c, ncclAllReduce(c->Vacc.p, c->Vacc.p, (size_t)c->m * c->kp, ncclFloat, ncclSum, c->comm, c->stream));
     return 0;
 }
 

@@ -1,61 +1,53 @@
-"""Multi-GPU plumbing for the ensemble: one process per GPU (torchrun), torch.distributed for
-rendezvous, RCCL ("nccl" backend on ROCm) for the single exchange step -- the all-gather of the
-members' topic matrices that replaces np.vstack over thread results (enstop/enstop_.py:231).
-No collective sits on the EM data path: members are independent."""
-import os
-import sys
+"""Ensemble across GPUs: one process per GPU, run r of the ensemble is fitted by rank r % world, and the
+members' topic matrices are brought together by ONE all-gather -- the np.vstack over thread results of
+enstop/enstop_.py:231.  No collective sits on the EM data path: members are independent.
 
+The exchange itself lives in `comm.py` (RCCL through the C ABI by default; a caller-initialised
+torch.distributed group is honoured).  Typical use under a launcher that sets RANK / WORLD_SIZE /
+LOCAL_RANK (torchrun, or `python bench.py --gpus N`):
+
+    import enstop_amd
+    enstop_amd.distributed.init()                       # RCCL communicator on this rank's GPU
+    topics = enstop_amd.ensemble_of_topics(X, k, n_runs=32)     # identical stack on every rank
+"""
 import numpy as np
 
+from . import comm as _comm
 
-def _dist():
-    # a process group can only have been initialised by code that imported torch.distributed itself:
-    # look it up instead of importing it (importing torch costs seconds, minutes on a cold box, and
-    # the single-process ensemble does not need it)
-    dist = sys.modules.get("torch.distributed")
-    if dist is None:
-        return None
-    return dist if dist.is_available() and dist.is_initialized() else None
+
+def init(eng=None, id_file=None):
+    """Create and install the RCCL communicator of this rank (no-op with WORLD_SIZE <= 1)."""
+    return _comm.init_from_env(eng, id_file)
+
+
+def shutdown():
+    _comm.shutdown()
 
 
 def rank_world():
-    d = _dist()
-    if d is None:
-        return 0, 1
-    return d.get_rank(), d.get_world_size()
+    c = _comm.current()
+    return c.rank, c.world
 
 
 def broadcast_seed():
-    import torch
-    d = _dist()
-    t = torch.zeros(1, dtype=torch.int64)
-    if d.get_rank() == 0:
-        t[0] = int(np.random.randint(0, 2 ** 31 - 1))
-    if d.get_backend() == "nccl":
-        t = t.cuda()
-    d.broadcast(t, src=0)
-    return int(t.item())
+    """One random seed, the same on every rank (drawn by rank 0)."""
+    c = _comm.current()
+    seed = np.array([np.random.randint(0, 2 ** 31 - 1) if c.rank == 0 else 0], np.int64)
+    return int(c.broadcast_array(seed, root=0)[0])
 
 
 def gather_topics(mine, n_runs, k, m, eng=None):
     """mine: {run index -> (k, m) float32 topics computed by this rank}.  Returns the
     (n_runs * k, m) stack in run order on every rank."""
-    d = _dist()
-    rank, world = rank_world()
-    if d is None or world == 1:
+    c = _comm.current()
+    if c.world == 1:
         return np.vstack([mine[r] for r in range(n_runs)])
-    import torch
-    per_rank = (n_runs + world - 1) // world
-    use_gpu = d.get_backend() == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if use_gpu else torch.device("cpu")
-    send = torch.zeros((per_rank, k, m), dtype=torch.float32, device=dev)
-    for slot, r in enumerate(range(rank, n_runs, world)):
-        send[slot].copy_(torch.from_numpy(mine[r]))
-    recv = torch.empty((world, per_rank, k, m), dtype=torch.float32, device=dev)
-    d.all_gather_into_tensor(recv.view(-1), send.view(-1)) if use_gpu else \
-        d.all_gather(list(recv.unbind(0)), send)
-    recv = recv.cpu().numpy()
+    per_rank = (n_runs + c.world - 1) // c.world
+    send = np.zeros((per_rank, k, m), np.float32)
+    for slot, r in enumerate(range(c.rank, n_runs, c.world)):
+        send[slot] = mine[r]
+    recv = c.allgather_array(send)                     # [world, per_rank, k, m]
     out = np.empty((n_runs * k, m), np.float32)
     for r in range(n_runs):
-        out[r * k:(r + 1) * k] = recv[r % world, r // world]
+        out[r * k:(r + 1) * k] = recv[r % c.world, r // c.world]
     return out

@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 from . import _lib
-from ._lib import PLSA_FUSED, PLSA_GRAPH, PLSA_STOP_NO_ZERO_ARM, PLSA_SW_LL_ONLY, PLSA_TRACE_LL, ptr
+from ._lib import PLSA_FUSED, PLSA_GRAPH, PLSA_SHARDED, PLSA_STOP_NO_ZERO_ARM, PLSA_SW_LL_ONLY, PLSA_TRACE_LL, ptr
 
 
 class DeviceError(RuntimeError):
@@ -19,8 +19,17 @@ class DeviceError(RuntimeError):
 
 
 def default_device():
-    """One process per GPU: LOCAL_RANK (torchrun) selects the device unless overridden."""
-    return int(os.environ.get("ENSTOP_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    """One process per GPU: LOCAL_RANK (torchrun / bench.py's spawner) selects the device unless
+    ENSTOP_AMD_DEVICE overrides it; a launcher that narrows the visible devices to one per rank
+    (HIP_VISIBLE_DEVICES) leaves only device 0."""
+    if "ENSTOP_AMD_DEVICE" in os.environ:
+        return int(os.environ["ENSTOP_AMD_DEVICE"])
+    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    if dev > 0:
+        cnt = C.c_int(0)
+        if _lib.load().plsa_device_count(C.byref(cnt)) == 0 and 0 < cnt.value <= dev:
+            dev = 0
+    return dev
 
 
 def default_flags():
@@ -246,6 +255,51 @@ class Engine:
 
     def accumulator_set(self, a):
         self._ok(self._L.plsa_accumulator_set(self._h, _f32(a)))
+
+    # -- multi-GPU exchange (RCCL through the C ABI; see comm.py) ------------------------------------------
+    def comm_init(self, id_bytes, rank, world):
+        if len(id_bytes) != 128:
+            raise ValueError("the RCCL unique id has 128 bytes")
+        self._ok(self._L.plsa_comm_init(self._h, bytes(id_bytes), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._ok(self._L.plsa_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, w = C.c_int32(0), C.c_int32(1)
+        self._ok(self._L.plsa_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def comm_barrier(self):
+        self._ok(self._L.plsa_comm_barrier(self._h))
+
+    def comm_allgather_components(self, want_host=True):
+        """[world, k, m] float32: every rank's current P(w|z) (one ncclAllGather on the engine's stream)."""
+        _, world = self.comm_info()
+        _, m, _ = self.shape
+        out = np.empty((world, self.k, m), np.float32) if want_host else None
+        self._ok(self._L.plsa_comm_allgather_components(self._h, ptr(out)))
+        return out
+
+    def comm_allgather_host(self, a):
+        a = np.ascontiguousarray(a)
+        _, world = self.comm_info()
+        out = np.empty((world,) + a.shape, a.dtype)
+        self._ok(self._L.plsa_comm_allgather_host(self._h, a.ctypes.data, a.nbytes, out.ctypes.data))
+        return out
+
+    def comm_allreduce_f64(self, values, op="sum"):
+        a = np.atleast_1d(np.array(values, dtype=np.float64))
+        self._ok(self._L.plsa_comm_allreduce_f64(self._h, a, a.size, {"sum": 0, "max": 1}[op]))
+        return a
+
+    def comm_broadcast_host(self, a, root=0):
+        a = np.array(a, copy=True, order="C")
+        self._ok(self._L.plsa_comm_broadcast_host(self._h, a.ctypes.data, a.nbytes, int(root)))
+        return a
+
+    def allreduce_accumulator(self):
+        self._ok(self._L.plsa_allreduce_accumulator(self._h))
 
     def all_pairs_hellinger(self, topics):
         """[t, t] float64 Hellinger distances between the rows of `topics` [t, m] (enstop_.py:258-266)."""

@@ -3,15 +3,19 @@ enstop/distributed_plsa.py, whose dask graph sums per-tile partial factors with
 `da.dstack(...).sum(axis=-1)`, distributed_plsa.py:116-131).
 
 Every rank owns a contiguous row range of X (balanced by nnz), its rows of P(z|d) and a full copy of
-P(w|z).  One EM iteration is: local fused E+M pass (`plsa_em_accumulate`) -> ONE all-reduce(sum) of
-the un-normalised P(w|z) accumulator [m, kp] floats (RCCL over xGMI; 25.6 MB at config 3, ring
-time ~0.3 ms) -> identical normalisation on every rank (`plsa_em_finish`).  The log-likelihood test
-is a scalar all-reduce every `n_iter_per_test` iterations.  The loop reproduces plsa_fit_inner's stop
-semantics (plsa.py:630-638) with the same one-pass-late decision as the single-GPU fused driver.
+P(w|z).  One EM iteration is: local fused E+M pass -> ONE all-reduce(sum) of the un-normalised P(w|z)
+accumulator [m, kp] floats (RCCL over xGMI; 25.6 MB at config 3, ring time ~0.3 ms) -> identical
+normalisation on every rank.  The log-likelihood test is a scalar all-reduce every `n_iter_per_test`
+iterations.  The loop reproduces plsa_fit_inner's stop semantics (plsa.py:630-638) with the same
+one-pass-late decision as the single-GPU fused driver.
 
-`Comm` abstracts the two exchanges so that the same loop runs (a) with torch.distributed (nccl =
-RCCL on device memory, gloo through the host) one rank per process, and (b) inside one process over
-several engines on one device (tests: emulates N ranks without N GPUs).
+Product path (RCCL communicator, `distributed.init()`): the whole loop runs inside the C ABI --
+`plsa_fit(..., PLSA_SHARDED)` -- with the accumulator all-reduce enqueued on the engine's second stream
+underneath the document pass and no host synchronisation between likelihood tests.  The same loop also
+exists as three ABI calls (`plsa_em_accumulate`, `plsa_allreduce_accumulator` or any external all-reduce
+of the buffer `plsa_accumulator_device` exposes, `plsa_em_finish`), driven by `sharded_em` below: that
+form runs (a) on a caller's torch.distributed group and (b) inside one process over several engines on
+one device (tests: N shards without N GPUs).
 """
 import numpy as np
 from sklearn.utils import check_random_state
@@ -21,17 +25,26 @@ from .plsa import plsa_init
 
 
 def row_ranges_by_nnz(indptr, parts):
-    """Contiguous row ranges with ~equal nnz."""
+    """Contiguous row ranges with ~equal nnz, every range non-empty whenever there are at least `parts`
+    rows (a corpus with fewer rows than ranks, or one row holding most of the non-zeros, would otherwise
+    leave a rank without rows: its engine cannot hold an empty matrix and its peers would wait for it in
+    the all-reduce).  With fewer rows than parts some ranges are necessarily empty; `sharded_plsa_fit`
+    then raises the same ValueError on every rank before any exchange."""
+    n = len(indptr) - 1
     nnz = int(indptr[-1])
     cuts = [0]
     for r in range(1, parts):
-        cuts.append(int(np.searchsorted(indptr, nnz * r / parts)))
-    cuts.append(len(indptr) - 1)
-    return [(cuts[i], max(cuts[i], cuts[i + 1])) for i in range(parts)]
+        c = int(np.searchsorted(indptr, nnz * r / parts))
+        lo = min(cuts[-1] + 1, n)                      # strictly increasing ...
+        hi = max(lo, n - (parts - r))                  # ... and leave one row for each later part
+        cuts.append(min(max(c, lo), hi))
+    cuts.append(n)
+    return [(cuts[i], cuts[i + 1]) for i in range(parts)]
 
 
 class LocalComm:
     """All 'ranks' are engines of this process: sums go through host memory (test double)."""
+    rank, world, name = 0, 1, "local"
 
     def allreduce_accumulators(self, engines):
         total = None
@@ -46,41 +59,24 @@ class LocalComm:
         return float(np.sum(values))
 
 
-class TorchComm:
-    """One rank per process over torch.distributed; device all-reduce when the backend is nccl."""
+class RankComm:
+    """One shard per process: the exchanges go through the communicator in force (comm.current():
+    RCCL through the C ABI, or the caller's torch.distributed group)."""
 
-    def __init__(self):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.device_path = dist.get_backend() == "nccl"
+    def __init__(self, comm):
+        self.comm = comm
+        self.rank, self.world, self.name = comm.rank, comm.world, comm.name
 
     def allreduce_accumulators(self, engines):
         (eng,) = engines
-        torch, dist = self.torch, self.dist
-        if self.device_path:
-            ptr, n = eng.accumulator_device()
-
-            class _View:        # zero-copy view of the engine's accumulator for RCCL
-                __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-            t = torch.as_tensor(_View(), device=torch.device("cuda", torch.cuda.current_device()))
-            dist.all_reduce(t)
-            torch.cuda.synchronize()
-        else:
-            t = torch.from_numpy(eng.accumulator_get())
-            dist.all_reduce(t)
-            eng.accumulator_set(t.numpy())
+        self.comm.allreduce_accumulator(eng)
 
     def allreduce_scalar(self, values):
-        torch, dist = self.torch, self.dist
-        t = torch.tensor([float(np.sum(values))], dtype=torch.float64,
-                         device="cuda" if self.device_path else "cpu")
-        dist.all_reduce(t)
-        return float(t.item())
+        return float(self.comm.allreduce_f64([float(np.sum(values))])[0])
 
 
 def sharded_em(engines, comm, sample_weights=None, n_iter=100, n_iter_per_test=10, tolerance=0.001,
-               e_step_thresh=1e-32, trace_last=False):
+               e_step_thresh=1e-32, trace_last=False, zero_arm=True):
     """plsa_fit_inner (plsa.py:583-640) over row shards.  `engines`: the shards local to this process,
     each with its rows uploaded and factors set (same P(w|z) everywhere).  Returns (iterations,
     float32 log-likelihood trace)."""
@@ -97,7 +93,8 @@ def sharded_em(engines, comm, sample_weights=None, n_iter=100, n_iter_per_test=1
             trace.append(cur)
             with np.errstate(invalid="ignore", divide="ignore"):
                 change = np.abs(cur - prev)
-                if change == 0 or float(change / np.abs(cur)) < tolerance:   # plsa.py:634-636
+                # plsa.py:634-636; zero_arm=False: distributed_plsa.py:277-278 has no `change == 0` arm
+                if (zero_arm and change == 0) or float(change / np.abs(cur)) < tolerance:
                     stopped = True
                     break                                          # this pass is discarded
             prev = cur
@@ -114,11 +111,19 @@ def sharded_em(engines, comm, sample_weights=None, n_iter=100, n_iter_per_test=1
 
 def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter_per_test=10,
                      tolerance=0.001, e_step_thresh=1e-32, random_state=None, device=None,
-                     local_shards=None, return_info=False):
-    """pLSA fit of X with the documents sharded over the ranks of torch.distributed (one process per
-    GPU) or, when `local_shards` is given, over that many engines of this process (single-GPU
-    emulation used by the tests).  Every rank passes the same X and arguments; returns the full
-    (P(z|d), P(w|z)) on every rank.  Same initial factors as `plsa_fit` for the same seed."""
+                     local_shards=None, return_info=False, flags=None, zero_arm=True):
+    """pLSA fit of X with the documents sharded over the ranks of the communicator in force (one process
+    per GPU; `distributed.init()` or a torch.distributed group) or, when `local_shards` is given, over
+    that many engines of this process (single-GPU emulation used by the tests).  Every rank passes the
+    same X and arguments; returns the full (P(z|d), P(w|z)) on every rank.  Same initial factors as
+    `plsa_fit` for the same seed.
+
+    With the RCCL communicator the whole loop runs inside the C ABI (`plsa_fit` with PLSA_SHARDED): the
+    all-reduce of the P(w|z) accumulator is enqueued on the engine's second stream underneath the
+    document pass, the log-likelihood is one scalar all-reduce per test, nothing synchronises with the
+    host between tests.  Other communicators use the accumulate / all-reduce / finish split."""
+    from . import comm as _comm
+    from .engine import PLSA_FUSED, PLSA_SHARDED, PLSA_STOP_NO_ZERO_ARM, get_engine
     X = X.tocsr()
     n, m = X.shape
     rng = check_random_state(random_state)
@@ -128,18 +133,22 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
     if sample_weight is not None and np.any(np.asarray(sample_weight) != 1.0):
         sw_all = np.asarray(sample_weight, np.float32)
 
+    native = False
     if local_shards:
         ranges = row_ranges_by_nnz(X.indptr, local_shards)
         engines = [Engine(device) for _ in ranges]
         comm = LocalComm()
         mine = list(range(local_shards))
     else:
-        from . import distributed
-        rank, world = distributed.rank_world()
-        ranges = row_ranges_by_nnz(X.indptr, world)
-        engines = [Engine(device)]
-        comm = TorchComm() if world > 1 or distributed._dist() is not None else LocalComm()
-        mine = [rank]
+        c = _comm.current()
+        ranges = row_ranges_by_nnz(X.indptr, c.world)
+        native = isinstance(c, _comm.RcclComm)
+        # the RCCL communicator belongs to one engine: the sharded fit runs on that engine
+        engines = [c.eng if native else Engine(device)]
+        comm = RankComm(c)
+        mine = [c.rank]
+    if any(b <= a for a, b in ranges):
+        raise ValueError("sharded_plsa_fit: %d documents cannot be split over %d shards" % (n, len(ranges)))
     try:
         sws = []
         for e, r in zip(engines, mine):
@@ -147,8 +156,13 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
             e.upload_csr(X[a:b])
             e.set_factors(U0[a:b], V0)
             sws.append(None if sw_all is None else sw_all[a:b])
-        iters, trace = sharded_em(engines, comm, sws, n_iter, n_iter_per_test, tolerance, e_step_thresh,
-                                  trace_last=return_info)
+        if native:
+            fl = (PLSA_FUSED if flags is None else flags) | PLSA_SHARDED | (0 if zero_arm else PLSA_STOP_NO_ZERO_ARM)
+            iters, trace = engines[0].fit(sws[0], n_iter, n_iter_per_test, tolerance, e_step_thresh, fl,
+                                          trace=return_info)
+        else:
+            iters, trace = sharded_em(engines, comm, sws, n_iter, n_iter_per_test, tolerance, e_step_thresh,
+                                      trace_last=return_info, zero_arm=zero_arm)
         U = np.zeros((n, k), np.float32)
         V = None
         for e, r in zip(engines, mine):
@@ -156,14 +170,20 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
             Ur, V = e.get_factors()
             U[a:b] = Ur
         if not local_shards and len(ranges) > 1:                  # assemble P(z|d) on every rank
-            t = comm.torch.from_numpy(U)
-            if comm.device_path:
-                t = t.cuda()
-            comm.dist.all_reduce(t)                                # disjoint row ranges: sum == concat
-            U = t.cpu().numpy()
+            parts = comm.comm.allgather_array(_pad_rows(U[ranges[mine[0]][0]:ranges[mine[0]][1]],
+                                                        max(b - a for a, b in ranges)))
+            for r, (a, b) in enumerate(ranges):
+                U[a:b] = parts[r, :b - a]
     finally:
         for e in engines:
-            e.close()
+            if not native:
+                e.close()
     if return_info:
         return U, V, dict(n_iter=iters, log_likelihood_trace=trace)
     return U, V
+
+
+def _pad_rows(a, rows):
+    out = np.zeros((rows, a.shape[1]), a.dtype)
+    out[:a.shape[0]] = a
+    return out

@@ -40,8 +40,12 @@ enum {
                            enstop/plsa.py:591, 606-628, 631                                         */
     PLSA_STOP_NO_ZERO_ARM = 16, /* plsa_fit: stop test of enstop/block_parallel_plsa.py:329-331
                            (`change / |cur| < tolerance` only, no `change == 0` arm)               */
-    PLSA_GRAPH     = 32 /* plsa_fit / plsa_refit: replay the launches of each run of iterations between
+    PLSA_GRAPH     = 32, /* plsa_fit / plsa_refit: replay the launches of each run of iterations between
                            two log-likelihood tests as one hipGraph (small corpora are launch-bound)  */
+    PLSA_SHARDED   = 64 /* plsa_fit: the context's rows are ONE SHARD of the corpus; the P(w|z)
+                           accumulator and the log-likelihood are all-reduced over the context's RCCL
+                           communicator every iteration (plsa_comm_init); every rank passes the same
+                           arguments and ends with its own P(z|d) rows and the full P(w|z)            */
 };
 
 /* ---- lifetime / errors ----------------------------------------------------------------------- */
@@ -143,6 +147,33 @@ int plsa_em_finish(plsa_ctx *ctx);
 int plsa_accumulator_device(plsa_ctx *ctx, void **ptr, int64_t *n_floats);
 int plsa_accumulator_get(plsa_ctx *ctx, float *host);
 int plsa_accumulator_set(plsa_ctx *ctx, const float *host);
+
+/* ---- multi-GPU exchange: RCCL over xGMI, one process per GPU -------------------------------------------
+ * Replaces the two exchange steps of the reference: np.vstack of the members' topics
+ * (enstop/enstop_.py:231) and the per-iteration sum of partial factors over tiles / workers
+ * (enstop/distributed_plsa.py:116-131, enstop/block_parallel_plsa.py:182-185).
+ *   plsa_comm_unique_id   rank 0 creates the 128-byte RCCL id (ncclGetUniqueId); the caller ships it to
+ *                         the other ranks (file, environment, any side channel: enstop_amd/comm.py)
+ *   plsa_comm_init        ncclCommInitRank on the context's device; collective over all ranks
+ *   plsa_comm_allgather_components   every rank's current P(w|z) [k, m] -> [world, k, m] (device buffer;
+ *                         copied to out_host when not NULL): ONE ncclAllGather on the context's stream
+ *   plsa_allreduce_accumulator       in-place ncclAllReduce(sum) of the un-normalised P(w|z) accumulator,
+ *                         stream-ordered between plsa_em_accumulate and plsa_em_finish; plsa_fit with
+ *                         PLSA_SHARDED issues the same call itself underneath the document pass
+ *   plsa_comm_allgather_host / _allreduce_f64 (op 0 sum, 1 max) / _broadcast_host / _barrier
+ *                         small host payloads staged through HBM (seeds, timings, member stacks)
+ * Without a communicator (world = 1) every call degenerates to the identity.                          */
+#define PLSA_COMM_ID_BYTES 128
+int plsa_comm_unique_id(void *id128);
+int plsa_comm_init(plsa_ctx *ctx, const void *id128, int32_t rank, int32_t world);
+int plsa_comm_destroy(plsa_ctx *ctx);
+int plsa_comm_info(plsa_ctx *ctx, int32_t *rank, int32_t *world);
+int plsa_comm_barrier(plsa_ctx *ctx);
+int plsa_comm_allgather_components(plsa_ctx *ctx, float *out_host /* [world, k, m] or NULL */);
+int plsa_comm_allgather_host(plsa_ctx *ctx, const void *send, int64_t bytes, void *recv /* world * bytes */);
+int plsa_comm_allreduce_f64(plsa_ctx *ctx, double *inout, int64_t count, int32_t op);
+int plsa_comm_broadcast_host(plsa_ctx *ctx, void *buf, int64_t bytes, int32_t root);
+int plsa_allreduce_accumulator(plsa_ctx *ctx);
 
 /* The materialised P array is placed by probing: up to PLSA_PLACEMENT_CANDIDATES (default 4)
  * allocations are streamed through once and the fastest is kept (HBM placement alone moves the

@@ -1,6 +1,8 @@
-"""N > 1 plumbing on CPU: world_size-2 gloo processes exercise the run -> rank dealing and the
-all-gather that rebuilds the np.vstack order of enstop_.py:231 (the RCCL path uses the same code
-with the "nccl" backend)."""
+"""N > 1 plumbing on CPU: world_size-2 processes exercise the run -> rank dealing and the all-gather
+that rebuilds the np.vstack order of enstop_.py:231, once over a torch.distributed gloo group
+(comm.TorchComm) and once over the host-file test double (comm.FileComm).  The product communicator
+(comm.RcclComm, RCCL through the C ABI) implements the same interface and is covered by the GPU tests;
+its rendezvous (a file carrying the RCCL unique id) is exercised here for the waiting ranks."""
 import os
 import socket
 import subprocess
@@ -68,3 +70,75 @@ def test_single_process_gather_is_vstack():
     mine = {r: np.random.RandomState(r).rand(2, 5).astype(np.float32) for r in range(3)}
     np.testing.assert_array_equal(distributed.gather_topics(mine, 3, 2, 5), np.vstack([mine[r] for r in range(3)]))
     assert distributed.rank_world() == (0, 1)
+
+
+FILE_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.environ["REPO_ROOT"])
+    from enstop_amd import comm, distributed
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    c = comm.install(comm.FileComm(os.environ["XDIR"], rank, world))
+    assert distributed.rank_world() == (rank, world)
+    n_runs, k, m = 5, 3, 7
+    mine = {r: np.full((k, m), float(r), np.float32) for r in range(rank, n_runs, world)}
+    stack = distributed.gather_topics(mine, n_runs, k, m)
+    np.testing.assert_array_equal(stack, np.vstack([np.full((k, m), float(r), np.float32) for r in range(n_runs)]))
+    assert c.allreduce_f64([rank + 1.0, 10.0])[0] == 3.0 and c.allreduce_f64([rank + 1.0], "max")[0] == 2.0
+    got = c.broadcast_array(np.arange(4) + 100 * rank, root=1)
+    np.testing.assert_array_equal(got, np.arange(4) + 100)
+    seed = distributed.broadcast_seed()
+    assert list(c.allgather_array(np.array([seed]))[:, 0]) == [seed, seed]
+    c.barrier()
+    print("rank", rank, "ok")
+""")
+
+
+def test_file_comm_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(FILE_WORKER)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", REPO_ROOT=ROOT, XDIR=str(tmp_path / "x"))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "ok" in out, "rank %d failed:\n%s" % (rank, out)
+
+
+def test_rendezvous_file_for_waiting_ranks(tmp_path, monkeypatch):
+    """Ranks > 0 wait for the file rank 0 publishes atomically; the default name is unique per launcher."""
+    import threading
+    import time
+    from enstop_amd import comm
+    path = str(tmp_path / "rccl.id")
+    payload = bytes(range(128))
+
+    def publish():
+        time.sleep(0.2)
+        with open(path + ".tmp", "wb") as f:
+            f.write(payload)
+        os.replace(path + ".tmp", path)
+    t = threading.Thread(target=publish)
+    t.start()
+    assert comm.rendezvous_id(1, path, timeout=30) == payload
+    t.join()
+    with pytest.raises(TimeoutError):
+        comm.rendezvous_id(1, str(tmp_path / "never.id"), timeout=0.2)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    monkeypatch.delenv("PLSA_COMM_ID_FILE", raising=False)
+    name = comm.default_id_file()
+    assert "127.0.0.1" in name and "29999" in name and str(os.getppid()) in name
+    monkeypatch.setenv("PLSA_COMM_ID_FILE", "/some/where.id")
+    assert comm.default_id_file() == "/some/where.id"
+    assert isinstance(comm.current(), comm.SingleComm) and comm.current().world == 1
+
+
+def test_bench_refuses_gpus_world_mismatch(tmp_path):
+    """`bench.py --gpus N` under a launcher whose WORLD_SIZE differs must fail, not report n_gpus wrongly."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and out.stdout.strip() == ""
