@@ -218,20 +218,21 @@ def pmc_child(args):
 
 
 def short_kernel_name(k):
-    """rocprofv3 kernel name -> the engine's timing name (k_e_step_rows / k_e_step -> k_e_step, ...)."""
-    k = k.replace("void ", "")
-    if "k_e_step" in k:
+    """rocprofv3 kernel name -> the engine's timing name (k_e_step_rows / k_e_step -> k_e_step, ...).
+    Names look like `void plsa::k_col_pass<plsa::Shape<16, 1, true>, false>(...)`: the flags that matter
+    are the template arguments BEHIND the Shape."""
+    import re
+    head = k.replace("void ", "").split("(")[0]
+    if "k_e_step" in head:
         return "k_e_step"
-    for base in ("k_row_pass", "k_col_pass"):
-        if base in k:
-            targs = k[k.index(base):]
-            if base == "k_col_pass":
-                return "k_col_pass<P>" if ", true>" in targs.split("(")[0] else "k_col_pass<fused>"
-            head = targs.split("(")[0]
-            if ", true, false>" in head:
-                return "k_row_pass<P>"
-            return "k_row_pass<fused,LL>" if ", false, true>" in head else "k_row_pass<fused>"
-    return None
+    mm = re.search(r"(k_row_pass|k_col_pass)<.*>\s*,\s*(true|false)(?:\s*,\s*(true|false))?\s*>\s*$", head)
+    if not mm:
+        return None
+    if mm.group(1) == "k_col_pass":
+        return "k_col_pass<P>" if mm.group(2) == "true" else "k_col_pass<fused>"
+    if mm.group(2) == "true":
+        return "k_row_pass<P>"
+    return "k_row_pass<fused,LL>" if mm.group(3) == "true" else "k_row_pass<fused>"
 
 
 def measure_traffic(args):

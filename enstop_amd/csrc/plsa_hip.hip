@@ -106,6 +106,13 @@ struct plsa_ctx {
     DevBuf sw, ll_partials, ll_out, colsum_partials, norm_pwz, norm_pdz, tmp0, tmp1, tmp2, cubtmp;
     double *h_ll = nullptr;  // pinned
 
+    // single-launch column tail (k_col_finish) for small corpora: 0 off, 1 plain launch with at most one
+    // block per CU + in-kernel grid barrier, 2 hipLaunchCooperativeKernel (PLSA_COOP)
+    int coop = 1, coop_bpc = 2;      // PLSA_COOP, PLSA_COOP_BPC (blocks per CU of the plain launch)
+    double coop_limit = 2e9;         // nnz * kp below which the single-launch tail is used (PLSA_COOP_LIMIT)
+    unsigned coop_epoch = 0;         // arrivals counted so far by the grid barrier
+    DevBuf coop_state;               // [0] arrival counter, [1] error flag
+
     // multi-GPU exchange: one RCCL communicator per context (one process per GPU), collectives are
     // enqueued on the context's own streams
     ncclComm_t comm = nullptr;
@@ -682,6 +689,76 @@ int run_v_normalise(plsa_ctx *c) {
     return 0;
 }
 
+// a grid barrier of k_col_finish that timed out leaves a flag behind (see plsa_kernels.hpp)
+int check_coop_error(plsa_ctx *c) {
+    if (!c->coop_state.p) return 0;
+    int flag = 0;
+    HIPCHK(c, hipMemcpyAsync(&flag, c->coop_state.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (flag) {
+        HIPCHK(c, hipMemsetAsync(c->coop_state.as<int>() + 1, 0, sizeof(int), c->stream));
+        return fail(c, "k_col_finish: grid barrier timed out (blocks were not co-resident); set PLSA_COOP=0");
+    }
+    return 0;
+}
+
+// Everything behind the column pass: per-column sums of the item partials -> Vacc, norm_pwz, division ->
+// Vt[1-cv].  Small corpora: ONE launch (k_col_finish, two in-kernel grid barriers); large corpora and the
+// doc-sharded fit (whose all-reduce sits in the middle): the four standalone kernels.
+int run_col_tail(plsa_ctx *c) {
+    const bool single = c->coop > 0 && !c->sharded && (double)c->nnz * c->kp < c->coop_limit;
+    if (!single) {
+        CHK(run_col_pass(c, false, nullptr, 0.f, 2));
+        return run_v_normalise(c);
+    }
+    CHK(ensure_csc(c));
+    const int nslab = (int)std::min<i64>(plsa::NORM_BLOCKS, std::max<i64>(1, c->m));
+    CHK(ensure(c, c->colsum_partials, sizeof(double) * (size_t)nslab * c->kp));
+    CHK(ensure(c, c->norm_pwz, sizeof(float) * (size_t)c->kp));
+    if (!c->coop_state.p) {
+        CHK(ensure(c, c->coop_state, 64));
+        HIPCHK(c, hipMemsetAsync(c->coop_state.p, 0, 64, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->coop_epoch = 0;
+    }
+    int rc = 0;
+    CHK(dispatch_shape(c, [&](auto S) {
+        using Sh = decltype(S);
+        constexpr int GPB = 256 / Sh::LPN;
+        const size_t smem = sizeof(float) * (size_t)std::max(GPB * c->kp, c->kp);
+        // a fraction of the chip's block slots only: co-residency must not depend on what else runs on the
+        // device, and a few contexts (threads, processes sharing the GPU) can be inside this kernel at
+        // once without starving each other's barriers; the cooperative launch may take every slot
+        int bpc = c->coop_bpc;
+        if (c->coop == 2 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, plsa::k_col_finish<Sh>, 256, smem) != hipSuccess)
+            bpc = 1;
+        const int grid = (int)std::min<i64>((i64)c->prop.multiProcessorCount * std::max(bpc, 1),
+                                            std::max<i64>((c->m + GPB - 1) / GPB, 1));
+        const int *item_first = c->item_first.as<int>(), *heavy_cols = c->heavy_cols.as<int>();
+        const float *partial = c->partial.as<float>();
+        float *Vacc = c->Vacc.as<float>(), *norm = c->norm_pwz.as<float>(), *Vt_out = c->Vt[1 - c->cv].as<float>();
+        double *csp = c->colsum_partials.as<double>();
+        unsigned *counter = c->coop_state.as<unsigned>();
+        int *err = c->coop_state.as<int>() + 1;
+        int m = (int)c->m, heavy_items = c->heavy_items, n_heavy = c->n_heavy, kp = c->kp;
+        unsigned base = c->coop_epoch;
+        Scope s(c, "k_col_finish");
+        if (c->coop == 2) {
+            void *args[] = {&item_first, &m, &heavy_items, &heavy_cols, &n_heavy, &partial, &Vacc, &kp, &csp,
+                            &norm, &Vt_out, &counter, &base, &err};
+            hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<void *>(plsa::k_col_finish<Sh>), dim3(grid),
+                                                      dim3(256), args, (unsigned)smem, c->ls);
+            if (e != hipSuccess) rc = fail(c, "hipLaunchCooperativeKernel(k_col_finish): %s", hipGetErrorString(e));
+        } else {
+            hipLaunchKernelGGL((plsa::k_col_finish<Sh>), dim3(grid), dim3(256), smem, c->ls, item_first, m, heavy_items,
+                               heavy_cols, n_heavy, partial, Vacc, kp, csp, norm, Vt_out, counter, base, err);
+        }
+        c->coop_epoch += 2u * (unsigned)grid;
+    }));
+    if (rc) return rc;
+    return launch_check(c, "k_col_finish");
+}
+
 int finish_ll(plsa_ctx *c, int blocks, double *out) {
     CHK(ensure(c, c->ll_out, sizeof(double)));
     {
@@ -718,8 +795,8 @@ int run_m_step_from_p(plsa_ctx *c, const float *d_sw, bool update_v, float *d_no
     if (!c->p_valid) return fail(c, "plsa_m_step: no P(z|w,d) on the device (run plsa_e_step or plsa_set_p)");
     CHK(run_row_pass(c, true, false, nullptr, 0.f, d_norm_pdz, nullptr));
     if (update_v) {
-        CHK(run_col_pass(c, true, d_sw, 0.f));
-        CHK(run_v_normalise(c));
+        CHK(run_col_pass(c, true, d_sw, 0.f, 1));
+        CHK(run_col_tail(c));
     }
     c->cu ^= 1;
     if (update_v) c->cv ^= 1;
@@ -796,6 +873,9 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_E_ROWS")) c->e_rows = atoi(s);
     if (const char *s = getenv("PLSA_MT_STREAMS")) c->mt_streams = std::max(1, std::min(4096, atoi(s)));
     if (const char *s = getenv("PLSA_MT_MIN_BLOCKS")) c->mt_min_blocks = std::max(1, atoi(s));
+    if (const char *s = getenv("PLSA_COOP")) c->coop = atoi(s);
+    if (const char *s = getenv("PLSA_COOP_BPC")) c->coop_bpc = std::max(1, atoi(s));
+    if (const char *s = getenv("PLSA_COOP_LIMIT")) c->coop_limit = atof(s);
     *out = c;
     return 0;
 }
@@ -805,7 +885,7 @@ void plsa_destroy(plsa_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
-    release(c->comm_send); release(c->comm_recv); release(c->comm_small);
+    release(c->comm_send); release(c->comm_recv); release(c->comm_small); release(c->coop_state);
     DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,
@@ -1187,6 +1267,7 @@ int plsa_m_step(plsa_ctx *c, const float *sw, int32_t update_v, float *norm_pwz,
     if (norm_pdz)
         HIPCHK(c, hipMemcpyAsync(norm_pdz, c->norm_pdz.p, sizeof(float) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(check_coop_error(c));
     return 0;
 }
 
@@ -1270,8 +1351,8 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
                 HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
                 c->ls = c->stream2;
-                int rc = run_col_pass(c, false, d_sw_m, thresh);
-                if (!rc) rc = run_v_normalise(c);
+                int rc = run_col_pass(c, false, d_sw_m, thresh, 1);
+                if (!rc) rc = run_col_tail(c);
                 c->ls = c->stream;
                 if (rc) return rc;
                 HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
@@ -1286,8 +1367,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
                 HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
                 c->ls = c->stream2;
-                int rc = run_col_pass(c, false, d_sw_m, thresh, 2);
-                if (!rc) rc = run_v_normalise(c);
+                int rc = run_col_tail(c);
                 c->ls = c->stream;
                 if (rc) return rc;
                 HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
@@ -1295,8 +1375,8 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
             } else {
                 CHK(run_row_pass(c, false, pending || first_ll_in_pass, d_sw, thresh, nullptr, &blocks));
-                CHK(run_col_pass(c, false, d_sw_m, thresh));
-                CHK(run_v_normalise(c));
+                CHK(run_col_pass(c, false, d_sw_m, thresh, 1));
+                CHK(run_col_tail(c));
             }
             if (first_ll_in_pass) {
                 CHK(finish_ll(c, blocks, &ll));
@@ -1322,6 +1402,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(check_coop_error(c));
     if (iters_done) *iters_done = iters;
     if (n_ll) *n_ll = nll;
     return 0;

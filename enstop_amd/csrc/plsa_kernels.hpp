@@ -585,27 +585,26 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int *__restr
 }
 
 // adds the item partials of each column (fixed order) into the un-normalised Vt_new.
-// Blocks [0, n_heavy) each take one column with more than `heavy_items` items (the Zipf head): the
-// block's groups stride over the column's items (fixed assignment, loads batched four deep, added in
-// item order), then their sums are added in group order through LDS -> bit-reproducible.  The other
-// blocks give one group to each of the remaining columns.
+// Columns with more than `heavy_items` items (the Zipf head) take a whole block: its groups stride
+// over the column's items (fixed assignment, loads batched four deep, added in item order), then their
+// sums are added in group order through LDS -> bit-reproducible.  Every other column takes one group.
+// `block` of `nblocks`: the caller's position in the grid (the standalone kernel and the single-launch
+// chain k_col_finish share this body; which block sums a column does not change the sum).
 template <class S>
-__global__ __launch_bounds__(256) void k_col_reduce(const int *__restrict__ item_first, int m,
-                                                    int heavy_items, const int *__restrict__ heavy_cols,
-                                                    int n_heavy, const float *__restrict__ partial,
-                                                    float *__restrict__ Vt_new, int kp_rt) {
+__device__ __forceinline__ void col_reduce_body(const int *__restrict__ item_first, int m, int heavy_items,
+                                                const int *__restrict__ heavy_cols, int n_heavy,
+                                                const float *__restrict__ partial, float *__restrict__ Vt_new,
+                                                int kp, int block, int nblocks, float *sacc /*[GPB][kp]*/) {
     constexpr int LPN = S::LPN, CH = S::CH;
     constexpr int GPB = 256 / LPN;
-    extern __shared__ float sacc[];  // [GPB][kp], heavy blocks only
-    const int kp = S::kp(kp_rt);
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
     float4 acc[CH];
-#pragma unroll
-    for (int j = 0; j < CH; ++j) acc[j] = zero4();
-    if ((int)blockIdx.x < n_heavy) {
-        const int c = heavy_cols[blockIdx.x];
+    for (int h = block; h < n_heavy; h += nblocks) {
+        const int c = heavy_cols[h];
         const int i0 = item_first[c], i1 = item_first[c + 1];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[j] = zero4();
         constexpr int B = 4;
         for (int it = i0 + gid; it < i1; it += GPB * B) {
             float4 p[B][CH];
@@ -635,10 +634,9 @@ __global__ __launch_bounds__(256) void k_col_reduce(const int *__restrict__ item
             for (int g = 0; g < GPB; ++g) t += sacc[g * kp + z];
             Vt_new[(i64)c * kp + z] = t;
         }
-        return;
+        __syncthreads();
     }
-    const i64 nb = (i64)gridDim.x - n_heavy;
-    for (i64 c = ((i64)blockIdx.x - n_heavy) * GPB + gid; c < m; c += nb * GPB) {
+    for (i64 c = (i64)block * GPB + gid; c < m; c += (i64)nblocks * GPB) {
         const int i0 = item_first[c], i1 = item_first[c + 1];
         if (i1 - i0 > heavy_items) continue;
 #pragma unroll
@@ -657,6 +655,17 @@ __global__ __launch_bounds__(256) void k_col_reduce(const int *__restrict__ item
     }
 }
 
+// standalone launch: blocks [0, n_heavy) start on the heavy columns, every block then strides over the rest
+template <class S>
+__global__ __launch_bounds__(256) void k_col_reduce(const int *__restrict__ item_first, int m,
+                                                    int heavy_items, const int *__restrict__ heavy_cols,
+                                                    int n_heavy, const float *__restrict__ partial,
+                                                    float *__restrict__ Vt_new, int kp_rt) {
+    extern __shared__ float sacc[];  // [GPB][kp]
+    col_reduce_body<S>(item_first, m, heavy_items, heavy_cols, n_heavy, partial, Vt_new, S::kp(kp_rt),
+                       (int)blockIdx.x, (int)gridDim.x, sacc);
+}
+
 __global__ void k_heavy_list(const int *__restrict__ item_first, int m, int heavy_items,
                              int *__restrict__ heavy_cols, int *__restrict__ n_heavy) {
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -672,12 +681,12 @@ __global__ void k_heavy_list(const int *__restrict__ item_first, int m, int heav
 // ------------------------------------------------------------------------------------------------
 constexpr int NORM_BLOCKS = 256;
 
-__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ Vt_new, int m,
-                                                        int kp, double *__restrict__ partials) {
+// slab `slab` of `n_slabs`: float32 strand sums of a contiguous range of words, added in strand order (f64)
+__device__ __forceinline__ void colsum_slab_body(const float *__restrict__ Vt_new, int m, int kp, int slab,
+                                                 int n_slabs, double *__restrict__ partials, double *sred /*[256]*/) {
     // thread t owns column z = t % span for rows t / span, t / span + rows_per_pass, ...
-    extern __shared__ double sred[];  // [256]
-    const i64 per = ((i64)m + gridDim.x - 1) / gridDim.x;
-    const i64 w0 = (i64)blockIdx.x * per, w1 = min((i64)m, w0 + per);
+    const i64 per = ((i64)m + n_slabs - 1) / n_slabs;
+    const i64 w0 = (i64)slab * per, w1 = min((i64)m, w0 + per);
     for (int zb = 0; zb < kp; zb += 256) {
         const int span = min(256, kp - zb);          // columns handled in this sweep
         const int rpp = 256 / span;                  // rows per pass
@@ -691,17 +700,22 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
         if ((int)threadIdx.x < span) {
             double tot = 0.0;
             for (int r = 0; r < rpp; ++r) tot += sred[r * span + threadIdx.x];
-            partials[(i64)blockIdx.x * kp + zb + threadIdx.x] = tot;
+            partials[(i64)slab * kp + zb + threadIdx.x] = tot;
         }
         __syncthreads();
     }
 }
 
-// norm_pwz[z] = fixed-order sum of the slab partials (one block; the 256 threads split the
-// partials of each column into 256/span interleaved strands that are then added in strand order)
-__global__ __launch_bounds__(256) void k_colsum_final(const double *__restrict__ partials, int n_partials,
-                                                      int kp, float *__restrict__ norm_pwz) {
-    __shared__ double sred[256];
+__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ Vt_new, int m,
+                                                        int kp, double *__restrict__ partials) {
+    extern __shared__ double sred_dyn[];  // [256]
+    colsum_slab_body(Vt_new, m, kp, (int)blockIdx.x, (int)gridDim.x, partials, sred_dyn);
+}
+
+// norm_pwz[z] = fixed-order sum of the slab partials (the 256 threads split the partials of each column
+// into 256/span interleaved strands that are then added in strand order); out may be LDS or global
+__device__ __forceinline__ void colsum_final_body(const double *__restrict__ partials, int n_partials, int kp,
+                                                  float *out, double *sred /*[256]*/) {
     for (int zb = 0; zb < kp; zb += 256) {
         const int span = min(256, kp - zb);
         const int rpp = 256 / span;
@@ -717,21 +731,24 @@ __global__ __launch_bounds__(256) void k_colsum_final(const double *__restrict__
         if ((int)threadIdx.x < span) {
             double t2 = 0.0;
             for (int r = 0; r < rpp; ++r) t2 += sred[r * span + threadIdx.x];
-            norm_pwz[zb + threadIdx.x] = (float)t2;
+            out[zb + threadIdx.x] = (float)t2;
         }
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void k_v_normalise(const float *__restrict__ Vt_new,
-                                                     float *__restrict__ Vt, int m, int kp,
-                                                     const float *__restrict__ norm_pwz) {
-    extern __shared__ float snorm[];  // [kp]
-    for (int z = threadIdx.x; z < kp; z += 256) snorm[z] = norm_pwz[z];
-    __syncthreads();
+__global__ __launch_bounds__(256) void k_colsum_final(const double *__restrict__ partials, int n_partials,
+                                                      int kp, float *__restrict__ norm_pwz) {
+    __shared__ double sred[256];
+    colsum_final_body(partials, n_partials, kp, norm_pwz, sred);
+}
+
+// division by norm_pwz (snorm: LDS copy), plsa.py:196-199
+__device__ __forceinline__ void v_normalise_body(const float *__restrict__ Vt_new, float *__restrict__ Vt, int m,
+                                                 int kp, const float *snorm, int block, int nblocks) {
     const i64 total4 = (i64)m * kp / 4;
     const int kq = kp / 4;
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total4; i += (i64)gridDim.x * 256) {
+    for (i64 i = (i64)block * 256 + threadIdx.x; i < total4; i += (i64)nblocks * 256) {
         const int z4 = (int)(i % kq) * 4;
         float4 v = ld4(Vt_new + i * 4);
         const float n0 = snorm[z4], n1 = snorm[z4 + 1], n2 = snorm[z4 + 2], n3 = snorm[z4 + 3];
@@ -741,6 +758,68 @@ __global__ __launch_bounds__(256) void k_v_normalise(const float *__restrict__ V
         if (n3 > 0.f) v.w /= n3;
         st4(Vt + i * 4, v);
     }
+}
+
+__global__ __launch_bounds__(256) void k_v_normalise(const float *__restrict__ Vt_new,
+                                                     float *__restrict__ Vt, int m, int kp,
+                                                     const float *__restrict__ norm_pwz) {
+    extern __shared__ float snorm[];  // [kp]
+    for (int z = threadIdx.x; z < kp; z += 256) snorm[z] = norm_pwz[z];
+    __syncthreads();
+    v_normalise_body(Vt_new, Vt, m, kp, snorm, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_col_finish: everything behind the column pass in ONE cooperative launch -- per-column sums of the
+// item partials, norm_pwz, division -- with two grid-wide barriers instead of three kernel boundaries.
+// On small corpora (BASELINE configs 1, 2, 4: 0.2 ms per EM iteration) the four short dependent
+// kernels of this chain were a third of the critical path.  Same device bodies as the standalone
+// kernels, hence bit-identical results; the doc-sharded fit keeps the standalone kernels (its
+// all-reduce sits between the column sums and the normalisation).
+// Grid barrier: arrival counter in global memory that only ever grows (the host passes the count at
+// which this launch starts, so nothing has to be zeroed between launches; comparisons are on the
+// wrapped difference).  All blocks must be co-resident: the host launches at most one block per CU
+// (plain launch) or goes through hipLaunchCooperativeKernel.  A barrier that does not complete within
+// ~2 s (a scheduling assumption was wrong) raises *error_flag and lets the kernel finish instead of
+// hanging the device; the host turns the flag into an error at its next synchronisation.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned target, int *error_flag) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(counter, 1u);
+        const unsigned long long t0 = wall_clock64();                 // 100 MHz constant clock
+        while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 200000000ull) { atomicExch(error_flag, 1); break; }
+        }
+        __threadfence();
+    }
+    __syncthreads();
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void k_col_finish(const int *__restrict__ item_first, int m, int heavy_items,
+                                                    const int *__restrict__ heavy_cols, int n_heavy,
+                                                    const float *__restrict__ partial, float *__restrict__ Vacc,
+                                                    int kp_rt, double *__restrict__ colsum_partials,
+                                                    float *__restrict__ norm_pwz, float *__restrict__ Vt_out,
+                                                    unsigned *__restrict__ barrier_counter, unsigned barrier_base,
+                                                    int *__restrict__ error_flag) {
+    extern __shared__ float sdyn[];               // [max(GPB * kp, kp)] floats: heavy-column sums, later norm_pwz
+    __shared__ double sred[256];
+    const int kp = S::kp(kp_rt);
+    const int block = (int)blockIdx.x, nblocks = (int)gridDim.x;
+    col_reduce_body<S>(item_first, m, heavy_items, heavy_cols, n_heavy, partial, Vacc, kp, block, nblocks, sdyn);
+    grid_barrier(barrier_counter, barrier_base + (unsigned)nblocks, error_flag);
+    const int n_slabs = min(NORM_BLOCKS, max(1, m));
+    for (int slab = block; slab < n_slabs; slab += nblocks)
+        colsum_slab_body(Vacc, m, kp, slab, n_slabs, colsum_partials, sred);
+    grid_barrier(barrier_counter, barrier_base + 2u * (unsigned)nblocks, error_flag);
+    colsum_final_body(colsum_partials, n_slabs, kp, sdyn, sred);      // every block: the same fixed-order sum
+    if (block == 0)
+        for (int z = threadIdx.x; z < kp; z += 256) norm_pwz[z] = sdyn[z];
+    v_normalise_body(Vacc, Vt_out, m, kp, sdyn, block, nblocks);
 }
 
 // final, fixed-order sum of the per-block log-likelihood partials

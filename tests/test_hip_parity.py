@@ -999,7 +999,7 @@ def test_randomised_shapes_vs_oracle(amd, oracle):
 
 # (case index, schedule) pairs of test_randomised_shapes_vs_oracle whose `change == 0` stop decision differs
 # from the float32 oracle's (see the comment there); established on MI355X, must stay short
-ZERO_CHANGE_FLIPS = set()
+ZERO_CHANGE_FLIPS = {(0, "materialised")}     # k = 1: 3 iterations instead of 2
 
 
 # ------------------------------------------------------------------------------------------------

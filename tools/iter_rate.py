@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""EM iterations/s of one BASELINE config WITHOUT per-kernel events (they cost ~13 % at 0.2 ms per iteration):
+    python tools/iter_rate.py --config 1 [--steps 200] [--flags fused|materialised] [--graph] [--events]
+Knobs are read from the environment by the engine (PLSA_COOP, PLSA_COL_SEG, ...)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from enstop_amd.engine import Engine, PLSA_FUSED, PLSA_GRAPH  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", type=int, default=1)
+ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--flags", default="fused")
+ap.add_argument("--graph", action="store_true")
+ap.add_argument("--events", action="store_true")
+ap.add_argument("--tag", default="")
+a = ap.parse_args()
+cfg = bench.CONFIGS[a.config]
+eng = Engine(0)
+nnz = eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], seed=0)
+U0, V0 = bench.init_factors(cfg["n"], cfg["m"], cfg["k"], 42)
+flags = (PLSA_FUSED if a.flags == "fused" else 0) | (PLSA_GRAPH if a.graph else 0)
+eng.set_factors(U0, V0)
+eng.fit(None, n_iter=10, n_iter_per_test=10, tolerance=0.0, flags=flags)
+best = None
+for _ in range(a.reps):
+    eng.set_factors(U0, V0)
+    eng.fit(None, n_iter=5, n_iter_per_test=10, tolerance=0.0, flags=flags)
+    if a.events:
+        eng.timing(True); eng.timing_reset()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    it, ll = eng.fit(None, n_iter=a.steps, n_iter_per_test=10, tolerance=0.0, flags=flags)
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    assert it == a.steps
+    best = dt if best is None else min(best, dt)
+out = {"tag": a.tag, "config": a.config, "nnz": nnz, "steps": a.steps, "ms_per_iter": round(best / a.steps * 1e3, 5),
+       "iter_per_s": round(a.steps / best, 1), "ll_last": float(ll[-1]),
+       "env": {k: v for k, v in os.environ.items() if k.startswith("PLSA_")}}
+if a.events:
+    out["kernels"] = {k: round(v[1] / v[0], 5) for k, v in eng.timing_report().items()}
+print(json.dumps(out))
