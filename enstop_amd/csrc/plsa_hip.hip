@@ -106,12 +106,16 @@ struct plsa_ctx {
     DevBuf sw, ll_partials, ll_out, colsum_partials, norm_pwz, norm_pdz, tmp0, tmp1, tmp2, cubtmp;
     double *h_ll = nullptr;  // pinned
 
-    // single-launch column tail (k_col_finish) for small corpora: 0 off, 1 plain launch with at most one
-    // block per CU + in-kernel grid barrier, 2 hipLaunchCooperativeKernel (PLSA_COOP)
-    int coop = 1, coop_bpc = 2;      // PLSA_COOP, PLSA_COOP_BPC (blocks per CU of the plain launch)
-    double coop_limit = 2e9;         // nnz * kp below which the single-launch tail is used (PLSA_COOP_LIMIT)
-    unsigned coop_epoch = 0;         // arrivals counted so far by the grid barrier
-    DevBuf coop_state;               // [0] arrival counter, [1] error flag
+    // hot columns: words with >= hot_min_per_tile entries per block of `hb` documents on average are cut at
+    // the block boundaries and processed by k_col_hot (P(z|d) rows of a block staged in LDS)
+    int hot_mode = 1;                // PLSA_HOT: 0 off, 1 on (fused schedule)
+    double hot_min_per_tile = 8.0;   // PLSA_HOT_MIN
+    int hot_lds_kb = 64;             // PLSA_HOT_LDS_KB: LDS per workgroup for the staged block
+    int hb = 0, n_tiles = 0, n_hot = 0, struct_kp = 0;
+    i64 n_cold_items = 0;
+    DevBuf hot_cols, item_end, colsum_rows, colsum_rows2;
+    int colsum_rows_used = 0;        // rows of colsum_rows written by the last column pass
+    hipEvent_t ev_hot = nullptr, ev_cold = nullptr;
 
     // multi-GPU exchange: one RCCL communicator per context (one process per GPU), collectives are
     // enqueued on the context's own streams
@@ -452,34 +456,71 @@ int ensure_csc(plsa_ctx *c) {
     } else {
         HIPCHK(c, hipMemsetAsync(c->colptr.p, 0, sizeof(int) * (size_t)(m + 1), c->stream));
     }
-    // column items
+    // column items (ordinary chunks + hot tiles, see k_col_item_counts)
+    {
+        // block of documents whose P(z|d) rows fit the LDS budget of k_col_hot (power of two)
+        const int kp = std::max(c->kp, 4);
+        int hb = 32;
+        while (hb * 2 * kp * 4 <= c->hot_lds_kb * 1024 && hb < 4096) hb *= 2;
+        c->hb = hb;
+        c->n_tiles = (int)((c->n + hb - 1) / hb);
+        c->struct_kp = c->kp;
+    }
+    const bool hot_on = c->hot_mode > 0 && c->kp > 0 && c->n_tiles >= 8;
+    const double hot_min_d = hot_on ? std::max(c->hot_min_per_tile * (double)c->n_tiles, (double)c->seg) : 0.0;
+    const int hot_min = hot_on ? (int)std::min<double>(hot_min_d, 2.0e9) : 0;
     CHK(ensure(c, c->item_first, sizeof(int) * (size_t)(m + 1)));
-    HIPCHK(c, hipMemsetAsync(c->tmp0.p, 0, sizeof(int) * (size_t)(m + 1), c->stream));
-    hipLaunchKernelGGL(plsa::k_item_counts, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                       c->colptr.as<int>(), (int)m, c->seg, c->tmp0.as<int>());
-    CHK(exclusive_sum_int(c, c->tmp0.as<int>(), c->item_first.as<int>(), m + 1));
-    int n_items = 0;
+    CHK(ensure(c, c->tmp0, sizeof(int) * (size_t)(m + 1) * 2));      // counts, hot flags
+    CHK(ensure(c, c->hot_cols, sizeof(int) * (size_t)(m + 1)));
+    int *d_cnt = c->tmp0.as<int>(), *d_flag = c->tmp0.as<int>() + (m + 1);
+    HIPCHK(c, hipMemsetAsync(c->tmp0.p, 0, sizeof(int) * (size_t)(m + 1) * 2, c->stream));
+    hipLaunchKernelGGL(plsa::k_col_item_counts, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                       c->colptr.as<int>(), (int)m, c->seg, hot_min, c->n_tiles, d_cnt, d_flag);
+    CHK(exclusive_sum_int(c, d_cnt, c->item_first.as<int>(), m + 1));
+    {   // the hot columns in ascending word order (deterministic), their count behind the list
+        CHK(ensure(c, c->tmp1, sizeof(int) * (size_t)std::max<i64>(nnz, m + 1)));
+        hipLaunchKernelGGL(plsa::k_iota, dim3(grid_for(c, m, 256)), dim3(256), 0, c->stream, c->tmp1.as<int>(), m);
+        size_t bytes = 0;
+        HIPCHK(c, hipcub::DeviceSelect::Flagged(nullptr, bytes, c->tmp1.as<int>(), d_flag, c->hot_cols.as<int>(),
+                                                c->hot_cols.as<int>() + m, (int)m, c->stream));
+        CHK(ensure(c, c->cubtmp, bytes));
+        HIPCHK(c, hipcub::DeviceSelect::Flagged(c->cubtmp.p, bytes, c->tmp1.as<int>(), d_flag, c->hot_cols.as<int>(),
+                                                c->hot_cols.as<int>() + m, (int)m, c->stream));
+    }
+    int n_items = 0, n_hot = 0;
     HIPCHK(c, hipMemcpyAsync(&n_items, c->item_first.as<int>() + m, sizeof(int), hipMemcpyDeviceToHost,
                              c->stream));
+    HIPCHK(c, hipMemcpyAsync(&n_hot, c->hot_cols.as<int>() + m, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_items = n_items;
-    CHK(ensure(c, c->item_col, sizeof(int) * (size_t)n_items));
-    CHK(ensure(c, c->item_start, sizeof(int) * (size_t)n_items));
-    CHK(ensure(c, c->item_order, sizeof(int) * (size_t)n_items));
-    CHK(ensure(c, c->tmp0, sizeof(int) * (size_t)std::max<i64>(n_items, 1) * 2));   // doc0, doc0 sorted
-    CHK(ensure(c, c->tmp1, sizeof(int) * (size_t)std::max<i64>(n_items, 1)));       // item ids
+    c->n_hot = n_hot;
+    c->n_cold_items = (i64)n_items - (i64)n_hot * c->n_tiles;
+    const size_t ni = (size_t)std::max<i64>(n_items, 1);
+    CHK(ensure(c, c->item_col, sizeof(int) * ni));
+    CHK(ensure(c, c->item_start, sizeof(int) * ni));
+    CHK(ensure(c, c->item_end, sizeof(int) * ni));
+    CHK(ensure(c, c->item_order, sizeof(int) * ni));
+    CHK(ensure(c, c->tmp2, sizeof(int) * ni * 2));                                   // keys, keys sorted
+    CHK(ensure(c, c->tmp1, sizeof(int) * std::max(ni, (size_t)std::max<i64>(nnz, m + 1))));   // item ids
+    unsigned *d_key = c->tmp2.as<unsigned>();
     hipLaunchKernelGGL(plsa::k_item_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                       c->colptr.as<int>(), c->item_first.as<int>(), (int)m, c->seg, c->csc_row.as<int>(),
-                       c->item_col.as<int>(), c->item_start.as<int>(), c->tmp0.as<int>(), c->tmp1.as<int>());
+                       c->colptr.as<int>(), c->item_first.as<int>(), d_flag, (int)m, c->seg, (int)c->n,
+                       c->csc_row.as<int>(), c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(),
+                       d_key, c->tmp1.as<int>());
+    if (n_hot > 0)
+        hipLaunchKernelGGL(plsa::k_hot_item_fill, dim3(grid_for(c, (i64)n_hot * c->n_tiles, 256)), dim3(256), 0, c->stream,
+                           c->hot_cols.as<int>(), n_hot, c->n_tiles, c->hb, (int)c->n, c->colptr.as<int>(),
+                           c->item_first.as<int>(), c->csc_row.as<int>(), c->item_col.as<int>(),
+                           c->item_start.as<int>(), c->item_end.as<int>(), d_key, c->tmp1.as<int>());
     CHK(launch_check(c, "k_item_fill"));
-    if (n_items > 0) {   // visiting order: ascending first document (stable) -> doc-band-major
+    if (n_items > 0) {   // visiting order: ascending first document (stable) -> doc-band-major; hot tiles last
         int dbits = 1;
-        while (((i64)1 << dbits) < c->n) ++dbits;
+        while (((i64)1 << dbits) < 2 * c->n) ++dbits;
         size_t bytes = 0;
-        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, c->tmp0.as<int>(), c->tmp0.as<int>() + n_items,
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, d_key, d_key + ni,
                                                      c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, dbits, c->stream));
         CHK(ensure(c, c->cubtmp, bytes));
-        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, bytes, c->tmp0.as<int>(), c->tmp0.as<int>() + n_items,
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, bytes, d_key, d_key + ni,
                                                      c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, dbits, c->stream));
     }
     // columns whose item count makes a single group's serial reduction a tail (Zipf head words)
@@ -502,6 +543,27 @@ int upload_sw(plsa_ctx *c, const float *sw, const float **d_sw) {
     HIPCHK(c, hipMemcpyAsync(c->sw.p, sw, sizeof(float) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
     *d_sw = c->sw.as<float>();
     return 0;
+}
+
+// lane decomposition of a k-vector (see plsa_kernels.hpp) + invalidation of the structures that depend on it
+void set_shape(plsa_ctx *c, int k) {
+    const int kp = (k + 3) / 4 * 4;
+    c->k = k; c->kp = kp;
+    const int prev_lpn = c->struct_lpn;
+    int lpn = 1;
+    while (lpn < kp / 4 && lpn < 64) lpn *= 2;
+    // k >= 128: 8 floats per lane (two float4 chunks) -- fewer reduction/shuffle instructions per
+    // cell, each access still covers whole 128-B lines (measured: config 5 document pass -15 %)
+    if (lpn >= 32 && lpn * 4 >= kp && c->chunks_per_lane == 2) lpn /= 2;
+    c->lpn = lpn;
+    c->ch = (kp / 4 + lpn - 1) / lpn;
+    if (c->ch == 3) c->ch = 4;
+    if (lpn != prev_lpn) {        // item lengths / the row-item decision depend on the lane shape
+        c->ritems_valid = false;
+        if (!c->seg_override) c->csc_valid = false;
+        c->struct_lpn = lpn;
+    }
+    if (c->hot_mode > 0 && kp != c->struct_kp) c->csc_valid = false;   // the hot tiles' block size depends on kp
 }
 
 int need_factors(plsa_ctx *c) {
@@ -614,44 +676,67 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, floa
     return 0;
 }
 
-// vocabulary-owned pass (no atomics): partial k-vectors per column item, then per-column sums -> Vacc
-// parts: 1 = the column pass itself, 2 = the per-column sums of its partials, 3 = both
+// vocabulary-owned pass (no atomics): partial k-vectors per column item (+ per-block sums of them, from
+// which the column tail gets norm_pwz), then per-column sums -> Vacc
+// parts: 1 = the column pass itself (ordinary items by k_col_pass, hot tiles by k_col_hot in the fused
+//        schedule), 2 = the un-normalised per-column sums of its partials (k_col_reduce), 3 = both
 int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int parts = 3) {
     CHK(ensure_csc(c));
     CHK(ensure(c, c->partial, sizeof(float) * (size_t)std::max<i64>(c->n_items, 1) * c->kp));
+    int rc = 0;
     CHK(dispatch_shape(c, [&](auto S) {
         using Sh = decltype(S);
-        constexpr int LPN = Sh::LPN;
-        const int grid = grid_for(c, c->n_items, 256 / LPN);
-        const int grid2 = grid_for(c, c->m, 256 / LPN);
-        const int *order = c->use_item_order ? c->item_order.as<int>() : nullptr;
+        constexpr int LPN = Sh::LPN, GPB = 256 / LPN;
+        const bool hot = !from_p && c->n_hot > 0;          // hot tiles by their own kernel (U rows from LDS)
+        const i64 n_visit = hot ? c->n_cold_items : c->n_items;
+        const int grid = grid_for(c, n_visit, GPB);
+        const int grid_hot = hot ? c->n_tiles : 0;
+        const int grid2 = grid_for(c, c->m, GPB);
+        const int *order = c->item_order.as<int>();
         const int xcd_split = (c->xcd_split && grid >= 64) ? 1 : 0;
-        if (c->n_items > 0 && (parts & 1)) {
+        if (parts & 1) {
+            rc = ensure(c, c->colsum_rows, sizeof(double) * (size_t)(grid + grid_hot) * c->kp);
+            if (rc) return;
+            const size_t smem = sizeof(double) * (size_t)GPB * c->kp;
             if (from_p) {
                 Scope s(c, "k_col_pass<P>");
-                hipLaunchKernelGGL((plsa::k_col_pass<Sh, true>), dim3(grid), dim3(256), 0, c->ls, order,
-                                   c->item_col.as<int>(), c->item_start.as<int>(), c->colptr.as<int>(),
-                                   c->n_items, c->seg, c->csc_row.as<int>(), c->csc_val.as<float>(),
+                hipLaunchKernelGGL((plsa::k_col_pass<Sh, true>), dim3(grid), dim3(256), smem, c->ls, order,
+                                   c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(),
+                                   n_visit, c->csc_row.as<int>(), c->csc_val.as<float>(),
                                    c->csc_pos.as<int>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
-                                   p_base(c), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split);
+                                   p_base(c), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split,
+                                   c->colsum_rows.as<double>());
             } else {
                 Scope s(c, "k_col_pass<fused>");
-                hipLaunchKernelGGL((plsa::k_col_pass<Sh, false>), dim3(grid), dim3(256), 0, c->ls, order,
-                                   c->item_col.as<int>(), c->item_start.as<int>(), c->colptr.as<int>(),
-                                   c->n_items, c->seg, c->csc_row.as<int>(), c->csc_val.as<float>(),
+                hipLaunchKernelGGL((plsa::k_col_pass<Sh, false>), dim3(grid), dim3(256), smem, c->ls, order,
+                                   c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(),
+                                   n_visit, c->csc_row.as<int>(), c->csc_val.as<float>(),
                                    c->csc_pos.as<int>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
-                                   p_base(c), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split);
+                                   p_base(c), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split,
+                                   c->colsum_rows.as<double>());
             }
+            if (hot) {
+                const size_t lds = std::max(sizeof(float) * (size_t)c->hb * c->kp, smem);
+                Scope s(c, "k_col_hot");
+                hipLaunchKernelGGL((plsa::k_col_hot<Sh>), dim3(grid_hot), dim3(256), lds, c->ls, c->hot_cols.as<int>(),
+                                   c->n_hot, c->n_tiles, c->hb, (int)c->n, c->item_first.as<int>(),
+                                   c->item_start.as<int>(), c->item_end.as<int>(), c->csc_row.as<int>(),
+                                   c->csc_val.as<float>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(), d_sw,
+                                   c->partial.as<float>(), c->kp, thresh,
+                                   c->colsum_rows.as<double>() + (size_t)grid * c->kp);
+            }
+            c->colsum_rows_used = grid + grid_hot;
         }
         if (parts & 2) {
             // heavy columns (one block each) and the rest share one launch
             Scope s(c, "k_col_reduce");
             hipLaunchKernelGGL((plsa::k_col_reduce<Sh>), dim3(grid2 + c->n_heavy), dim3(256),
-                               c->n_heavy > 0 ? (256 / LPN) * c->kp * sizeof(float) : 0, c->ls,
+                               (256 / LPN) * c->kp * sizeof(float), c->ls,
                                c->item_first.as<int>(), (int)c->m, c->heavy_items, c->heavy_cols.as<int>(), c->n_heavy,
                                c->partial.as<float>(), c->Vacc.as<float>(), c->kp);
         }
     }));
+    if (rc) return rc;
     CHK(launch_check(c, "k_col_pass"));
     return 0;
 }
@@ -689,74 +774,41 @@ int run_v_normalise(plsa_ctx *c) {
     return 0;
 }
 
-// a grid barrier of k_col_finish that timed out leaves a flag behind (see plsa_kernels.hpp)
-int check_coop_error(plsa_ctx *c) {
-    if (!c->coop_state.p) return 0;
-    int flag = 0;
-    HIPCHK(c, hipMemcpyAsync(&flag, c->coop_state.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (flag) {
-        HIPCHK(c, hipMemsetAsync(c->coop_state.as<int>() + 1, 0, sizeof(int), c->stream));
-        return fail(c, "k_col_finish: grid barrier timed out (blocks were not co-resident); set PLSA_COOP=0");
-    }
-    return 0;
-}
-
-// Everything behind the column pass: per-column sums of the item partials -> Vacc, norm_pwz, division ->
-// Vt[1-cv].  Small corpora: ONE launch (k_col_finish, two in-kernel grid barriers); large corpora and the
-// doc-sharded fit (whose all-reduce sits in the middle): the four standalone kernels.
+// Everything behind the column pass: norm_pwz from the pass' own per-block sums (two small launches),
+// then per-column sums of the item partials and the division in ONE sweep (k_col_reduce_norm) ->
+// Vt[1-cv].  The doc-sharded fit needs the un-normalised accumulator for its all-reduce and keeps the
+// four-kernel form (k_col_reduce, k_colsum_partial, k_colsum_final, k_v_normalise).
 int run_col_tail(plsa_ctx *c) {
-    const bool single = c->coop > 0 && !c->sharded && (double)c->nnz * c->kp < c->coop_limit;
-    if (!single) {
+    if (c->sharded) {
         CHK(run_col_pass(c, false, nullptr, 0.f, 2));
         return run_v_normalise(c);
     }
-    CHK(ensure_csc(c));
-    const int nslab = (int)std::min<i64>(plsa::NORM_BLOCKS, std::max<i64>(1, c->m));
-    CHK(ensure(c, c->colsum_partials, sizeof(double) * (size_t)nslab * c->kp));
+    const int rows = c->colsum_rows_used;
+    if (rows <= 0) return fail(c, "internal: column tail without a column pass");
+    const int nb = std::min(rows, 64);
+    CHK(ensure(c, c->colsum_rows2, sizeof(double) * (size_t)nb * c->kp));
     CHK(ensure(c, c->norm_pwz, sizeof(float) * (size_t)c->kp));
-    if (!c->coop_state.p) {
-        CHK(ensure(c, c->coop_state, 64));
-        HIPCHK(c, hipMemsetAsync(c->coop_state.p, 0, 64, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->coop_epoch = 0;
+    {
+        Scope s(c, "k_norm_reduce");
+        hipLaunchKernelGGL(plsa::k_norm_reduce, dim3(nb), dim3(256), 0, c->ls, c->colsum_rows.as<double>(), rows, c->kp,
+                           c->colsum_rows2.as<double>());
     }
-    int rc = 0;
+    {
+        Scope s(c, "k_colsum_final");
+        hipLaunchKernelGGL(plsa::k_colsum_final, dim3(1), dim3(256), 0, c->ls, c->colsum_rows2.as<double>(), nb, c->kp,
+                           c->norm_pwz.as<float>());
+    }
     CHK(dispatch_shape(c, [&](auto S) {
         using Sh = decltype(S);
         constexpr int GPB = 256 / Sh::LPN;
-        const size_t smem = sizeof(float) * (size_t)std::max(GPB * c->kp, c->kp);
-        // a fraction of the chip's block slots only: co-residency must not depend on what else runs on the
-        // device, and a few contexts (threads, processes sharing the GPU) can be inside this kernel at
-        // once without starving each other's barriers; the cooperative launch may take every slot
-        int bpc = c->coop_bpc;
-        if (c->coop == 2 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, plsa::k_col_finish<Sh>, 256, smem) != hipSuccess)
-            bpc = 1;
-        const int grid = (int)std::min<i64>((i64)c->prop.multiProcessorCount * std::max(bpc, 1),
-                                            std::max<i64>((c->m + GPB - 1) / GPB, 1));
-        const int *item_first = c->item_first.as<int>(), *heavy_cols = c->heavy_cols.as<int>();
-        const float *partial = c->partial.as<float>();
-        float *Vacc = c->Vacc.as<float>(), *norm = c->norm_pwz.as<float>(), *Vt_out = c->Vt[1 - c->cv].as<float>();
-        double *csp = c->colsum_partials.as<double>();
-        unsigned *counter = c->coop_state.as<unsigned>();
-        int *err = c->coop_state.as<int>() + 1;
-        int m = (int)c->m, heavy_items = c->heavy_items, n_heavy = c->n_heavy, kp = c->kp;
-        unsigned base = c->coop_epoch;
-        Scope s(c, "k_col_finish");
-        if (c->coop == 2) {
-            void *args[] = {&item_first, &m, &heavy_items, &heavy_cols, &n_heavy, &partial, &Vacc, &kp, &csp,
-                            &norm, &Vt_out, &counter, &base, &err};
-            hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<void *>(plsa::k_col_finish<Sh>), dim3(grid),
-                                                      dim3(256), args, (unsigned)smem, c->ls);
-            if (e != hipSuccess) rc = fail(c, "hipLaunchCooperativeKernel(k_col_finish): %s", hipGetErrorString(e));
-        } else {
-            hipLaunchKernelGGL((plsa::k_col_finish<Sh>), dim3(grid), dim3(256), smem, c->ls, item_first, m, heavy_items,
-                               heavy_cols, n_heavy, partial, Vacc, kp, csp, norm, Vt_out, counter, base, err);
-        }
-        c->coop_epoch += 2u * (unsigned)grid;
+        const int grid2 = grid_for(c, c->m, GPB);
+        Scope s(c, "k_col_reduce_norm");
+        hipLaunchKernelGGL((plsa::k_col_reduce_norm<Sh>), dim3(grid2 + c->n_heavy), dim3(256),
+                           sizeof(float) * (size_t)(GPB + 1) * c->kp, c->ls, c->item_first.as<int>(), (int)c->m,
+                           c->heavy_items, c->heavy_cols.as<int>(), c->n_heavy, c->partial.as<float>(),
+                           c->norm_pwz.as<float>(), c->Vt[1 - c->cv].as<float>(), c->kp);
     }));
-    if (rc) return rc;
-    return launch_check(c, "k_col_finish");
+    return launch_check(c, "k_col_reduce_norm");
 }
 
 int finish_ll(plsa_ctx *c, int blocks, double *out) {
@@ -850,6 +902,8 @@ int plsa_create(int device, plsa_ctx **out) {
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_hot, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_cold, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&c->h_ll, sizeof(double) * 2, hipHostMallocDefault) != hipSuccess) {
         delete c;
         return fail(nullptr, "stream / pinned buffer creation failed");
@@ -873,9 +927,9 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_E_ROWS")) c->e_rows = atoi(s);
     if (const char *s = getenv("PLSA_MT_STREAMS")) c->mt_streams = std::max(1, std::min(4096, atoi(s)));
     if (const char *s = getenv("PLSA_MT_MIN_BLOCKS")) c->mt_min_blocks = std::max(1, atoi(s));
-    if (const char *s = getenv("PLSA_COOP")) c->coop = atoi(s);
-    if (const char *s = getenv("PLSA_COOP_BPC")) c->coop_bpc = std::max(1, atoi(s));
-    if (const char *s = getenv("PLSA_COOP_LIMIT")) c->coop_limit = atof(s);
+    if (const char *s = getenv("PLSA_HOT")) c->hot_mode = atoi(s);
+    if (const char *s = getenv("PLSA_HOT_MIN")) c->hot_min_per_tile = std::max(1.0, atof(s));
+    if (const char *s = getenv("PLSA_HOT_LDS_KB")) c->hot_lds_kb = std::max(4, std::min(64, atoi(s)));
     *out = c;
     return 0;
 }
@@ -885,7 +939,10 @@ void plsa_destroy(plsa_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
-    release(c->comm_send); release(c->comm_recv); release(c->comm_small); release(c->coop_state);
+    release(c->comm_send); release(c->comm_recv); release(c->comm_small);
+    release(c->hot_cols); release(c->item_end); release(c->colsum_rows); release(c->colsum_rows2);
+    if (c->ev_hot) (void)hipEventDestroy(c->ev_hot);
+    if (c->ev_cold) (void)hipEventDestroy(c->ev_cold);
     DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,
@@ -1021,23 +1078,9 @@ int plsa_set_factors(plsa_ctx *c, const float *U, const float *V, int64_t n, int
     if (k <= 0 || k > 1024) return fail(c, "plsa_set_factors: k=%d outside [1,1024]", k);
     if (!U) return fail(c, "plsa_set_factors: U is NULL");
     if (!V && (k != c->k || !c->Vt[0].p)) return fail(c, "plsa_set_factors: V is NULL but no topics with k=%d are resident", k);
-    const int kp = (k + 3) / 4 * 4;
-    c->k = k; c->kp = kp;
+    set_shape(c, k);
+    const int kp = c->kp;
     c->fac_n = n; c->fac_m = m;
-    const int prev_lpn = c->struct_lpn;
-    int lpn = 1;
-    while (lpn < kp / 4 && lpn < 64) lpn *= 2;
-    // k >= 128: 8 floats per lane (two float4 chunks) -- fewer reduction/shuffle instructions per
-    // cell, each access still covers whole 128-B lines (measured: config 5 document pass -15 %)
-    if (lpn >= 32 && lpn * 4 >= kp && c->chunks_per_lane == 2) lpn /= 2;
-    c->lpn = lpn;
-    c->ch = (kp / 4 + lpn - 1) / lpn;
-    if (c->ch == 3) c->ch = 4;
-    if (lpn != prev_lpn) {        // item lengths / the row-item decision depend on the lane shape
-        c->ritems_valid = false;
-        if (!c->seg_override) c->csc_valid = false;
-        c->struct_lpn = lpn;
-    }
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->U[i], sizeof(float) * (size_t)n * kp));
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->Vt[i], sizeof(float) * (size_t)m * kp));
     CHK(ensure(c, c->Vacc, sizeof(float) * (size_t)m * kp));
@@ -1065,20 +1108,9 @@ int plsa_init_factors_device(plsa_ctx *c, int32_t k, uint64_t seed) {
     if (c->n <= 0) return fail(c, "plsa_init_factors_device: upload a corpus first");
     if (k <= 0 || k > 1024) return fail(c, "plsa_init_factors_device: k=%d outside [1,1024]", k);
     const i64 n = c->n, m = c->m;
-    const int kp = (k + 3) / 4 * 4;
-    c->k = k; c->kp = kp; c->fac_n = n; c->fac_m = m;
-    const int prev_lpn = c->struct_lpn;
-    int lpn = 1;
-    while (lpn < kp / 4 && lpn < 64) lpn *= 2;
-    if (lpn >= 32 && lpn * 4 >= kp && c->chunks_per_lane == 2) lpn /= 2;
-    c->lpn = lpn;
-    c->ch = (kp / 4 + lpn - 1) / lpn;
-    if (c->ch == 3) c->ch = 4;
-    if (lpn != prev_lpn) {        // item lengths / the row-item decision depend on the lane shape
-        c->ritems_valid = false;
-        if (!c->seg_override) c->csc_valid = false;
-        c->struct_lpn = lpn;
-    }
+    set_shape(c, k);
+    const int kp = c->kp;
+    c->fac_n = n; c->fac_m = m;
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->U[i], sizeof(float) * (size_t)n * kp));
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->Vt[i], sizeof(float) * (size_t)m * kp));
     CHK(ensure(c, c->Vacc, sizeof(float) * (size_t)m * kp));
@@ -1107,16 +1139,9 @@ static int mt_init(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/, const f
     if (k <= 0 || k > 1024) return fail(c, "plsa_init_factors_mt19937: k=%d outside [1,1024]", k);
     if (state_io[624] > 624) return fail(c, "plsa_init_factors_mt19937: bad generator position");
     const i64 n = c->n, m = c->m;
-    const int kp = (k + 3) / 4 * 4;
-    const int prev_lpn = c->struct_lpn;
-    c->k = k; c->kp = kp; c->fac_n = n; c->fac_m = m;
-    int lpn = 1;
-    while (lpn < kp / 4 && lpn < 64) lpn *= 2;
-    if (lpn >= 32 && lpn * 4 >= kp && c->chunks_per_lane == 2) lpn /= 2;
-    c->lpn = lpn;
-    c->ch = (kp / 4 + lpn - 1) / lpn;
-    if (c->ch == 3) c->ch = 4;
-    if (lpn != prev_lpn) { c->ritems_valid = false; if (!c->seg_override) c->csc_valid = false; c->struct_lpn = lpn; }
+    set_shape(c, k);
+    const int kp = c->kp;
+    c->fac_n = n; c->fac_m = m;
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->U[i], sizeof(float) * (size_t)n * kp));
     for (int i = 0; i < 2; ++i) CHK(ensure(c, c->Vt[i], sizeof(float) * (size_t)m * kp));
     CHK(ensure(c, c->Vacc, sizeof(float) * (size_t)m * kp));
@@ -1267,7 +1292,6 @@ int plsa_m_step(plsa_ctx *c, const float *sw, int32_t update_v, float *norm_pwz,
     if (norm_pdz)
         HIPCHK(c, hipMemcpyAsync(norm_pdz, c->norm_pdz.p, sizeof(float) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    CHK(check_coop_error(c));
     return 0;
 }
 
@@ -1402,7 +1426,6 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    CHK(check_coop_error(c));
     if (iters_done) *iters_done = iters;
     if (n_ll) *n_ll = nll;
     return 0;

@@ -482,6 +482,26 @@ __global__ void k_ritem_fill(const int *__restrict__ indptr, const int *__restri
 // concurrently gather from the same band of U rows.  FROM_P = false recomputes the
 // responsibilities from U (gather) and Vt (registers).
 // ------------------------------------------------------------------------------------------------
+// block-wide sum of per-thread k-vector chunks (float) in float64, fixed group order -> out_row[kp]
+template <class S>
+__device__ __forceinline__ void block_colsum(const float4 (&csum)[S::CH], int li, int gid, int kp,
+                                             double *sred /*[256 / LPN][kp]*/, double *__restrict__ out_row) {
+    constexpr int GPB = 256 / S::LPN;
+#pragma unroll
+    for (int j = 0; j < S::CH; ++j) {
+        if (S::ok(li, j, kp)) {
+            double *p = sred + gid * kp + S::c4(li, j);
+            p[0] = (double)csum[j].x; p[1] = (double)csum[j].y; p[2] = (double)csum[j].z; p[3] = (double)csum[j].w;
+        }
+    }
+    __syncthreads();
+    for (int z = threadIdx.x; z < kp; z += 256) {
+        double t = 0.0;
+        for (int g = 0; g < GPB; ++g) t += sred[g * kp + z];
+        out_row[z] = t;
+    }
+}
+
 // one batch of UN entries of a column item: all UN gathers are issued before the first use
 template <class S, bool FROM_P, int UN>
 __device__ __forceinline__ void col_batch(int s0, int d_l, float x_l, int p_l, int li, int kp, float thresh,
@@ -525,8 +545,8 @@ template <class S, bool FROM_P>
 __global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int *__restrict__ item_order,
                                                   const int *__restrict__ item_col,
                                                   const int *__restrict__ item_start,
-                                                  const int *__restrict__ colptr, i64 n_items,
-                                                  int seg, const int *__restrict__ csc_row,
+                                                  const int *__restrict__ item_end, i64 n_items,
+                                                  const int *__restrict__ csc_row,
                                                   const float *__restrict__ csc_val,
                                                   const int *__restrict__ csc_pos,
                                                   const float *__restrict__ U,
@@ -534,12 +554,16 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int *__restr
                                                   const float *__restrict__ P,
                                                   const float *__restrict__ sw,
                                                   float *__restrict__ partial, int kp_rt, float thresh,
-                                                  int xcd_split) {
+                                                  int xcd_split, double *__restrict__ colsum_rows) {
     constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR_COL;
     constexpr int GPB = 256 / LPN;
+    extern __shared__ double scol[];   // [GPB][kp]: block sum of the item accumulators (-> norm_pwz)
     const int kp = S::kp(kp_rt);
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
+    float4 csum[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) csum[j] = zero4();
     // XCD-aware traversal: workgroup b runs on XCD b % 8 (observed dispatch rule; a different
     // placement only costs speed).  Each XCD walks its own contiguous eighth of the doc-band-major
     // item list, so all workgroups sharing an L2 gather from the same band of U rows.
@@ -552,7 +576,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int *__restr
         const int it = item_order ? item_order[io] : (int)io;
         const int w = item_col[it];
         const int j0 = item_start[it];
-        const int j1 = min(j0 + seg, colptr[w + 1]);
+        const int j1 = item_end[it];
         float4 vt[CH], acc[CH];
         load_row<S, true, PLSA_NT_STREAMS>(Vt + (i64)w * kp, li, kp, vt);
 #pragma unroll
@@ -579,22 +603,93 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int *__restr
                 col_batch<S, FROM_P, TAIL>(s0, d_l, x_l, p_l, li, kp, thresh, U, P, vt, acc);
         }
 #pragma unroll
-        for (int j = 0; j < CH; ++j)
+        for (int j = 0; j < CH; ++j) {
             if (S::ok(li, j, kp)) st4(partial + (i64)it * kp + S::c4(li, j), acc[j]);
+            csum[j].x += acc[j].x; csum[j].y += acc[j].y; csum[j].z += acc[j].z; csum[j].w += acc[j].w;
+        }
     }
+    block_colsum<S>(csum, li, gid, kp, scol, colsum_rows + (i64)blockIdx.x * kp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_col_hot: the column pass of the FREQUENT words (those with several entries in every block of HB
+// consecutive documents).  Their postings are the L2-friendliest of the column pass, but each still costs
+// a 256-byte gather through the L2 request pipe; here a workgroup owns a block of HB documents, stages
+// their P(z|d) rows in LDS once (one coalesced read of the block) and walks every hot word's run of
+// entries inside the block -- contiguous in the CSC arrays, because a column's entries are in document
+// order.  Gathers become LDS reads; one partial row per (word, block) tile.  Tiles are ordinary column
+// items (item_first / item_start / item_end), so the materialised schedule and the reduce kernels see
+// nothing special.  A group takes hot words gid, gid + GPB, ... (rank-interleaved: balanced).
+// ------------------------------------------------------------------------------------------------
+template <class S>
+__global__ __launch_bounds__(256) void k_col_hot(const int *__restrict__ hot_cols, int n_hot, int n_tiles, int hb,
+                                                 int n, const int *__restrict__ item_first,
+                                                 const int *__restrict__ item_start, const int *__restrict__ item_end,
+                                                 const int *__restrict__ csc_row, const float *__restrict__ csc_val,
+                                                 const float *__restrict__ U, const float *__restrict__ Vt,
+                                                 const float *__restrict__ sw, float *__restrict__ partial,
+                                                 int kp_rt, float thresh, double *__restrict__ colsum_rows) {
+    constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR_COL;
+    constexpr int GPB = 256 / LPN;
+    extern __shared__ float su[];      // [hb][kp] P(z|d) rows of the block; reused for the block column sums
+    const int kp = S::kp(kp_rt);
+    const int li = threadIdx.x % LPN;
+    const int gid = threadIdx.x / LPN;
+    float4 csum[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) csum[j] = zero4();
+    for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) {
+        const int d0 = b * hb, rows = min(hb, n - d0);
+        const i64 n4 = (i64)rows * kp / 4;
+        __syncthreads();               // previous block's readers are done
+        for (i64 i = threadIdx.x; i < n4; i += 256) st4(su + i * 4, ld4(U + (i64)d0 * kp + i * 4));
+        __syncthreads();
+        for (int h = gid; h < n_hot; h += GPB) {
+            const int w = hot_cols[h];
+            const int it = item_first[w] + b;
+            const int j0 = item_start[it], j1 = item_end[it];
+            float4 vt[CH], acc[CH];
+            load_row<S, true>(Vt + (i64)w * kp, li, kp, vt);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[j] = zero4();
+            for (int jb = j0; jb < j1; jb += LPN) {
+                const int jn = jb + li;
+                const int d_l = jn < j1 ? csc_row[jn] - d0 : 0;       // row inside the staged block
+                float x_l = jn < j1 ? csc_val[jn] : 0.f;
+                if (sw && jn < j1) x_l *= sw[d0 + d_l];
+                const int cnt = min(LPN, j1 - jb);
+                int s0 = 0;
+                for (; s0 + UNR <= cnt; s0 += UNR)
+                    col_batch<S, false, UNR>(s0, d_l, x_l, 0, li, kp, thresh, su, nullptr, vt, acc);
+                constexpr int TAIL = (UNR >= 2 && LPN >= 2) ? 2 : 1;
+                for (; s0 < cnt; s0 += TAIL)
+                    col_batch<S, false, TAIL>(s0, d_l, x_l, 0, li, kp, thresh, su, nullptr, vt, acc);
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                if (S::ok(li, j, kp)) st4(partial + (i64)it * kp + S::c4(li, j), acc[j]);
+                csum[j].x += acc[j].x; csum[j].y += acc[j].y; csum[j].z += acc[j].z; csum[j].w += acc[j].w;
+            }
+        }
+    }
+    __syncthreads();
+    block_colsum<S>(csum, li, gid, kp, reinterpret_cast<double *>(su), colsum_rows + (i64)blockIdx.x * kp);
 }
 
 // adds the item partials of each column (fixed order) into the un-normalised Vt_new.
 // Columns with more than `heavy_items` items (the Zipf head) take a whole block: its groups stride
 // over the column's items (fixed assignment, loads batched four deep, added in item order), then their
 // sums are added in group order through LDS -> bit-reproducible.  Every other column takes one group.
-// `block` of `nblocks`: the caller's position in the grid (the standalone kernel and the single-launch
-// chain k_col_finish share this body; which block sums a column does not change the sum).
-template <class S>
+// `block` of `nblocks`: the caller's position in the grid.  NORMALISE: divide by norm_pwz on the way out
+// (plsa.py:196-199: true division, only where the norm is positive) -- snorm is its LDS copy.
+__device__ __forceinline__ float div_pos(float v, float n) { return n > 0.f ? v / n : v; }
+
+template <class S, bool NORMALISE>
 __device__ __forceinline__ void col_reduce_body(const int *__restrict__ item_first, int m, int heavy_items,
                                                 const int *__restrict__ heavy_cols, int n_heavy,
                                                 const float *__restrict__ partial, float *__restrict__ Vt_new,
-                                                int kp, int block, int nblocks, float *sacc /*[GPB][kp]*/) {
+                                                int kp, int block, int nblocks, float *sacc /*[GPB][kp]*/,
+                                                const float *snorm /*[kp], NORMALISE only*/) {
     constexpr int LPN = S::LPN, CH = S::CH;
     constexpr int GPB = 256 / LPN;
     const int li = threadIdx.x % LPN;
@@ -632,7 +727,7 @@ __device__ __forceinline__ void col_reduce_body(const int *__restrict__ item_fir
         for (int z = threadIdx.x; z < kp; z += 256) {
             float t = 0.f;
             for (int g = 0; g < GPB; ++g) t += sacc[g * kp + z];
-            Vt_new[(i64)c * kp + z] = t;
+            Vt_new[(i64)c * kp + z] = NORMALISE ? div_pos(t, snorm[z]) : t;
         }
         __syncthreads();
     }
@@ -650,20 +745,47 @@ __device__ __forceinline__ void col_reduce_body(const int *__restrict__ item_fir
             }
         }
 #pragma unroll
-        for (int j = 0; j < CH; ++j)
-            if (S::ok(li, j, kp)) st4(Vt_new + c * kp + S::c4(li, j), acc[j]);
+        for (int j = 0; j < CH; ++j) {
+            if (S::ok(li, j, kp)) {
+                float4 o = acc[j];
+                if (NORMALISE) {
+                    const float *nn = snorm + S::c4(li, j);
+                    o.x = div_pos(o.x, nn[0]); o.y = div_pos(o.y, nn[1]); o.z = div_pos(o.z, nn[2]); o.w = div_pos(o.w, nn[3]);
+                }
+                st4(Vt_new + c * kp + S::c4(li, j), o);
+            }
+        }
     }
 }
 
-// standalone launch: blocks [0, n_heavy) start on the heavy columns, every block then strides over the rest
+// un-normalised sums -> Vacc (doc-sharded fit: the all-reduce comes next; plsa_em_accumulate)
 template <class S>
 __global__ __launch_bounds__(256) void k_col_reduce(const int *__restrict__ item_first, int m,
                                                     int heavy_items, const int *__restrict__ heavy_cols,
                                                     int n_heavy, const float *__restrict__ partial,
                                                     float *__restrict__ Vt_new, int kp_rt) {
     extern __shared__ float sacc[];  // [GPB][kp]
-    col_reduce_body<S>(item_first, m, heavy_items, heavy_cols, n_heavy, partial, Vt_new, S::kp(kp_rt),
-                       (int)blockIdx.x, (int)gridDim.x, sacc);
+    col_reduce_body<S, false>(item_first, m, heavy_items, heavy_cols, n_heavy, partial, Vt_new, S::kp(kp_rt),
+                              (int)blockIdx.x, (int)gridDim.x, sacc, nullptr);
+}
+
+// sums AND division in one pass: norm_pwz is already known when this runs, because the column pass
+// itself adds up its accumulators (sum_w Vacc[w, z] == sum over all items of their partial rows), so the
+// two extra sweeps over the [m, kp] accumulator (column sums, division) of the first version are gone.
+template <class S>
+__global__ __launch_bounds__(256) void k_col_reduce_norm(const int *__restrict__ item_first, int m,
+                                                         int heavy_items, const int *__restrict__ heavy_cols,
+                                                         int n_heavy, const float *__restrict__ partial,
+                                                         const float *__restrict__ norm_pwz,
+                                                         float *__restrict__ Vt_out, int kp_rt) {
+    extern __shared__ float sdyn[];  // [GPB][kp] heavy-column sums, then [kp] norm_pwz
+    const int kp = S::kp(kp_rt);
+    constexpr int GPB = 256 / S::LPN;
+    float *snorm = sdyn + GPB * kp;
+    for (int z = threadIdx.x; z < kp; z += 256) snorm[z] = norm_pwz[z];
+    __syncthreads();
+    col_reduce_body<S, true>(item_first, m, heavy_items, heavy_cols, n_heavy, partial, Vt_out, kp,
+                             (int)blockIdx.x, (int)gridDim.x, sdyn, snorm);
 }
 
 __global__ void k_heavy_list(const int *__restrict__ item_first, int m, int heavy_items,
@@ -743,6 +865,32 @@ __global__ __launch_bounds__(256) void k_colsum_final(const double *__restrict__
     colsum_final_body(partials, n_partials, kp, norm_pwz, sred);
 }
 
+// stage 1 of norm_pwz from the column pass' per-block sums: `rows` rows of kp doubles -> gridDim.x rows
+// (block b adds rows b*per .. in strand order; same thread layout as colsum_slab_body)
+__global__ __launch_bounds__(256) void k_norm_reduce(const double *__restrict__ in, int rows, int kp,
+                                                     double *__restrict__ out) {
+    __shared__ double sred[256];
+    const i64 per = ((i64)rows + gridDim.x - 1) / gridDim.x;
+    const i64 r0 = (i64)blockIdx.x * per, r1 = min((i64)rows, r0 + per);
+    for (int zb = 0; zb < kp; zb += 256) {
+        const int span = min(256, kp - zb);
+        const int rpp = 256 / span;
+        const int z = zb + (int)threadIdx.x % span;
+        const int ro = (int)threadIdx.x / span;
+        double s = 0.0;
+        if (ro < rpp)
+            for (i64 r = r0 + ro; r < r1; r += rpp) s += in[r * kp + z];
+        sred[threadIdx.x] = (ro < rpp) ? s : 0.0;
+        __syncthreads();
+        if ((int)threadIdx.x < span) {
+            double tot = 0.0;
+            for (int r = 0; r < rpp; ++r) tot += sred[r * span + threadIdx.x];
+            out[(i64)blockIdx.x * kp + zb + threadIdx.x] = tot;
+        }
+        __syncthreads();
+    }
+}
+
 // division by norm_pwz (snorm: LDS copy), plsa.py:196-199
 __device__ __forceinline__ void v_normalise_body(const float *__restrict__ Vt_new, float *__restrict__ Vt, int m,
                                                  int kp, const float *snorm, int block, int nblocks) {
@@ -767,59 +915,6 @@ __global__ __launch_bounds__(256) void k_v_normalise(const float *__restrict__ V
     for (int z = threadIdx.x; z < kp; z += 256) snorm[z] = norm_pwz[z];
     __syncthreads();
     v_normalise_body(Vt_new, Vt, m, kp, snorm, (int)blockIdx.x, (int)gridDim.x);
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_col_finish: everything behind the column pass in ONE cooperative launch -- per-column sums of the
-// item partials, norm_pwz, division -- with two grid-wide barriers instead of three kernel boundaries.
-// On small corpora (BASELINE configs 1, 2, 4: 0.2 ms per EM iteration) the four short dependent
-// kernels of this chain were a third of the critical path.  Same device bodies as the standalone
-// kernels, hence bit-identical results; the doc-sharded fit keeps the standalone kernels (its
-// all-reduce sits between the column sums and the normalisation).
-// Grid barrier: arrival counter in global memory that only ever grows (the host passes the count at
-// which this launch starts, so nothing has to be zeroed between launches; comparisons are on the
-// wrapped difference).  All blocks must be co-resident: the host launches at most one block per CU
-// (plain launch) or goes through hipLaunchCooperativeKernel.  A barrier that does not complete within
-// ~2 s (a scheduling assumption was wrong) raises *error_flag and lets the kernel finish instead of
-// hanging the device; the host turns the flag into an error at its next synchronisation.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned target, int *error_flag) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        atomicAdd(counter, 1u);
-        const unsigned long long t0 = wall_clock64();                 // 100 MHz constant clock
-        while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > 200000000ull) { atomicExch(error_flag, 1); break; }
-        }
-        __threadfence();
-    }
-    __syncthreads();
-}
-
-template <class S>
-__global__ __launch_bounds__(256) void k_col_finish(const int *__restrict__ item_first, int m, int heavy_items,
-                                                    const int *__restrict__ heavy_cols, int n_heavy,
-                                                    const float *__restrict__ partial, float *__restrict__ Vacc,
-                                                    int kp_rt, double *__restrict__ colsum_partials,
-                                                    float *__restrict__ norm_pwz, float *__restrict__ Vt_out,
-                                                    unsigned *__restrict__ barrier_counter, unsigned barrier_base,
-                                                    int *__restrict__ error_flag) {
-    extern __shared__ float sdyn[];               // [max(GPB * kp, kp)] floats: heavy-column sums, later norm_pwz
-    __shared__ double sred[256];
-    const int kp = S::kp(kp_rt);
-    const int block = (int)blockIdx.x, nblocks = (int)gridDim.x;
-    col_reduce_body<S>(item_first, m, heavy_items, heavy_cols, n_heavy, partial, Vacc, kp, block, nblocks, sdyn);
-    grid_barrier(barrier_counter, barrier_base + (unsigned)nblocks, error_flag);
-    const int n_slabs = min(NORM_BLOCKS, max(1, m));
-    for (int slab = block; slab < n_slabs; slab += nblocks)
-        colsum_slab_body(Vacc, m, kp, slab, n_slabs, colsum_partials, sred);
-    grid_barrier(barrier_counter, barrier_base + 2u * (unsigned)nblocks, error_flag);
-    colsum_final_body(colsum_partials, n_slabs, kp, sdyn, sred);      // every block: the same fixed-order sum
-    if (block == 0)
-        for (int z = threadIdx.x; z < kp; z += 256) norm_pwz[z] = sdyn[z];
-    v_normalise_body(Vacc, Vt_out, m, kp, sdyn, block, nblocks);
 }
 
 // final, fixed-order sum of the per-block log-likelihood partials
@@ -1037,21 +1132,66 @@ __global__ void k_item_counts(const int *__restrict__ colptr, int m, int seg, in
     if (c < m) cnt[c] = (colptr[c + 1] - colptr[c] + seg - 1) / seg;
 }
 // item arrays + the first document of every item (sort key of the doc-band-major visiting order)
-__global__ void k_item_fill(const int *__restrict__ colptr, const int *__restrict__ item_first, int m,
-                            int seg, const int *__restrict__ csc_row, int *__restrict__ item_col,
-                            int *__restrict__ item_start, int *__restrict__ item_doc0,
-                            int *__restrict__ item_id) {
+// Column items.  An ordinary column is cut into chunks of <= seg entries.  A HOT column (at least
+// hot_min entries, hot_min = tiles * a few: several entries in every block of hb documents) is cut at the
+// block boundaries instead: n_tiles items, item b = its entries with document in [b hb, (b+1) hb).
+__global__ void k_col_item_counts(const int *__restrict__ colptr, int m, int seg, int hot_min, int n_tiles,
+                                  int *__restrict__ cnt, int *__restrict__ hot_flag) {
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m) {
+        const int len = colptr[c + 1] - colptr[c];
+        const bool hot = hot_min > 0 && len >= hot_min;
+        cnt[c] = hot ? n_tiles : (len + seg - 1) / seg;
+        hot_flag[c] = hot ? 1 : 0;
+    }
+}
+
+// sort key of an item for the visiting order: ordinary items by first document, hot tiles behind them
+__global__ void k_item_fill(const int *__restrict__ colptr, const int *__restrict__ item_first,
+                            const int *__restrict__ hot_flag, int m, int seg, int n,
+                            const int *__restrict__ csc_row, int *__restrict__ item_col,
+                            int *__restrict__ item_start, int *__restrict__ item_end,
+                            unsigned *__restrict__ item_key, int *__restrict__ item_id) {
+    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m && !hot_flag[c]) {
         const int i0 = item_first[c], i1 = item_first[c + 1];
         for (int i = i0; i < i1; ++i) {
             const int st = colptr[c] + (i - i0) * seg;
             item_col[i] = (int)c;
             item_start[i] = st;
-            item_doc0[i] = csc_row[st];
+            item_end[i] = min(st + seg, colptr[c + 1]);
+            item_key[i] = (unsigned)csc_row[st];
             item_id[i] = i;
         }
     }
+}
+
+// one thread per (hot column, tile): the tile's run of entries by binary search in the column's
+// (ascending) document ids
+__global__ void k_hot_item_fill(const int *__restrict__ hot_cols, int n_hot, int n_tiles, int hb, int n,
+                                const int *__restrict__ colptr, const int *__restrict__ item_first,
+                                const int *__restrict__ csc_row, int *__restrict__ item_col,
+                                int *__restrict__ item_start, int *__restrict__ item_end,
+                                unsigned *__restrict__ item_key, int *__restrict__ item_id) {
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (i64)n_hot * n_tiles) return;
+    const int h = (int)(t / n_tiles), b = (int)(t % n_tiles);
+    const int c = hot_cols[h];
+    const int c0 = colptr[c], c1 = colptr[c + 1];
+    auto lower = [&](int doc) {        // first entry of the column with document id >= doc
+        int lo = c0, hi = c1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (csc_row[mid] < doc) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const int i = item_first[c] + b;
+    item_col[i] = c;
+    item_start[i] = lower(b * hb);
+    item_end[i] = (b + 1 == n_tiles) ? c1 : lower((b + 1) * hb);
+    item_key[i] = (unsigned)n + (unsigned)(b * hb);      // behind every ordinary item, tiles in block order
+    item_id[i] = i;
 }
 
 // ------------------------------------------------------------------------------------------------
