@@ -108,9 +108,12 @@ struct plsa_ctx {
 
     // hot columns: words with >= hot_min_per_tile entries per block of `hb` documents on average are cut at
     // the block boundaries and processed by k_col_hot (P(z|d) rows of a block staged in LDS)
-    int hot_mode = 1;                // PLSA_HOT: 0 off, 1 on (fused schedule)
+    int hot_mode = 1;                // PLSA_HOT: 0 off, 1 large corpora only (fused schedule), 2 whenever possible
     double hot_min_per_tile = 8.0;   // PLSA_HOT_MIN
-    int hot_lds_kb = 64;             // PLSA_HOT_LDS_KB: LDS per workgroup for the staged block
+    int hot_lds_kb = 32;             // PLSA_HOT_LDS_KB: LDS per workgroup for the staged block of P(z|d) rows
+    double hot_limit = 2e9;          // nnz * kp from which hot_mode 1 switches the tiles on (PLSA_HOT_LIMIT)
+    int hot_slices = 0;              // PLSA_HOT_SLICES (0 = by size)
+    DevBuf hot_seg, hot_base;
     int hb = 0, n_tiles = 0, n_hot = 0, struct_kp = 0;
     i64 n_cold_items = 0;
     DevBuf hot_cols, item_end, colsum_rows, colsum_rows2;
@@ -466,19 +469,21 @@ int ensure_csc(plsa_ctx *c) {
         c->n_tiles = (int)((c->n + hb - 1) / hb);
         c->struct_kp = c->kp;
     }
-    const bool hot_on = c->hot_mode > 0 && c->kp > 0 && c->n_tiles >= 8;
-    const double hot_min_d = hot_on ? std::max(c->hot_min_per_tile * (double)c->n_tiles, (double)c->seg) : 0.0;
-    const int hot_min = hot_on ? (int)std::min<double>(hot_min_d, 2.0e9) : 0;
+    const bool hot_on = c->kp > 0 && c->n_tiles >= 8 && (i64)c->hb * c->kp * 4 <= (i64)c->hot_lds_kb * 1024 &&
+                        (c->hot_mode >= 2 || (c->hot_mode == 1 && (double)nnz * c->kp >= c->hot_limit));
+    double hot_min_d = hot_on ? std::max(c->hot_min_per_tile * (double)c->n_tiles, (double)c->seg) : 0.0;
     CHK(ensure(c, c->item_first, sizeof(int) * (size_t)(m + 1)));
     CHK(ensure(c, c->tmp0, sizeof(int) * (size_t)(m + 1) * 2));      // counts, hot flags
     CHK(ensure(c, c->hot_cols, sizeof(int) * (size_t)(m + 1)));
+    CHK(ensure(c, c->tmp1, sizeof(int) * (size_t)std::max<i64>(nnz, m + 1)));
     int *d_cnt = c->tmp0.as<int>(), *d_flag = c->tmp0.as<int>() + (m + 1);
-    HIPCHK(c, hipMemsetAsync(c->tmp0.p, 0, sizeof(int) * (size_t)(m + 1) * 2, c->stream));
-    hipLaunchKernelGGL(plsa::k_col_item_counts, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                       c->colptr.as<int>(), (int)m, c->seg, hot_min, c->n_tiles, d_cnt, d_flag);
-    CHK(exclusive_sum_int(c, d_cnt, c->item_first.as<int>(), m + 1));
-    {   // the hot columns in ascending word order (deterministic), their count behind the list
-        CHK(ensure(c, c->tmp1, sizeof(int) * (size_t)std::max<i64>(nnz, m + 1)));
+    constexpr int HOT_CAP = 2048;    // word ids + item bases of the hot columns live in k_col_hot's LDS
+    for (int attempt = 0;; ++attempt) {
+        const int hot_min = hot_on ? (int)std::min<double>(hot_min_d, 2.0e9) : 0;
+        HIPCHK(c, hipMemsetAsync(c->tmp0.p, 0, sizeof(int) * (size_t)(m + 1) * 2, c->stream));
+        hipLaunchKernelGGL(plsa::k_col_item_counts, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                           c->colptr.as<int>(), (int)m, c->seg, hot_min, c->n_tiles, d_cnt, d_flag);
+        // the hot columns in ascending word order (deterministic), their count behind the list
         hipLaunchKernelGGL(plsa::k_iota, dim3(grid_for(c, m, 256)), dim3(256), 0, c->stream, c->tmp1.as<int>(), m);
         size_t bytes = 0;
         HIPCHK(c, hipcub::DeviceSelect::Flagged(nullptr, bytes, c->tmp1.as<int>(), d_flag, c->hot_cols.as<int>(),
@@ -486,7 +491,13 @@ int ensure_csc(plsa_ctx *c) {
         CHK(ensure(c, c->cubtmp, bytes));
         HIPCHK(c, hipcub::DeviceSelect::Flagged(c->cubtmp.p, bytes, c->tmp1.as<int>(), d_flag, c->hot_cols.as<int>(),
                                                 c->hot_cols.as<int>() + m, (int)m, c->stream));
+        int cnt_hot = 0;
+        HIPCHK(c, hipMemcpyAsync(&cnt_hot, c->hot_cols.as<int>() + m, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (cnt_hot <= HOT_CAP || attempt >= 12) break;
+        hot_min_d *= 2.0;            // too many: only the more frequent ones
     }
+    CHK(exclusive_sum_int(c, d_cnt, c->item_first.as<int>(), m + 1));
     int n_items = 0, n_hot = 0;
     HIPCHK(c, hipMemcpyAsync(&n_items, c->item_first.as<int>() + m, sizeof(int), hipMemcpyDeviceToHost,
                              c->stream));
@@ -507,11 +518,15 @@ int ensure_csc(plsa_ctx *c) {
                        c->colptr.as<int>(), c->item_first.as<int>(), d_flag, (int)m, c->seg, (int)c->n,
                        c->csc_row.as<int>(), c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(),
                        d_key, c->tmp1.as<int>());
-    if (n_hot > 0)
-        hipLaunchKernelGGL(plsa::k_hot_item_fill, dim3(grid_for(c, (i64)n_hot * c->n_tiles, 256)), dim3(256), 0, c->stream,
+    if (n_hot > 0) {
+        CHK(ensure(c, c->hot_seg, sizeof(int) * (size_t)(c->n_tiles + 1) * n_hot));
+        CHK(ensure(c, c->hot_base, sizeof(int) * (size_t)n_hot));
+        hipLaunchKernelGGL(plsa::k_hot_item_fill, dim3((unsigned)(((i64)n_hot * c->n_tiles + 255) / 256)), dim3(256), 0, c->stream,
                            c->hot_cols.as<int>(), n_hot, c->n_tiles, c->hb, (int)c->n, c->colptr.as<int>(),
                            c->item_first.as<int>(), c->csc_row.as<int>(), c->item_col.as<int>(),
-                           c->item_start.as<int>(), c->item_end.as<int>(), d_key, c->tmp1.as<int>());
+                           c->item_start.as<int>(), c->item_end.as<int>(), d_key, c->tmp1.as<int>(),
+                           c->hot_seg.as<int>(), c->hot_base.as<int>());
+    }
     CHK(launch_check(c, "k_item_fill"));
     if (n_items > 0) {   // visiting order: ascending first document (stable) -> doc-band-major; hot tiles last
         int dbits = 1;
@@ -690,7 +705,12 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int 
         const bool hot = !from_p && c->n_hot > 0;          // hot tiles by their own kernel (U rows from LDS)
         const i64 n_visit = hot ? c->n_cold_items : c->n_items;
         const int grid = grid_for(c, n_visit, GPB);
-        const int grid_hot = hot ? c->n_tiles : 0;
+        constexpr int HOT_THREADS = 512, HOT_GPB = HOT_THREADS / LPN;
+        // enough workgroups to fill the chip a few times over; every slice re-stages the tile's rows
+        int slices = c->hot_slices > 0 ? c->hot_slices
+                                       : (int)std::max<i64>(1, (8 * (i64)c->prop.multiProcessorCount + c->n_tiles - 1) / std::max(c->n_tiles, 1));
+        slices = std::max(1, std::min(slices, (c->n_hot + HOT_GPB - 1) / HOT_GPB));
+        const int grid_hot = hot ? c->n_tiles * slices : 0;
         const int grid2 = grid_for(c, c->m, GPB);
         const int *order = c->item_order.as<int>();
         const int xcd_split = (c->xcd_split && grid >= 64) ? 1 : 0;
@@ -716,11 +736,12 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int 
                                    c->colsum_rows.as<double>());
             }
             if (hot) {
-                const size_t lds = std::max(sizeof(float) * (size_t)c->hb * c->kp, smem);
+                const size_t lds = std::max(sizeof(float) * (size_t)c->hb * c->kp + sizeof(int) * 2 * (size_t)c->n_hot,
+                                            sizeof(double) * (size_t)HOT_GPB * c->kp);
                 Scope s(c, "k_col_hot");
-                hipLaunchKernelGGL((plsa::k_col_hot<Sh>), dim3(grid_hot), dim3(256), lds, c->ls, c->hot_cols.as<int>(),
-                                   c->n_hot, c->n_tiles, c->hb, (int)c->n, c->item_first.as<int>(),
-                                   c->item_start.as<int>(), c->item_end.as<int>(), c->csc_row.as<int>(),
+                hipLaunchKernelGGL((plsa::k_col_hot<Sh, HOT_THREADS>), dim3(grid_hot), dim3(HOT_THREADS), lds, c->ls,
+                                   c->hot_cols.as<int>(), c->hot_base.as<int>(), c->n_hot, c->hot_seg.as<int>(),
+                                   c->n_tiles, slices, c->hb, (int)c->n, c->csc_row.as<int>(),
                                    c->csc_val.as<float>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(), d_sw,
                                    c->partial.as<float>(), c->kp, thresh,
                                    c->colsum_rows.as<double>() + (size_t)grid * c->kp);
@@ -929,7 +950,9 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_MT_MIN_BLOCKS")) c->mt_min_blocks = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_HOT")) c->hot_mode = atoi(s);
     if (const char *s = getenv("PLSA_HOT_MIN")) c->hot_min_per_tile = std::max(1.0, atof(s));
-    if (const char *s = getenv("PLSA_HOT_LDS_KB")) c->hot_lds_kb = std::max(4, std::min(64, atoi(s)));
+    if (const char *s = getenv("PLSA_HOT_LDS_KB")) c->hot_lds_kb = std::max(1, std::min(48, atoi(s)));
+    if (const char *s = getenv("PLSA_HOT_LIMIT")) c->hot_limit = atof(s);
+    if (const char *s = getenv("PLSA_HOT_SLICES")) c->hot_slices = std::max(0, atoi(s));
     *out = c;
     return 0;
 }
@@ -940,7 +963,7 @@ void plsa_destroy(plsa_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     release(c->comm_send); release(c->comm_recv); release(c->comm_small);
-    release(c->hot_cols); release(c->item_end); release(c->colsum_rows); release(c->colsum_rows2);
+    release(c->hot_cols); release(c->item_end); release(c->hot_seg); release(c->hot_base); release(c->colsum_rows); release(c->colsum_rows2);
     if (c->ev_hot) (void)hipEventDestroy(c->ev_hot);
     if (c->ev_cold) (void)hipEventDestroy(c->ev_cold);
     DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,

@@ -483,10 +483,10 @@ __global__ void k_ritem_fill(const int *__restrict__ indptr, const int *__restri
 // responsibilities from U (gather) and Vt (registers).
 // ------------------------------------------------------------------------------------------------
 // block-wide sum of per-thread k-vector chunks (float) in float64, fixed group order -> out_row[kp]
-template <class S>
+template <class S, int THREADS = 256>
 __device__ __forceinline__ void block_colsum(const float4 (&csum)[S::CH], int li, int gid, int kp,
-                                             double *sred /*[256 / LPN][kp]*/, double *__restrict__ out_row) {
-    constexpr int GPB = 256 / S::LPN;
+                                             double *sred /*[THREADS / LPN][kp]*/, double *__restrict__ out_row) {
+    constexpr int GPB = THREADS / S::LPN;
 #pragma unroll
     for (int j = 0; j < S::CH; ++j) {
         if (S::ok(li, j, kp)) {
@@ -495,7 +495,7 @@ __device__ __forceinline__ void block_colsum(const float4 (&csum)[S::CH], int li
         }
     }
     __syncthreads();
-    for (int z = threadIdx.x; z < kp; z += 256) {
+    for (int z = threadIdx.x; z < kp; z += THREADS) {
         double t = 0.0;
         for (int g = 0; g < GPB; ++g) t += sred[g * kp + z];
         out_row[z] = t;
@@ -612,68 +612,99 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_col_hot: the column pass of the FREQUENT words (those with several entries in every block of HB
+// k_col_hot: the column pass of the FREQUENT words (those with several entries in every block of hb
 // consecutive documents).  Their postings are the L2-friendliest of the column pass, but each still costs
-// a 256-byte gather through the L2 request pipe; here a workgroup owns a block of HB documents, stages
-// their P(z|d) rows in LDS once (one coalesced read of the block) and walks every hot word's run of
+// a 256-byte gather through the L2 request pipe; here a workgroup owns a block ("tile") of hb documents,
+// stages their P(z|d) rows in LDS once (one coalesced read of the block) and walks the hot words' runs of
 // entries inside the block -- contiguous in the CSC arrays, because a column's entries are in document
-// order.  Gathers become LDS reads; one partial row per (word, block) tile.  Tiles are ordinary column
-// items (item_first / item_start / item_end), so the materialised schedule and the reduce kernels see
-// nothing special.  A group takes hot words gid, gid + GPB, ... (rank-interleaved: balanced).
+// order.  Gathers become LDS reads; one partial row per (word, tile).  Tiles are ordinary column items
+// (item_first / item_start / item_end), so the materialised schedule and the reduce kernels see nothing
+// special; this kernel reads the same run boundaries from a dense [tile][word] table (hot_seg) so that
+// nothing it loads depends on another load: the boundaries are fetched two words ahead, the word's P(w|z)
+// row and its first LPN entries one word ahead.  Grid: n_tiles x slices workgroups of THREADS lanes;
+// slice s of a tile takes the hot words s GPB + gid, + slices GPB, ... (rank-interleaved: balanced).
 // ------------------------------------------------------------------------------------------------
-template <class S>
-__global__ __launch_bounds__(256) void k_col_hot(const int *__restrict__ hot_cols, int n_hot, int n_tiles, int hb,
-                                                 int n, const int *__restrict__ item_first,
-                                                 const int *__restrict__ item_start, const int *__restrict__ item_end,
-                                                 const int *__restrict__ csc_row, const float *__restrict__ csc_val,
-                                                 const float *__restrict__ U, const float *__restrict__ Vt,
-                                                 const float *__restrict__ sw, float *__restrict__ partial,
-                                                 int kp_rt, float thresh, double *__restrict__ colsum_rows) {
+template <class S, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_col_hot(const int *__restrict__ hot_cols, const int *__restrict__ hot_base,
+                                                     int n_hot, const int *__restrict__ hot_seg, int n_tiles,
+                                                     int slices, int hb, int n, const int *__restrict__ csc_row,
+                                                     const float *__restrict__ csc_val, const float *__restrict__ U,
+                                                     const float *__restrict__ Vt, const float *__restrict__ sw,
+                                                     float *__restrict__ partial, int kp_rt, float thresh,
+                                                     double *__restrict__ colsum_rows) {
     constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR_COL;
-    constexpr int GPB = 256 / LPN;
-    extern __shared__ float su[];      // [hb][kp] P(z|d) rows of the block; reused for the block column sums
+    constexpr int GPB = THREADS / LPN;
+    extern __shared__ float su[];      // [hb][kp] P(z|d) rows of the tile, then word ids and item bases
     const int kp = S::kp(kp_rt);
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
+    int *s_cols = reinterpret_cast<int *>(su + (i64)hb * kp);
+    int *s_base = s_cols + n_hot;
+    const int b = (int)(blockIdx.x % n_tiles), sl = (int)(blockIdx.x / n_tiles);
+    const int d0 = b * hb, rows = min(hb, n - d0);
+    {
+        const i64 n4 = (i64)rows * kp / 4;
+        for (i64 i = threadIdx.x; i < n4; i += THREADS) st4(su + i * 4, ld4(U + (i64)d0 * kp + i * 4));
+        for (int i = threadIdx.x; i < n_hot; i += THREADS) { s_cols[i] = hot_cols[i]; s_base[i] = hot_base[i]; }
+    }
+    __syncthreads();
     float4 csum[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) csum[j] = zero4();
-    for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) {
-        const int d0 = b * hb, rows = min(hb, n - d0);
-        const i64 n4 = (i64)rows * kp / 4;
-        __syncthreads();               // previous block's readers are done
-        for (i64 i = threadIdx.x; i < n4; i += 256) st4(su + i * 4, ld4(U + (i64)d0 * kp + i * 4));
-        __syncthreads();
-        for (int h = gid; h < n_hot; h += GPB) {
-            const int w = hot_cols[h];
-            const int it = item_first[w] + b;
-            const int j0 = item_start[it], j1 = item_end[it];
-            float4 vt[CH], acc[CH];
-            load_row<S, true>(Vt + (i64)w * kp, li, kp, vt);
+    const int stride = slices * GPB;
+    const int *seg0 = hot_seg + (i64)b * n_hot, *seg1 = seg0 + n_hot;
+    int h = sl * GPB + gid;
+    int j0a = 0, j1a = 0, j0b = 0, j1b = 0;
+    if (h < n_hot) { j0a = seg0[h]; j1a = seg1[h]; }
+    if (h + stride < n_hot) { j0b = seg0[h + stride]; j1b = seg1[h + stride]; }
+    float4 vt_n[CH];
+    int d_n = 0;
+    float x_n = 0.f;
 #pragma unroll
-            for (int j = 0; j < CH; ++j) acc[j] = zero4();
-            for (int jb = j0; jb < j1; jb += LPN) {
+    for (int j = 0; j < CH; ++j) vt_n[j] = zero4();
+    if (h < n_hot) {
+        load_row<S, true>(Vt + (i64)s_cols[h] * kp, li, kp, vt_n);
+        if (j0a + li < j1a) { d_n = csc_row[j0a + li] - d0; x_n = csc_val[j0a + li]; }
+    }
+    for (; h < n_hot; h += stride) {
+        const int j0 = j0a, j1 = j1a, it = s_base[h] + b;
+        float4 vt[CH], acc[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { vt[j] = vt_n[j]; acc[j] = zero4(); }
+        int d_l = d_n;
+        float x_l = x_n;
+        // next word: its P(w|z) row and first entries; the word after it: its run boundaries
+        j0a = j0b; j1a = j1b;
+        const int hn = h + stride;
+        d_n = 0; x_n = 0.f;
+        if (hn < n_hot) {
+            load_row<S, true>(Vt + (i64)s_cols[hn] * kp, li, kp, vt_n);
+            if (j0a + li < j1a) { d_n = csc_row[j0a + li] - d0; x_n = csc_val[j0a + li]; }
+        }
+        if (hn + stride < n_hot) { j0b = seg0[hn + stride]; j1b = seg1[hn + stride]; }
+        for (int jb = j0; jb < j1; jb += LPN) {
+            if (jb > j0) {                                   // runs longer than LPN entries
                 const int jn = jb + li;
-                const int d_l = jn < j1 ? csc_row[jn] - d0 : 0;       // row inside the staged block
-                float x_l = jn < j1 ? csc_val[jn] : 0.f;
-                if (sw && jn < j1) x_l *= sw[d0 + d_l];
-                const int cnt = min(LPN, j1 - jb);
-                int s0 = 0;
-                for (; s0 + UNR <= cnt; s0 += UNR)
-                    col_batch<S, false, UNR>(s0, d_l, x_l, 0, li, kp, thresh, su, nullptr, vt, acc);
-                constexpr int TAIL = (UNR >= 2 && LPN >= 2) ? 2 : 1;
-                for (; s0 < cnt; s0 += TAIL)
-                    col_batch<S, false, TAIL>(s0, d_l, x_l, 0, li, kp, thresh, su, nullptr, vt, acc);
+                d_l = jn < j1 ? csc_row[jn] - d0 : 0;
+                x_l = jn < j1 ? csc_val[jn] : 0.f;
             }
+            if (sw) x_l *= sw[d0 + d_l];                     // lanes beyond the run hold (row 0, count 0)
+            const int cnt = min(LPN, j1 - jb);
+            int s0 = 0;
+            for (; s0 + UNR <= cnt; s0 += UNR)
+                col_batch<S, false, UNR>(s0, d_l, x_l, 0, li, kp, thresh, su, nullptr, vt, acc);
+            constexpr int TAIL = (UNR >= 2 && LPN >= 2) ? 2 : 1;
+            for (; s0 < cnt; s0 += TAIL)
+                col_batch<S, false, TAIL>(s0, d_l, x_l, 0, li, kp, thresh, su, nullptr, vt, acc);
+        }
 #pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                if (S::ok(li, j, kp)) st4(partial + (i64)it * kp + S::c4(li, j), acc[j]);
-                csum[j].x += acc[j].x; csum[j].y += acc[j].y; csum[j].z += acc[j].z; csum[j].w += acc[j].w;
-            }
+        for (int j = 0; j < CH; ++j) {
+            if (S::ok(li, j, kp)) st4(partial + (i64)it * kp + S::c4(li, j), acc[j]);
+            csum[j].x += acc[j].x; csum[j].y += acc[j].y; csum[j].z += acc[j].z; csum[j].w += acc[j].w;
         }
     }
     __syncthreads();
-    block_colsum<S>(csum, li, gid, kp, reinterpret_cast<double *>(su), colsum_rows + (i64)blockIdx.x * kp);
+    block_colsum<S, THREADS>(csum, li, gid, kp, reinterpret_cast<double *>(su), colsum_rows + (i64)blockIdx.x * kp);
 }
 
 // adds the item partials of each column (fixed order) into the un-normalised Vt_new.
@@ -1172,10 +1203,11 @@ __global__ void k_hot_item_fill(const int *__restrict__ hot_cols, int n_hot, int
                                 const int *__restrict__ colptr, const int *__restrict__ item_first,
                                 const int *__restrict__ csc_row, int *__restrict__ item_col,
                                 int *__restrict__ item_start, int *__restrict__ item_end,
-                                unsigned *__restrict__ item_key, int *__restrict__ item_id) {
+                                unsigned *__restrict__ item_key, int *__restrict__ item_id,
+                                int *__restrict__ hot_seg /*[(n_tiles + 1)][n_hot]*/, int *__restrict__ hot_base) {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (i64)n_hot * n_tiles) return;
-    const int h = (int)(t / n_tiles), b = (int)(t % n_tiles);
+    const int h = (int)(t % n_hot), b = (int)(t / n_hot);
     const int c = hot_cols[h];
     const int c0 = colptr[c], c1 = colptr[c + 1];
     auto lower = [&](int doc) {        // first entry of the column with document id >= doc
@@ -1187,9 +1219,13 @@ __global__ void k_hot_item_fill(const int *__restrict__ hot_cols, int n_hot, int
         return lo;
     };
     const int i = item_first[c] + b;
+    const int st = lower(b * hb), en = (b + 1 == n_tiles) ? c1 : lower((b + 1) * hb);
     item_col[i] = c;
-    item_start[i] = lower(b * hb);
-    item_end[i] = (b + 1 == n_tiles) ? c1 : lower((b + 1) * hb);
+    item_start[i] = st;
+    item_end[i] = en;
+    hot_seg[(i64)b * n_hot + h] = st;
+    if (b + 1 == n_tiles) hot_seg[(i64)n_tiles * n_hot + h] = c1;
+    if (b == 0) hot_base[h] = item_first[c];
     item_key[i] = (unsigned)n + (unsigned)(b * hb);      // behind every ordinary item, tiles in block order
     item_id[i] = i;
 }

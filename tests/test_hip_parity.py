@@ -656,8 +656,10 @@ def test_native_rccl_communicator_single_rank(amd):
         np.testing.assert_array_equal(c.allgather_components(eng)[0], V1)
         U2, V2, i2 = amd.sharded_plsa_fit(X, 32, sw, return_info=True, **kw)      # native PLSA_SHARDED loop
         assert i1["n_iter"] == i2["n_iter"]
-        np.testing.assert_array_equal(i2["log_likelihood_trace"], i1["log_likelihood_trace"])
-        np.testing.assert_array_equal(U1, U2); np.testing.assert_array_equal(V1, V2)
+        # (the sharded loop normalises from the all-reduced accumulator, the plain loop from the column
+        # pass' own sums: same value, different float64 summation order)
+        np.testing.assert_allclose(i2["log_likelihood_trace"], i1["log_likelihood_trace"], rtol=1e-6)
+        close_factors(U2, U1, tol=2e-6); close_factors(V2, V1, tol=2e-6)
         # the three-call form with the in-stream all-reduce between accumulate and finish
         eng.upload_csr(X)
         from enstop_amd.plsa import plsa_init
@@ -1156,7 +1158,7 @@ def test_hot_column_tiles_vs_oracle(amd, oracle, monkeypatch, k):
     kw = dict(n_iter=6, n_iter_per_test=2, tolerance=0.0, e_step_thresh=1e-16, random_state=5)
     Uo, Vo, trace, iters = oracle.plsa_fit(X, k, sw, return_trace=True, **kw)
     out = {}
-    for hot in ("1", "0"):
+    for hot in ("2", "0"):
         monkeypatch.setenv("PLSA_HOT", hot)
         monkeypatch.setenv("PLSA_HOT_LDS_KB", "4")
         monkeypatch.setenv("PLSA_HOT_MIN", "1")
@@ -1168,5 +1170,5 @@ def test_hot_column_tiles_vs_oracle(amd, oracle, monkeypatch, k):
             close_factors(U, Uo); close_factors(V, Vo)
             out[hot, name] = (U, V)
     reset_engines()
-    close_factors(out["1", "fused"][1], out["0", "fused"][1], tol=2e-6)
-    close_factors(out["1", "fused"][0], out["0", "fused"][0], tol=2e-6)
+    close_factors(out["2", "fused"][1], out["0", "fused"][1], tol=2e-6)
+    close_factors(out["2", "fused"][0], out["0", "fused"][0], tol=2e-6)
