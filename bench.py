@@ -289,7 +289,6 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "files"],
                     help="files: TEST MODE for boxes with fewer GPUs than ranks (host-file exchange, shared GPUs)")
-    ap.add_argument("--graph", action="store_true", help="replay each run of iterations as a hipGraph (PLSA_GRAPH)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
@@ -312,7 +311,7 @@ def main():
         sys.exit(2)
 
     from enstop_amd import _lib, comm as plsa_comm
-    from enstop_amd.engine import Engine, PLSA_FUSED, PLSA_GRAPH
+    from enstop_amd.engine import Engine, PLSA_FUSED
     import ctypes
     cnt = ctypes.c_int(0)
     if _lib.load().plsa_device_count(ctypes.byref(cnt)) or cnt.value < 1:
@@ -331,7 +330,7 @@ def main():
 
     cfg = CONFIGS[args.config]
     n, m, k = cfg["n"], cfg["m"], cfg["k"]
-    flags = (PLSA_FUSED if args.schedule == "fused" else 0) | (PLSA_GRAPH if args.graph else 0)
+    flags = (PLSA_FUSED if args.schedule == "fused" else 0)
 
     eng = Engine(device)
     info = eng.device_info()
@@ -450,7 +449,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "n_docs": n, "n_vocab": m, "nnz": nnz, "k": k,
-                   "schedule": args.schedule + (" + hipGraph" if args.graph else ""),
+                   "schedule": args.schedule,
                    "parallelism": "single fit" if n_gpus == 1 else
                    "ensemble: one bootstrap member per GPU x%d, all-gather of topics: %s" % (n_gpus, exchange),
                    "ll_test_every": 10, "tolerance": 0.0, "e_step_thresh": 1e-32},

@@ -16,7 +16,6 @@ PLSA_FUSED = 1
 PLSA_TRACE_LL = 4
 PLSA_SW_LL_ONLY = 8
 PLSA_STOP_NO_ZERO_ARM = 16
-PLSA_GRAPH = 32
 PLSA_SHARDED = 64
 
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")

@@ -106,19 +106,8 @@ struct plsa_ctx {
     DevBuf sw, ll_partials, ll_out, colsum_partials, norm_pwz, norm_pdz, tmp0, tmp1, tmp2, cubtmp;
     double *h_ll = nullptr;  // pinned
 
-    // hot columns: words with >= hot_min_per_tile entries per block of `hb` documents on average are cut at
-    // the block boundaries and processed by k_col_hot (P(z|d) rows of a block staged in LDS)
-    int hot_mode = 1;                // PLSA_HOT: 0 off, 1 large corpora only (fused schedule), 2 whenever possible
-    double hot_min_per_tile = 8.0;   // PLSA_HOT_MIN
-    int hot_lds_kb = 32;             // PLSA_HOT_LDS_KB: LDS per workgroup for the staged block of P(z|d) rows
-    double hot_limit = 2e9;          // nnz * kp from which hot_mode 1 switches the tiles on (PLSA_HOT_LIMIT)
-    int hot_slices = 0;              // PLSA_HOT_SLICES (0 = by size)
-    DevBuf hot_seg, hot_base;
-    int hb = 0, n_tiles = 0, n_hot = 0, struct_kp = 0;
-    i64 n_cold_items = 0;
-    DevBuf hot_cols, item_end, colsum_rows, colsum_rows2;
+    DevBuf item_end, colsum_rows, colsum_rows2;
     int colsum_rows_used = 0;        // rows of colsum_rows written by the last column pass
-    hipEvent_t ev_hot = nullptr, ev_cold = nullptr;
 
     // multi-GPU exchange: one RCCL communicator per context (one process per GPU), collectives are
     // enqueued on the context's own streams
@@ -459,78 +448,32 @@ int ensure_csc(plsa_ctx *c) {
     } else {
         HIPCHK(c, hipMemsetAsync(c->colptr.p, 0, sizeof(int) * (size_t)(m + 1), c->stream));
     }
-    // column items (ordinary chunks + hot tiles, see k_col_item_counts)
-    {
-        // block of documents whose P(z|d) rows fit the LDS budget of k_col_hot (power of two)
-        const int kp = std::max(c->kp, 4);
-        int hb = 32;
-        while (hb * 2 * kp * 4 <= c->hot_lds_kb * 1024 && hb < 4096) hb *= 2;
-        c->hb = hb;
-        c->n_tiles = (int)((c->n + hb - 1) / hb);
-        c->struct_kp = c->kp;
-    }
-    const bool hot_on = c->kp > 0 && c->n_tiles >= 8 && (i64)c->hb * c->kp * 4 <= (i64)c->hot_lds_kb * 1024 &&
-                        (c->hot_mode >= 2 || (c->hot_mode == 1 && (double)nnz * c->kp >= c->hot_limit));
-    double hot_min_d = hot_on ? std::max(c->hot_min_per_tile * (double)c->n_tiles, (double)c->seg) : 0.0;
+    // column items
     CHK(ensure(c, c->item_first, sizeof(int) * (size_t)(m + 1)));
-    CHK(ensure(c, c->tmp0, sizeof(int) * (size_t)(m + 1) * 2));      // counts, hot flags
-    CHK(ensure(c, c->hot_cols, sizeof(int) * (size_t)(m + 1)));
-    CHK(ensure(c, c->tmp1, sizeof(int) * (size_t)std::max<i64>(nnz, m + 1)));
-    int *d_cnt = c->tmp0.as<int>(), *d_flag = c->tmp0.as<int>() + (m + 1);
-    constexpr int HOT_CAP = 2048;    // word ids + item bases of the hot columns live in k_col_hot's LDS
-    for (int attempt = 0;; ++attempt) {
-        const int hot_min = hot_on ? (int)std::min<double>(hot_min_d, 2.0e9) : 0;
-        HIPCHK(c, hipMemsetAsync(c->tmp0.p, 0, sizeof(int) * (size_t)(m + 1) * 2, c->stream));
-        hipLaunchKernelGGL(plsa::k_col_item_counts, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                           c->colptr.as<int>(), (int)m, c->seg, hot_min, c->n_tiles, d_cnt, d_flag);
-        // the hot columns in ascending word order (deterministic), their count behind the list
-        hipLaunchKernelGGL(plsa::k_iota, dim3(grid_for(c, m, 256)), dim3(256), 0, c->stream, c->tmp1.as<int>(), m);
-        size_t bytes = 0;
-        HIPCHK(c, hipcub::DeviceSelect::Flagged(nullptr, bytes, c->tmp1.as<int>(), d_flag, c->hot_cols.as<int>(),
-                                                c->hot_cols.as<int>() + m, (int)m, c->stream));
-        CHK(ensure(c, c->cubtmp, bytes));
-        HIPCHK(c, hipcub::DeviceSelect::Flagged(c->cubtmp.p, bytes, c->tmp1.as<int>(), d_flag, c->hot_cols.as<int>(),
-                                                c->hot_cols.as<int>() + m, (int)m, c->stream));
-        int cnt_hot = 0;
-        HIPCHK(c, hipMemcpyAsync(&cnt_hot, c->hot_cols.as<int>() + m, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (cnt_hot <= HOT_CAP || attempt >= 12) break;
-        hot_min_d *= 2.0;            // too many: only the more frequent ones
-    }
-    CHK(exclusive_sum_int(c, d_cnt, c->item_first.as<int>(), m + 1));
-    int n_items = 0, n_hot = 0;
+    HIPCHK(c, hipMemsetAsync(c->tmp0.p, 0, sizeof(int) * (size_t)(m + 1), c->stream));
+    hipLaunchKernelGGL(plsa::k_col_item_counts, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                       c->colptr.as<int>(), (int)m, c->seg, c->tmp0.as<int>());
+    CHK(exclusive_sum_int(c, c->tmp0.as<int>(), c->item_first.as<int>(), m + 1));
+    int n_items = 0;
     HIPCHK(c, hipMemcpyAsync(&n_items, c->item_first.as<int>() + m, sizeof(int), hipMemcpyDeviceToHost,
                              c->stream));
-    HIPCHK(c, hipMemcpyAsync(&n_hot, c->hot_cols.as<int>() + m, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_items = n_items;
-    c->n_hot = n_hot;
-    c->n_cold_items = (i64)n_items - (i64)n_hot * c->n_tiles;
     const size_t ni = (size_t)std::max<i64>(n_items, 1);
     CHK(ensure(c, c->item_col, sizeof(int) * ni));
     CHK(ensure(c, c->item_start, sizeof(int) * ni));
     CHK(ensure(c, c->item_end, sizeof(int) * ni));
     CHK(ensure(c, c->item_order, sizeof(int) * ni));
-    CHK(ensure(c, c->tmp2, sizeof(int) * ni * 2));                                   // keys, keys sorted
-    CHK(ensure(c, c->tmp1, sizeof(int) * std::max(ni, (size_t)std::max<i64>(nnz, m + 1))));   // item ids
+    CHK(ensure(c, c->tmp2, sizeof(int) * ni * 2));       // first documents, sorted
+    CHK(ensure(c, c->tmp1, sizeof(int) * ni));           // item ids
     unsigned *d_key = c->tmp2.as<unsigned>();
     hipLaunchKernelGGL(plsa::k_item_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                       c->colptr.as<int>(), c->item_first.as<int>(), d_flag, (int)m, c->seg, (int)c->n,
-                       c->csc_row.as<int>(), c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(),
-                       d_key, c->tmp1.as<int>());
-    if (n_hot > 0) {
-        CHK(ensure(c, c->hot_seg, sizeof(int) * (size_t)(c->n_tiles + 1) * n_hot));
-        CHK(ensure(c, c->hot_base, sizeof(int) * (size_t)n_hot));
-        hipLaunchKernelGGL(plsa::k_hot_item_fill, dim3((unsigned)(((i64)n_hot * c->n_tiles + 255) / 256)), dim3(256), 0, c->stream,
-                           c->hot_cols.as<int>(), n_hot, c->n_tiles, c->hb, (int)c->n, c->colptr.as<int>(),
-                           c->item_first.as<int>(), c->csc_row.as<int>(), c->item_col.as<int>(),
-                           c->item_start.as<int>(), c->item_end.as<int>(), d_key, c->tmp1.as<int>(),
-                           c->hot_seg.as<int>(), c->hot_base.as<int>());
-    }
+                       c->colptr.as<int>(), c->item_first.as<int>(), (int)m, c->seg, c->csc_row.as<int>(),
+                       c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(), d_key, c->tmp1.as<int>());
     CHK(launch_check(c, "k_item_fill"));
-    if (n_items > 0) {   // visiting order: ascending first document (stable) -> doc-band-major; hot tiles last
+    if (n_items > 0) {   // visiting order: ascending first document (stable) -> doc-band-major
         int dbits = 1;
-        while (((i64)1 << dbits) < 2 * c->n) ++dbits;
+        while (((i64)1 << dbits) < c->n) ++dbits;
         size_t bytes = 0;
         HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, d_key, d_key + ni,
                                                      c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, dbits, c->stream));
@@ -578,7 +521,6 @@ void set_shape(plsa_ctx *c, int k) {
         if (!c->seg_override) c->csc_valid = false;
         c->struct_lpn = lpn;
     }
-    if (c->hot_mode > 0 && kp != c->struct_kp) c->csc_valid = false;   // the hot tiles' block size depends on kp
 }
 
 int need_factors(plsa_ctx *c) {
@@ -693,8 +635,8 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, floa
 
 // vocabulary-owned pass (no atomics): partial k-vectors per column item (+ per-block sums of them, from
 // which the column tail gets norm_pwz), then per-column sums -> Vacc
-// parts: 1 = the column pass itself (ordinary items by k_col_pass, hot tiles by k_col_hot in the fused
-//        schedule), 2 = the un-normalised per-column sums of its partials (k_col_reduce), 3 = both
+// parts: 1 = the column pass itself, 2 = the un-normalised per-column sums of its partials (k_col_reduce),
+//        3 = both
 int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int parts = 3) {
     CHK(ensure_csc(c));
     CHK(ensure(c, c->partial, sizeof(float) * (size_t)std::max<i64>(c->n_items, 1) * c->kp));
@@ -702,20 +644,16 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int 
     CHK(dispatch_shape(c, [&](auto S) {
         using Sh = decltype(S);
         constexpr int LPN = Sh::LPN, GPB = 256 / LPN;
-        const bool hot = !from_p && c->n_hot > 0;          // hot tiles by their own kernel (U rows from LDS)
-        const i64 n_visit = hot ? c->n_cold_items : c->n_items;
-        const int grid = grid_for(c, n_visit, GPB);
-        constexpr int HOT_THREADS = 512, HOT_GPB = HOT_THREADS / LPN;
-        // enough workgroups to fill the chip a few times over; every slice re-stages the tile's rows
-        int slices = c->hot_slices > 0 ? c->hot_slices
-                                       : (int)std::max<i64>(1, (8 * (i64)c->prop.multiProcessorCount + c->n_tiles - 1) / std::max(c->n_tiles, 1));
-        slices = std::max(1, std::min(slices, (c->n_hot + HOT_GPB - 1) / HOT_GPB));
-        const int grid_hot = hot ? c->n_tiles * slices : 0;
+        const i64 n_visit = c->n_items;
+        int grid = grid_for(c, n_visit, GPB);
+        // small corpora: one resident wave of workgroups (5 per CU at ~94 VGPRs), so that norm_pwz comes out
+        // of their ~1280 sum rows in one short single-workgroup launch (4096 rows took 22-29 us, traced)
+        if ((double)c->nnz * c->kp < c->overlap_full_limit) grid = std::min(grid, 5 * c->prop.multiProcessorCount);
         const int grid2 = grid_for(c, c->m, GPB);
-        const int *order = c->item_order.as<int>();
+        const int *order = c->use_item_order ? c->item_order.as<int>() : nullptr;
         const int xcd_split = (c->xcd_split && grid >= 64) ? 1 : 0;
         if (parts & 1) {
-            rc = ensure(c, c->colsum_rows, sizeof(double) * (size_t)(grid + grid_hot) * c->kp);
+            rc = ensure(c, c->colsum_rows, sizeof(double) * (size_t)grid * c->kp);
             if (rc) return;
             const size_t smem = sizeof(double) * (size_t)GPB * c->kp;
             if (from_p) {
@@ -735,18 +673,7 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int 
                                    p_base(c), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split,
                                    c->colsum_rows.as<double>());
             }
-            if (hot) {
-                const size_t lds = std::max(sizeof(float) * (size_t)c->hb * c->kp + sizeof(int) * 2 * (size_t)c->n_hot,
-                                            sizeof(double) * (size_t)HOT_GPB * c->kp);
-                Scope s(c, "k_col_hot");
-                hipLaunchKernelGGL((plsa::k_col_hot<Sh, HOT_THREADS>), dim3(grid_hot), dim3(HOT_THREADS), lds, c->ls,
-                                   c->hot_cols.as<int>(), c->hot_base.as<int>(), c->n_hot, c->hot_seg.as<int>(),
-                                   c->n_tiles, slices, c->hb, (int)c->n, c->csc_row.as<int>(),
-                                   c->csc_val.as<float>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(), d_sw,
-                                   c->partial.as<float>(), c->kp, thresh,
-                                   c->colsum_rows.as<double>() + (size_t)grid * c->kp);
-            }
-            c->colsum_rows_used = grid + grid_hot;
+            c->colsum_rows_used = grid;
         }
         if (parts & 2) {
             // heavy columns (one block each) and the rest share one launch
@@ -806,17 +733,21 @@ int run_col_tail(plsa_ctx *c) {
     }
     const int rows = c->colsum_rows_used;
     if (rows <= 0) return fail(c, "internal: column tail without a column pass");
-    const int nb = std::min(rows, 64);
-    CHK(ensure(c, c->colsum_rows2, sizeof(double) * (size_t)nb * c->kp));
     CHK(ensure(c, c->norm_pwz, sizeof(float) * (size_t)c->kp));
-    {
+    const double *rows_in = c->colsum_rows.as<double>();
+    int n_rows = rows;
+    if (rows > 2048) {               // many workgroups (large corpora): two stages, 64 workgroups first
+        const int nb = 64;
+        CHK(ensure(c, c->colsum_rows2, sizeof(double) * (size_t)nb * c->kp));
         Scope s(c, "k_norm_reduce");
-        hipLaunchKernelGGL(plsa::k_norm_reduce, dim3(nb), dim3(256), 0, c->ls, c->colsum_rows.as<double>(), rows, c->kp,
+        hipLaunchKernelGGL(plsa::k_norm_reduce, dim3(nb), dim3(256), 0, c->ls, rows_in, rows, c->kp,
                            c->colsum_rows2.as<double>());
+        rows_in = c->colsum_rows2.as<double>();
+        n_rows = nb;
     }
     {
         Scope s(c, "k_colsum_final");
-        hipLaunchKernelGGL(plsa::k_colsum_final, dim3(1), dim3(256), 0, c->ls, c->colsum_rows2.as<double>(), nb, c->kp,
+        hipLaunchKernelGGL(plsa::k_colsum_final, dim3(1), dim3(256), 0, c->ls, rows_in, n_rows, c->kp,
                            c->norm_pwz.as<float>());
     }
     CHK(dispatch_shape(c, [&](auto S) {
@@ -923,8 +854,6 @@ int plsa_create(int device, plsa_ctx **out) {
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_hot, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_cold, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&c->h_ll, sizeof(double) * 2, hipHostMallocDefault) != hipSuccess) {
         delete c;
         return fail(nullptr, "stream / pinned buffer creation failed");
@@ -948,11 +877,6 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_E_ROWS")) c->e_rows = atoi(s);
     if (const char *s = getenv("PLSA_MT_STREAMS")) c->mt_streams = std::max(1, std::min(4096, atoi(s)));
     if (const char *s = getenv("PLSA_MT_MIN_BLOCKS")) c->mt_min_blocks = std::max(1, atoi(s));
-    if (const char *s = getenv("PLSA_HOT")) c->hot_mode = atoi(s);
-    if (const char *s = getenv("PLSA_HOT_MIN")) c->hot_min_per_tile = std::max(1.0, atof(s));
-    if (const char *s = getenv("PLSA_HOT_LDS_KB")) c->hot_lds_kb = std::max(1, std::min(48, atoi(s)));
-    if (const char *s = getenv("PLSA_HOT_LIMIT")) c->hot_limit = atof(s);
-    if (const char *s = getenv("PLSA_HOT_SLICES")) c->hot_slices = std::max(0, atoi(s));
     *out = c;
     return 0;
 }
@@ -963,9 +887,7 @@ void plsa_destroy(plsa_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     release(c->comm_send); release(c->comm_recv); release(c->comm_small);
-    release(c->hot_cols); release(c->item_end); release(c->hot_seg); release(c->hot_base); release(c->colsum_rows); release(c->colsum_rows2);
-    if (c->ev_hot) (void)hipEventDestroy(c->ev_hot);
-    if (c->ev_cold) (void)hipEventDestroy(c->ev_cold);
+    release(c->item_end); release(c->colsum_rows); release(c->colsum_rows2);
     DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,

@@ -611,102 +611,6 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int *__restr
     block_colsum<S>(csum, li, gid, kp, scol, colsum_rows + (i64)blockIdx.x * kp);
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_col_hot: the column pass of the FREQUENT words (those with several entries in every block of hb
-// consecutive documents).  Their postings are the L2-friendliest of the column pass, but each still costs
-// a 256-byte gather through the L2 request pipe; here a workgroup owns a block ("tile") of hb documents,
-// stages their P(z|d) rows in LDS once (one coalesced read of the block) and walks the hot words' runs of
-// entries inside the block -- contiguous in the CSC arrays, because a column's entries are in document
-// order.  Gathers become LDS reads; one partial row per (word, tile).  Tiles are ordinary column items
-// (item_first / item_start / item_end), so the materialised schedule and the reduce kernels see nothing
-// special; this kernel reads the same run boundaries from a dense [tile][word] table (hot_seg) so that
-// nothing it loads depends on another load: the boundaries are fetched two words ahead, the word's P(w|z)
-// row and its first LPN entries one word ahead.  Grid: n_tiles x slices workgroups of THREADS lanes;
-// slice s of a tile takes the hot words s GPB + gid, + slices GPB, ... (rank-interleaved: balanced).
-// ------------------------------------------------------------------------------------------------
-template <class S, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_col_hot(const int *__restrict__ hot_cols, const int *__restrict__ hot_base,
-                                                     int n_hot, const int *__restrict__ hot_seg, int n_tiles,
-                                                     int slices, int hb, int n, const int *__restrict__ csc_row,
-                                                     const float *__restrict__ csc_val, const float *__restrict__ U,
-                                                     const float *__restrict__ Vt, const float *__restrict__ sw,
-                                                     float *__restrict__ partial, int kp_rt, float thresh,
-                                                     double *__restrict__ colsum_rows) {
-    constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR_COL;
-    constexpr int GPB = THREADS / LPN;
-    extern __shared__ float su[];      // [hb][kp] P(z|d) rows of the tile, then word ids and item bases
-    const int kp = S::kp(kp_rt);
-    const int li = threadIdx.x % LPN;
-    const int gid = threadIdx.x / LPN;
-    int *s_cols = reinterpret_cast<int *>(su + (i64)hb * kp);
-    int *s_base = s_cols + n_hot;
-    const int b = (int)(blockIdx.x % n_tiles), sl = (int)(blockIdx.x / n_tiles);
-    const int d0 = b * hb, rows = min(hb, n - d0);
-    {
-        const i64 n4 = (i64)rows * kp / 4;
-        for (i64 i = threadIdx.x; i < n4; i += THREADS) st4(su + i * 4, ld4(U + (i64)d0 * kp + i * 4));
-        for (int i = threadIdx.x; i < n_hot; i += THREADS) { s_cols[i] = hot_cols[i]; s_base[i] = hot_base[i]; }
-    }
-    __syncthreads();
-    float4 csum[CH];
-#pragma unroll
-    for (int j = 0; j < CH; ++j) csum[j] = zero4();
-    const int stride = slices * GPB;
-    const int *seg0 = hot_seg + (i64)b * n_hot, *seg1 = seg0 + n_hot;
-    int h = sl * GPB + gid;
-    int j0a = 0, j1a = 0, j0b = 0, j1b = 0;
-    if (h < n_hot) { j0a = seg0[h]; j1a = seg1[h]; }
-    if (h + stride < n_hot) { j0b = seg0[h + stride]; j1b = seg1[h + stride]; }
-    float4 vt_n[CH];
-    int d_n = 0;
-    float x_n = 0.f;
-#pragma unroll
-    for (int j = 0; j < CH; ++j) vt_n[j] = zero4();
-    if (h < n_hot) {
-        load_row<S, true>(Vt + (i64)s_cols[h] * kp, li, kp, vt_n);
-        if (j0a + li < j1a) { d_n = csc_row[j0a + li] - d0; x_n = csc_val[j0a + li]; }
-    }
-    for (; h < n_hot; h += stride) {
-        const int j0 = j0a, j1 = j1a, it = s_base[h] + b;
-        float4 vt[CH], acc[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) { vt[j] = vt_n[j]; acc[j] = zero4(); }
-        int d_l = d_n;
-        float x_l = x_n;
-        // next word: its P(w|z) row and first entries; the word after it: its run boundaries
-        j0a = j0b; j1a = j1b;
-        const int hn = h + stride;
-        d_n = 0; x_n = 0.f;
-        if (hn < n_hot) {
-            load_row<S, true>(Vt + (i64)s_cols[hn] * kp, li, kp, vt_n);
-            if (j0a + li < j1a) { d_n = csc_row[j0a + li] - d0; x_n = csc_val[j0a + li]; }
-        }
-        if (hn + stride < n_hot) { j0b = seg0[hn + stride]; j1b = seg1[hn + stride]; }
-        for (int jb = j0; jb < j1; jb += LPN) {
-            if (jb > j0) {                                   // runs longer than LPN entries
-                const int jn = jb + li;
-                d_l = jn < j1 ? csc_row[jn] - d0 : 0;
-                x_l = jn < j1 ? csc_val[jn] : 0.f;
-            }
-            if (sw) x_l *= sw[d0 + d_l];                     // lanes beyond the run hold (row 0, count 0)
-            const int cnt = min(LPN, j1 - jb);
-            int s0 = 0;
-            for (; s0 + UNR <= cnt; s0 += UNR)
-                col_batch<S, false, UNR>(s0, d_l, x_l, 0, li, kp, thresh, su, nullptr, vt, acc);
-            constexpr int TAIL = (UNR >= 2 && LPN >= 2) ? 2 : 1;
-            for (; s0 < cnt; s0 += TAIL)
-                col_batch<S, false, TAIL>(s0, d_l, x_l, 0, li, kp, thresh, su, nullptr, vt, acc);
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            if (S::ok(li, j, kp)) st4(partial + (i64)it * kp + S::c4(li, j), acc[j]);
-            csum[j].x += acc[j].x; csum[j].y += acc[j].y; csum[j].z += acc[j].z; csum[j].w += acc[j].w;
-        }
-    }
-    __syncthreads();
-    block_colsum<S, THREADS>(csum, li, gid, kp, reinterpret_cast<double *>(su), colsum_rows + (i64)blockIdx.x * kp);
-}
-
 // adds the item partials of each column (fixed order) into the un-normalised Vt_new.
 // Columns with more than `heavy_items` items (the Zipf head) take a whole block: its groups stride
 // over the column's items (fixed assignment, loads batched four deep, added in item order), then their
@@ -1163,28 +1067,19 @@ __global__ void k_item_counts(const int *__restrict__ colptr, int m, int seg, in
     if (c < m) cnt[c] = (colptr[c + 1] - colptr[c] + seg - 1) / seg;
 }
 // item arrays + the first document of every item (sort key of the doc-band-major visiting order)
-// Column items.  An ordinary column is cut into chunks of <= seg entries.  A HOT column (at least
-// hot_min entries, hot_min = tiles * a few: several entries in every block of hb documents) is cut at the
-// block boundaries instead: n_tiles items, item b = its entries with document in [b hb, (b+1) hb).
-__global__ void k_col_item_counts(const int *__restrict__ colptr, int m, int seg, int hot_min, int n_tiles,
-                                  int *__restrict__ cnt, int *__restrict__ hot_flag) {
+// Column items: a column is cut into chunks of <= seg entries (explicit [item_start, item_end) bounds).
+__global__ void k_col_item_counts(const int *__restrict__ colptr, int m, int seg, int *__restrict__ cnt) {
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < m) {
-        const int len = colptr[c + 1] - colptr[c];
-        const bool hot = hot_min > 0 && len >= hot_min;
-        cnt[c] = hot ? n_tiles : (len + seg - 1) / seg;
-        hot_flag[c] = hot ? 1 : 0;
-    }
+    if (c < m) cnt[c] = (colptr[c + 1] - colptr[c] + seg - 1) / seg;
 }
 
-// sort key of an item for the visiting order: ordinary items by first document, hot tiles behind them
-__global__ void k_item_fill(const int *__restrict__ colptr, const int *__restrict__ item_first,
-                            const int *__restrict__ hot_flag, int m, int seg, int n,
+// sort key of an item for the visiting order: its first document
+__global__ void k_item_fill(const int *__restrict__ colptr, const int *__restrict__ item_first, int m, int seg,
                             const int *__restrict__ csc_row, int *__restrict__ item_col,
                             int *__restrict__ item_start, int *__restrict__ item_end,
                             unsigned *__restrict__ item_key, int *__restrict__ item_id) {
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < m && !hot_flag[c]) {
+    if (c < m) {
         const int i0 = item_first[c], i1 = item_first[c + 1];
         for (int i = i0; i < i1; ++i) {
             const int st = colptr[c] + (i - i0) * seg;
@@ -1195,39 +1090,6 @@ __global__ void k_item_fill(const int *__restrict__ colptr, const int *__restric
             item_id[i] = i;
         }
     }
-}
-
-// one thread per (hot column, tile): the tile's run of entries by binary search in the column's
-// (ascending) document ids
-__global__ void k_hot_item_fill(const int *__restrict__ hot_cols, int n_hot, int n_tiles, int hb, int n,
-                                const int *__restrict__ colptr, const int *__restrict__ item_first,
-                                const int *__restrict__ csc_row, int *__restrict__ item_col,
-                                int *__restrict__ item_start, int *__restrict__ item_end,
-                                unsigned *__restrict__ item_key, int *__restrict__ item_id,
-                                int *__restrict__ hot_seg /*[(n_tiles + 1)][n_hot]*/, int *__restrict__ hot_base) {
-    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (i64)n_hot * n_tiles) return;
-    const int h = (int)(t % n_hot), b = (int)(t / n_hot);
-    const int c = hot_cols[h];
-    const int c0 = colptr[c], c1 = colptr[c + 1];
-    auto lower = [&](int doc) {        // first entry of the column with document id >= doc
-        int lo = c0, hi = c1;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (csc_row[mid] < doc) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-    };
-    const int i = item_first[c] + b;
-    const int st = lower(b * hb), en = (b + 1 == n_tiles) ? c1 : lower((b + 1) * hb);
-    item_col[i] = c;
-    item_start[i] = st;
-    item_end[i] = en;
-    hot_seg[(i64)b * n_hot + h] = st;
-    if (b + 1 == n_tiles) hot_seg[(i64)n_tiles * n_hot + h] = c1;
-    if (b == 0) hot_base[h] = item_first[c];
-    item_key[i] = (unsigned)n + (unsigned)(b * hb);      // behind every ordinary item, tiles in block order
-    item_id[i] = i;
 }
 
 // ------------------------------------------------------------------------------------------------

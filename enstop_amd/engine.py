@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 from . import _lib
-from ._lib import PLSA_FUSED, PLSA_GRAPH, PLSA_SHARDED, PLSA_STOP_NO_ZERO_ARM, PLSA_SW_LL_ONLY, PLSA_TRACE_LL, ptr
+from ._lib import PLSA_FUSED, PLSA_SHARDED, PLSA_STOP_NO_ZERO_ARM, PLSA_SW_LL_ONLY, PLSA_TRACE_LL, ptr
 
 
 class DeviceError(RuntimeError):

@@ -40,8 +40,6 @@ enum {
                            enstop/plsa.py:591, 606-628, 631                                         */
     PLSA_STOP_NO_ZERO_ARM = 16, /* plsa_fit: stop test of enstop/block_parallel_plsa.py:329-331
                            (`change / |cur| < tolerance` only, no `change == 0` arm)               */
-    PLSA_GRAPH     = 32, /* plsa_fit / plsa_refit: replay the launches of each run of iterations between
-                           two log-likelihood tests as one hipGraph (small corpora are launch-bound)  */
     PLSA_SHARDED   = 64 /* plsa_fit: the context's rows are ONE SHARD of the corpus; the P(w|z)
                            accumulator and the log-likelihood are all-reduced over the context's RCCL
                            communicator every iteration (plsa_comm_init); every rank passes the same

