@@ -107,6 +107,7 @@ struct plsa_ctx {
     double *h_ll = nullptr;  // pinned
 
     DevBuf item_end, colsum_rows, colsum_rows2;
+    int small_grid = 5;              // PLSA_SMALL_GRID: workgroups per CU of the column pass on small corpora (0 = no cap)
     int colsum_rows_used = 0;        // rows of colsum_rows written by the last column pass
 
     // multi-GPU exchange: one RCCL communicator per context (one process per GPU), collectives are
@@ -648,7 +649,10 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int 
         int grid = grid_for(c, n_visit, GPB);
         // small corpora: one resident wave of workgroups (5 per CU at ~94 VGPRs), so that norm_pwz comes out
         // of their ~1280 sum rows in one short single-workgroup launch (4096 rows took 22-29 us, traced)
-        if ((double)c->nnz * c->kp < c->overlap_full_limit) grid = std::min(grid, 5 * c->prop.multiProcessorCount);
+        // (only when the items would fill the chip a few times at most: with more items the dynamic balance
+        // of a large grid wins -- config 2's pass went 183 -> 218 us under the cap)
+        if (c->small_grid > 0 && (double)c->nnz * c->kp < c->overlap_full_limit && grid <= 32 * c->prop.multiProcessorCount)
+            grid = std::min(grid, c->small_grid * c->prop.multiProcessorCount);
         const int grid2 = grid_for(c, c->m, GPB);
         const int *order = c->use_item_order ? c->item_order.as<int>() : nullptr;
         const int xcd_split = (c->xcd_split && grid >= 64) ? 1 : 0;
@@ -877,6 +881,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_E_ROWS")) c->e_rows = atoi(s);
     if (const char *s = getenv("PLSA_MT_STREAMS")) c->mt_streams = std::max(1, std::min(4096, atoi(s)));
     if (const char *s = getenv("PLSA_MT_MIN_BLOCKS")) c->mt_min_blocks = std::max(1, atoi(s));
+    if (const char *s = getenv("PLSA_SMALL_GRID")) c->small_grid = std::max(0, atoi(s));
     *out = c;
     return 0;
 }

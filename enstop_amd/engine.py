@@ -383,12 +383,29 @@ def get_engine(device=None):
     return eng
 
 
+_member_engines = {}
+
+
+def get_member_engines(device=None, jobs=1):
+    """`jobs` engines on one device for ensemble members fitted concurrently (each context has its own
+    HIP streams and buffers): the process-wide engine of the device first, then cached extra ones."""
+    first = get_engine(device)
+    extra = _member_engines.setdefault(first.device, [])
+    while len(extra) < jobs - 1:
+        extra.append(Engine(first.device))
+    return [first] + extra[:max(jobs - 1, 0)]
+
+
 def reset_engines():
     """Close the cached per-device engines (tools / tests that change PLSA_* knobs, which a context
     reads when it is created)."""
     for eng in list(_engines.values()):
         eng.close()
     _engines.clear()
+    for lst in _member_engines.values():
+        for eng in lst:
+            eng.close()
+    _member_engines.clear()
 
 
 def host_normalize_rows(a):

@@ -986,26 +986,30 @@ def test_randomised_shapes_vs_oracle(amd, oracle):
             U, V, info = amd.plsa_fit(X, k, sw, flags=mode, return_info=True, **kw)
             msg = "case %d (%s): n=%d m=%d k=%d dens=%g thresh=%g %r" % (case, name, n, m, k, dens, thresh, kw)
             # tolerance = 0: the loop can only stop through the `change == 0` arm (plsa.py:635), i.e. when
-            # two successive float32 log-likelihoods are bit-equal.  That decision must agree with the
-            # oracle's except for the cases listed in ZERO_CHANGE_FLIPS (converged fits whose likelihood
-            # sits on a float32 rounding boundary: HIP accumulates it in float64, the reference in
-            # float32); for those the converged factors must still agree.
+            # two successive float32 log-likelihoods are bit-equal.  HIP accumulates the likelihood in
+            # float64, the reference in float32, so on a converged fit (k = 1 ...) the two can disagree on
+            # WHEN that happens.  Such a disagreement is accepted only if it is exactly that: the traces
+            # agree as far as both exist, the shorter run stopped on a converged likelihood (last relative
+            # change <= 3e-7, about two float32 ulps), and the factors agree like everywhere else.
+            t_hip = info["log_likelihood_trace"]
             if info["n_iter"] != iters:
+                q = min(len(t_hip), len(trace))
+                assert q >= 2, msg
+                close_ll(t_hip[:q], trace[:q])
+                longer = t_hip if len(t_hip) > len(trace) else trace
+                tail = abs(np.float64(longer[q - 1]) - np.float64(longer[q - 2])) / abs(np.float64(longer[q - 1]))
+                assert tail <= 3e-7, "iteration count %d != %d without a converged likelihood: %s" % (
+                    info["n_iter"], iters, msg)
                 flips.add((case, name, k, info["n_iter"], iters))
             else:
-                close_ll(info["log_likelihood_trace"], trace)
+                close_ll(t_hip, trace)
             # a threshold inside the range of the products P(w|z) P(z|d) (1e-4 here) lets single
             # responsibilities flip in and out on last-bit differences -- between any two summation orders,
             # two CPU builds of the oracle included; such cases get 2e-3
             tol = 2e-3 if thresh >= 1e-6 else 1e-4
             assert np.abs(U - Uo).max() <= tol * max(Uo.max(), 1e-30), msg
             assert np.abs(V - Vo).max() <= tol * max(Vo.max(), 1e-30), msg
-    assert {f[:2] for f in flips} == ZERO_CHANGE_FLIPS, sorted(flips)
-
-
-# (case index, schedule) pairs of test_randomised_shapes_vs_oracle whose `change == 0` stop decision differs
-# from the float32 oracle's (see the comment there); established on MI355X, must stay short
-ZERO_CHANGE_FLIPS = {(0, "materialised")}     # k = 1: 3 iterations instead of 2
+    assert len(flips) <= 2, sorted(flips)          # converged-fit boundary cases are rare
 
 
 # ------------------------------------------------------------------------------------------------

@@ -196,13 +196,19 @@ def test_config4_ensemble_on_20ng_shaped_corpus(amd, oracles):
     n, m = X.shape
     k = CONFIG1["k"]
     kw = dict(n_iter=20, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-16)
+    amd.ensemble_of_topics(X, k, n_runs=4, random_state=7, n_jobs=4, **kw)       # warm-up: contexts, buffers
     t0 = time.time()
-    stack = amd.ensemble_of_topics(X, k, n_runs=32, random_state=7, **kw)
+    stack = amd.ensemble_of_topics(X, k, n_runs=32, random_state=7, n_jobs=4, **kw)
     dt = time.time() - t0
+    t0 = time.time()
+    serial = amd.ensemble_of_topics(X, k, n_runs=32, random_state=7, n_jobs=1, **kw)
+    dt1 = time.time() - t0
+    np.testing.assert_array_equal(stack, serial)          # concurrent members: same stack, bit for bit
     assert stack.shape == (32 * k, m) and stack.dtype == np.float32
     np.testing.assert_allclose(stack.sum(axis=1, dtype=np.float64), 1.0, atol=2e-4)
     rec = REPORT.setdefault("config4", {"n_runs": 32, "k": k, "shape": [n, m], "nnz": int(X.nnz),
-                                        "ensemble_seconds_20_iters": round(dt, 3)})
+                                        "ensemble_seconds_20_iters_4_concurrent_members": round(dt, 3),
+                                        "ensemble_seconds_20_iters_one_member_at_a_time": round(dt1, 3)})
     # run r of the ensemble == the standalone member with the r-th derived stream, bit for bit
     for run in (0, 13, 31):
         V = amd.plsa_topics(X, k, random_state=np.random.RandomState(7 + run), **kw)

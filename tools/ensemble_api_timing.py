@@ -23,14 +23,15 @@ def main():
             eng.generate_synthetic(n, m, nnz_t, seed=0)
             X = eng.download_active_csr()
         enstop_amd.ensemble_of_topics(X, k, n_runs=1, parallelism="none", n_iter=2, tolerance=0.0, random_state=1)   # warm-up
-        for par in ("none", "dask"):
+        enstop_amd.ensemble_of_topics(X, k, n_runs=4, n_jobs=4, n_iter=2, tolerance=0.0, random_state=1)             # extra contexts
+        for par, jobs in (("none", 1), ("dask", 1), ("dask", 2), ("dask", 4)):
             t0 = time.perf_counter()
-            T = enstop_amd.ensemble_of_topics(X, k, n_runs=runs, parallelism=par, n_iter=50, n_iter_per_test=10,
-                                              tolerance=0.0, random_state=7)
+            T = enstop_amd.ensemble_of_topics(X, k, n_runs=runs, parallelism=par, n_jobs=jobs, n_iter=50,
+                                              n_iter_per_test=10, tolerance=0.0, random_state=7)
             dt = time.perf_counter() - t0
             assert T.shape == (runs * k, m) and np.isfinite(T).all()
-            print(json.dumps({"config": name, "nnz": int(X.nnz), "parallelism": par, "n_iter": 50, "seconds": round(dt, 3),
-                              "fits_per_min_1gpu": round(runs / dt * 60, 1)}), flush=True)
+            print(json.dumps({"config": name, "nnz": int(X.nnz), "parallelism": par, "n_jobs": jobs, "n_iter": 50,
+                              "seconds": round(dt, 3), "fits_per_min_1gpu": round(runs / dt * 60, 1)}), flush=True)
 
 
 if __name__ == "__main__":
