@@ -87,6 +87,13 @@ struct plsa_ctx {
     i64 n_ritems = 0;
     DevBuf ritem_first, ritem_row, ritem_start, rpartial;
 
+    // items of the document-owned E-step: documents cut into pieces of eseg entries (balanced: the four
+    // groups of a wave all run the same number of gather/store bursts; measured 5.27 -> 4.62 ms at config 3)
+    bool eitems_valid = false;
+    int eseg = 0, eseg_override = -1;      // PLSA_E_SEG: -1 auto, 0 whole documents, N pieces of N entries
+    i64 n_eitems = 0;
+    DevBuf eitem_row, eitem_start;
+
     // rows in descending-length order (row-owned kernels: groups of a wave finish together)
     bool sort_rows = true, roworder_valid = false;
     DevBuf row_order;
@@ -107,7 +114,7 @@ struct plsa_ctx {
     double *h_ll = nullptr;  // pinned
 
     DevBuf item_end, colsum_rows, colsum_rows2;
-    int small_grid = 5;              // PLSA_SMALL_GRID: workgroups per CU of the column pass on small corpora (0 = no cap)
+    int small_grid = 0;              // PLSA_SMALL_GRID: workgroups per CU of the column pass on small corpora (0 = no cap)
     int colsum_rows_used = 0;        // rows of colsum_rows written by the last column pass
 
     // multi-GPU exchange: one RCCL communicator per context (one process per GPU), collectives are
@@ -325,6 +332,7 @@ void set_active_pointers(plsa_ctx *c) {
     c->csc_valid = false;
     c->roworder_valid = false;
     c->ritems_valid = false;
+    c->eitems_valid = false;
     c->p_valid = false;
 }
 
@@ -396,6 +404,34 @@ int ensure_ritems(plsa_ctx *c) {
         CHK(launch_check(c, "k_ritem_fill"));
     }
     c->ritems_valid = true;
+    return 0;
+}
+
+// items of the document-owned E-step (its own piece length, independent of the document pass' row items)
+int ensure_eitems(plsa_ctx *c, int eseg) {
+    if (c->eitems_valid && c->eseg == eseg) return 0;
+    const i64 n = c->n;
+    c->eseg = eseg;
+    c->n_eitems = 0;
+    if (eseg > 0) {
+        CHK(ensure(c, c->tmp0, sizeof(int) * (size_t)(n + 1)));
+        CHK(ensure(c, c->tmp1, sizeof(int) * (size_t)(n + 1)));
+        HIPCHK(c, hipMemsetAsync(c->tmp0.p, 0, sizeof(int) * (size_t)(n + 1), c->stream));
+        hipLaunchKernelGGL(plsa::k_item_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           c->indptr, (int)n, eseg, c->tmp0.as<int>());
+        CHK(exclusive_sum_int(c, c->tmp0.as<int>(), c->tmp1.as<int>(), n + 1));
+        int cnt = 0;
+        HIPCHK(c, hipMemcpyAsync(&cnt, c->tmp1.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->n_eitems = cnt;
+        CHK(ensure(c, c->eitem_row, sizeof(int) * (size_t)std::max(cnt, 1)));
+        CHK(ensure(c, c->eitem_start, sizeof(int) * (size_t)std::max(cnt, 1)));
+        hipLaunchKernelGGL(plsa::k_ritem_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           c->indptr, c->tmp1.as<int>(), (int)n, eseg, c->eitem_row.as<int>(), c->eitem_start.as<int>());
+        CHK(launch_check(c, "k_ritem_fill"));
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // tmp1 is reused by other structure builds
+    }
+    c->eitems_valid = true;
     return 0;
 }
 
@@ -519,6 +555,7 @@ void set_shape(plsa_ctx *c, int k) {
     if (c->ch == 3) c->ch = 4;
     if (lpn != prev_lpn) {        // item lengths / the row-item decision depend on the lane shape
         c->ritems_valid = false;
+        c->eitems_valid = false;
         if (!c->seg_override) c->csc_valid = false;
         c->struct_lpn = lpn;
     }
@@ -553,25 +590,28 @@ int run_e_step(plsa_ctx *c, float thresh) {
         CHK(ensure_best_placement(c, c->P, sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp + std::max(slack, c->p_shift),
                                   c->placement_candidates, c->placement_gbps, &c->placement_tried));
     }
-    // Two traversals.  Document-owned (a group keeps its document's P(z|d) row in registers, gathers
-    // only P(w|z) rows): config 3 5.4 ms against 6.3 ms, config 5 49 ms against 59 ms.  It needs many
-    // documents per resident group to average their lengths out; small corpora (config 2: 1.5
-    // documents per group slot, 0.36 ms against 0.33 ms) keep the perfectly balanced flat kernel.
-    CHK(ensure_ritems(c));
-    const bool items = c->use_ritems && c->n_ritems > 0;
-    const i64 owners = items ? c->n_ritems : c->n;
-    const i64 group_slots = (i64)c->prop.multiProcessorCount * 32 * (64 / c->lpn);
-    const bool e_rows = c->e_rows < 0 ? owners >= 16 * group_slots : c->e_rows != 0;
+    // Two traversals.  Document-owned: a group keeps its document's P(z|d) row in registers and gathers only
+    // P(w|z) rows (config 3 5.3 ms against 6.3 ms for one group per non-zero), and with the documents cut
+    // into pieces of 4 index batches every group of a wave runs the same number of gather/store bursts
+    // (config 3 5.27 -> 4.62 ms = 71 % of the HBM peak; config 2 0.357 -> 0.235 ms = 71 %).  Tiny corpora
+    // (config 1: 84 us in all) keep the flat kernel: one group per non-zero, perfectly balanced, no setup.
+    bool e_rows = c->e_rows < 0 ? (double)c->nnz * c->kp >= 1e8 : c->e_rows != 0;
     if (e_rows) {
-        const int grid = grid_for(c, items ? c->n_ritems : c->n, 256 / c->lpn);
+        // piece length: measured optimum 64 entries at k = 64 (48: 4.86, 64: 4.61, 80: 5.03, whole documents:
+        // 5.36 ms at config 3; config 5, k = 128: flat within 1 % from 32 to 128), 8 entries at k = 32
+        // (0.224 against 0.234-0.238 ms for 16-40 and 0.316 ms for whole documents at config 2)
+        const int eseg = c->eseg_override >= 0 ? c->eseg_override : (c->lpn >= 16 ? 64 : (c->lpn == 8 ? 8 : 16));
+        CHK(ensure_eitems(c, eseg));
+        const bool items = eseg > 0 && c->n_eitems > 0;
+        const int grid = grid_for(c, items ? c->n_eitems : c->n, 256 / c->lpn);
         const int *order = nullptr;
         if (!items) CHK(ensure_roworder(c, &order));
         CHK(dispatch_shape(c, [&](auto S) {
             Scope s(c, "k_e_step");
             hipLaunchKernelGGL((plsa::k_e_step_rows<decltype(S)>), dim3(grid), dim3(256), 0, c->stream,
                                c->indptr, c->col, (int)c->n, order, c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
-                               p_base(c), c->kp, thresh, items ? c->ritem_row.as<int>() : nullptr,
-                               items ? c->ritem_start.as<int>() : nullptr, c->rseg, c->n_ritems);
+                               p_base(c), c->kp, thresh, items ? c->eitem_row.as<int>() : nullptr,
+                               items ? c->eitem_start.as<int>() : nullptr, eseg, c->n_eitems);
         }));
     } else {
         CHK(ensure_rowidx(c));
@@ -879,6 +919,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_XCD_SPLIT")) c->xcd_split = atoi(s) != 0;
     if (const char *s = getenv("PLSA_CHUNKS_PER_LANE")) c->chunks_per_lane = atoi(s);
     if (const char *s = getenv("PLSA_E_ROWS")) c->e_rows = atoi(s);
+    if (const char *s = getenv("PLSA_E_SEG")) c->eseg_override = atoi(s);
     if (const char *s = getenv("PLSA_MT_STREAMS")) c->mt_streams = std::max(1, std::min(4096, atoi(s)));
     if (const char *s = getenv("PLSA_MT_MIN_BLOCKS")) c->mt_min_blocks = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_SMALL_GRID")) c->small_grid = std::max(0, atoi(s));
@@ -895,7 +936,7 @@ void plsa_destroy(plsa_ctx *c) {
     release(c->item_end); release(c->colsum_rows); release(c->colsum_rows2);
     DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
-                     &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,
+                     &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,
                      &c->P, &c->sw, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
                      &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp};
     for (DevBuf *b : all) release(*b);

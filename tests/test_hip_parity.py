@@ -256,15 +256,14 @@ def test_kernels_vs_oracle_midsize(amd, oracle, k):
              np.array([oracle.log_likelihood(r, c, v, Vo, Uo, ones)]))
 
 
-@pytest.mark.parametrize("traversal", ["flat", "documents", "document_items"])
+@pytest.mark.parametrize("traversal", ["flat", "documents", "document_items", "document_items_auto"])
 def test_e_step_traversals_agree_with_reference_and_oracle(amd, oracle, monkeypatch, traversal):
     """The E-step has two traversals, picked by corpus size (one group per non-zero; one group per
     document or document piece).  Both are forced here on the reference goldens and on seeded
     shapes with empty, single-entry and very long documents; the two must agree bit for bit."""
     monkeypatch.setenv("PLSA_E_ROWS", "0" if traversal == "flat" else "1")
-    if traversal == "document_items":
-        monkeypatch.setenv("PLSA_ROW_ITEMS", "1")
-        monkeypatch.setenv("PLSA_ROW_SEG", "16")
+    monkeypatch.setenv("PLSA_E_SEG", {"flat": "0", "documents": "0", "document_items": "16",
+                                      "document_items_auto": "-1"}[traversal])
     results = []
     with amd.Engine() as eng:
         for case in KERNEL_CASES:
@@ -894,10 +893,28 @@ def test_host_and_device_refit_init_paths_give_identical_vectors(amd, monkeypatc
 def test_device_all_pairs_hellinger_matches_definition(amd):
     """plsa_all_pairs_hellinger against the float64 definition (umap.distances.hellinger pairwise,
     enstop_.py:258-266), including zero-mass rows, identical rows and ragged sizes."""
-    from enstop_amd.ensemble import all_pairs_hellinger_distance
+    def hellinger(x, y):
+        """umap.distances.hellinger (umap-learn >= 0.3.8), statement by statement in float64: result,
+        l1_norm_x, l1_norm_y accumulated over the coordinates; both norms zero -> 0, one zero -> 1,
+        else sqrt(1 - result / sqrt(l1_norm_x * l1_norm_y))."""
+        x = x.astype(np.float64); y = y.astype(np.float64)
+        result, lx, ly = np.sum(np.sqrt(x * y)), np.sum(x), np.sum(y)
+        if lx == 0 and ly == 0:
+            return 0.0
+        if lx == 0 or ly == 0:
+            return 1.0
+        return float(np.sqrt(max(1.0 - result / np.sqrt(lx * ly), 0.0)))
+
+    def all_pairs_hellinger_distance(T):                       # enstop_.py:258-266: the pairwise loop
+        t = T.shape[0]
+        D = np.zeros((t, t))
+        for i in range(t):
+            for j in range(i + 1, t):
+                D[i, j] = D[j, i] = hellinger(T[i], T[j])
+        return D
     rs = np.random.RandomState(4)
     with amd.Engine() as eng:
-        for t, m in ((5, 7), (64, 1000), (130, 4097), (321, 25000)):
+        for t, m in ((5, 7), (64, 1000), (130, 4097), (200, 25000)):
             T = rs.rand(t, m).astype(np.float32) ** 3
             T /= T.sum(1, keepdims=True)
             T[1] = T[0]                                            # identical topics: distance 0

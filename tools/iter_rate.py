@@ -18,6 +18,7 @@ ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--flags", default="fused")
 ap.add_argument("--events", action="store_true")
+ap.add_argument("--estep", action="store_true", help="time the materialising E-step kernel instead of fits")
 ap.add_argument("--tag", default="")
 a = ap.parse_args()
 cfg = bench.CONFIGS[a.config]
@@ -26,6 +27,21 @@ nnz = eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], seed=0)
 U0, V0 = bench.init_factors(cfg["n"], cfg["m"], cfg["k"], 42)
 flags = (PLSA_FUSED if a.flags == "fused" else 0)
 eng.set_factors(U0, V0)
+if a.estep:
+    eng.timing(True)
+    eng.e_step(1e-32, want_host_copy=False)
+    best = None
+    for _ in range(a.reps):
+        eng.timing_reset()
+        for _ in range(10):
+            eng.e_step(1e-32, want_host_copy=False)
+        ms, cnt = eng.timing_get("k_e_step")
+        best = ms / cnt if best is None else min(best, ms / cnt)
+    b = bench.algorithmic_bytes("e_step", cfg["n"], cfg["m"], nnz, cfg["k"])
+    print(json.dumps({"tag": a.tag, "config": a.config, "e_step_ms": round(best, 5), "GBps": round(b / 1e9 / (best / 1e3), 1),
+                      "frac": round(b / 1e9 / (best / 1e3) / bench.HBM_PEAK_GBS, 4),
+                      "env": {k: v for k, v in os.environ.items() if k.startswith("PLSA_")}}))
+    sys.exit(0)
 eng.fit(None, n_iter=10, n_iter_per_test=10, tolerance=0.0, flags=flags)
 best = None
 for _ in range(a.reps):
