@@ -48,6 +48,13 @@ for cfg, src in ((3, "bench_default.json"), (1, "bench_cfg1.json"), (2, "bench_c
     f = os.path.join(G, src)
     if os.path.exists(f):
         json.dump(last_json(f), open(os.path.join(P, "%s_bench_cfg%d_1gpu.json" % (tag, cfg)), "w"), indent=1)
+for src, dst in (("bench_cfg2_world2_files.json", "%s_bench_cfg2_world2_on_one_gpu_files_test_mode.json"),):
+    f = os.path.join(G, src)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        json.dump(last_json(f), open(os.path.join(P, dst % tag), "w"), indent=1)
+f = os.path.join(G, "bench_cfg2_world2_rccl_on_one_gpu.txt")
+if os.path.exists(f):
+    shutil.copy(f, os.path.join(P, "%s_bench_world2_rccl_refused_on_one_gpu.txt" % tag))
 f = os.path.join(G, "prof", "bench_under_rocprof.json")
 if os.path.exists(f):
     json.dump(last_json(f), open(os.path.join(P, "%s_bench_cfg3_under_rocprofv3.json" % tag), "w"), indent=1)

@@ -6,7 +6,11 @@ mkdir -p $R/gpurun_out/prof
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/pytest_gpu.log; tail -2 gpurun_out/pytest_gpu.log
 timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 300 gpurun_out/bench_default.err
-for c in 2 1 5; do timeout 900 python bench.py --config $c --no-cpu-baseline > gpurun_out/bench_cfg$c.json 2> gpurun_out/bench_cfg$c.err; done
+for c in 2 1 5; do timeout 900 python bench.py --config $c --no-cpu-baseline --no-pmc > gpurun_out/bench_cfg$c.json 2> gpurun_out/bench_cfg$c.err; done
+# the N = 2 launch path on this single-GPU box: bench.py spawns its own ranks; RCCL refuses two ranks on one
+# device, so this is the host-file TEST MODE (labelled as such in the JSON) -- and the RCCL attempt must fail
+timeout 600 python bench.py --gpus 2 --config 2 --steps 20 --no-cpu-baseline --exchange files > gpurun_out/bench_cfg2_world2_files.json 2> gpurun_out/bench_cfg2_world2_files.err
+timeout 600 python bench.py --gpus 2 --config 2 --steps 20 --no-cpu-baseline > gpurun_out/bench_cfg2_world2_rccl_on_one_gpu.out 2> gpurun_out/bench_cfg2_world2_rccl_on_one_gpu.err; echo "rccl world-2 on one GPU: rc $? (expected non-zero), stdout bytes $(wc -c < gpurun_out/bench_cfg2_world2_rccl_on_one_gpu.out)" | tee gpurun_out/bench_cfg2_world2_rccl_on_one_gpu.txt
 python - <<'PY' > gpurun_out/stream_probe.txt
 from enstop_amd.engine import Engine
 e = Engine(0)
@@ -16,9 +20,9 @@ for kind, name in ((0, "fill nt"), (1, "fill plain"), (2, "copy")):
 PY
 cat gpurun_out/stream_probe.txt
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o bench -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof/bench_under_rocprof.json 2> $R/gpurun_out/prof/rocprof_stats.err
-timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof/pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof/rocprof_fetch.err
-timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof/pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof/rocprof_write.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o bench -- python $R/bench.py --no-cpu-baseline --no-pmc > $R/gpurun_out/prof/bench_under_rocprof.json 2> $R/gpurun_out/prof/rocprof_stats.err
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof/pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc > /dev/null 2> $R/gpurun_out/prof/rocprof_fetch.err
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof/pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc > /dev/null 2> $R/gpurun_out/prof/rocprof_write.err
 cd $R
 for f in $(find /tmp/prof/stats -name "*kernel_stats.csv"); do cp $f gpurun_out/prof/bench_kernel_stats.csv; done
 python - <<'PY'
