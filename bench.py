@@ -362,7 +362,7 @@ def main():
         if world == 1:
             return None
         if isinstance(comm, plsa_comm.RcclComm):
-            return eng.comm_allgather_components(want_host=(rank == 0))
+            return eng.comm_allgather_components(want_host=(rank == 0), pinned=True)
         return comm.allgather_components(eng)
 
     # ---- warmup (untimed): W EM iterations + the collective --------------------------------------

@@ -273,10 +273,15 @@ class Engine:
     def comm_barrier(self):
         self._ok(self._L.plsa_comm_barrier(self._h))
 
-    def comm_allgather_components(self, want_host=True):
-        """[world, k, m] float32: every rank's current P(w|z) (one ncclAllGather on the engine's stream)."""
+    def comm_allgather_components(self, want_host=True, pinned=False):
+        """[world, k, m] float32: every rank's current P(w|z) (one ncclAllGather on the engine's stream).
+        pinned=True: a VIEW of a page-locked buffer owned by the engine, overwritten by the next call."""
         _, world = self.comm_info()
         _, m, _ = self.shape
+        if want_host and pinned:
+            p = C.POINTER(C.c_float)()
+            self._ok(self._L.plsa_comm_allgather_components_pinned(self._h, C.byref(p)))
+            return np.ctypeslib.as_array(p, shape=(world, self.k, m))
         out = np.empty((world, self.k, m), np.float32) if want_host else None
         self._ok(self._L.plsa_comm_allgather_components(self._h, ptr(out)))
         return out

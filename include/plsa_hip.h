@@ -168,6 +168,8 @@ int plsa_comm_destroy(plsa_ctx *ctx);
 int plsa_comm_info(plsa_ctx *ctx, int32_t *rank, int32_t *world);
 int plsa_comm_barrier(plsa_ctx *ctx);
 int plsa_comm_allgather_components(plsa_ctx *ctx, float *out_host /* [world, k, m] or NULL */);
+/* same, into a page-locked buffer owned by the context (*host valid until the next call on ctx) */
+int plsa_comm_allgather_components_pinned(plsa_ctx *ctx, float **host);
 int plsa_comm_allgather_host(plsa_ctx *ctx, const void *send, int64_t bytes, void *recv /* world * bytes */);
 int plsa_comm_allreduce_f64(plsa_ctx *ctx, double *inout, int64_t count, int32_t op);
 int plsa_comm_broadcast_host(plsa_ctx *ctx, void *buf, int64_t bytes, int32_t root);

@@ -46,6 +46,29 @@ int main(void) {
     double worst = 0;
     for (int64_t d = 0; d < n; d++) { double t = 0; for (int z = 0; z < k; z++) t += U[d * k + z]; if (indptr[d + 1] > indptr[d] && fabs(t - 1) > worst) worst = fabs(t - 1); }
     for (int z = 0; z < k; z++) { double t = 0; for (int64_t w = 0; w < m; w++) t += V[z * m + w]; if (fabs(t - 1) > worst) worst = fabs(t - 1); }
+    /* the multi-GPU exchange from plain C: a one-rank RCCL communicator (rank 0 makes the id, every rank
+     * joins), all-gather of the topics, the doc-sharded loop with its in-stream all-reduce */
+    unsigned char id[PLSA_COMM_ID_BYTES];
+    int32_t rank = -1, world = -1;
+    CHECK(plsa_comm_unique_id(id));
+    CHECK(plsa_comm_init(ctx, id, 0, 1));
+    CHECK(plsa_comm_info(ctx, &rank, &world));
+    float *stack = malloc(sizeof(float) * k * m), *pinned = NULL;
+    CHECK(plsa_comm_allgather_components(ctx, stack));
+    CHECK(plsa_comm_allgather_components_pinned(ctx, &pinned));
+    double gather_err = 0;
+    for (int64_t i = 0; i < (int64_t)k * m; i++) { if (fabs(stack[i] - V[i]) > gather_err) gather_err = fabs(stack[i] - V[i]);
+                                                   if (fabs(pinned[i] - V[i]) > gather_err) gather_err = fabs(pinned[i] - V[i]); }
+    int32_t iters2 = 0;
+    CHECK(plsa_fit(ctx, NULL, 3, 5, 0.0, 1e-32f, PLSA_FUSED | PLSA_SHARDED, &iters2, NULL, NULL));
+    double red[2] = {1.5, -2.0};
+    CHECK(plsa_comm_allreduce_f64(ctx, red, 2, 0));
+    CHECK(plsa_comm_barrier(ctx));
+    CHECK(plsa_comm_destroy(ctx));
+    if (rank != 0 || world != 1 || gather_err != 0.0 || iters2 != 3 || red[0] != 1.5) {
+        fprintf(stderr, "comm: rank=%d world=%d gather_err=%g iters2=%d\n", rank, world, gather_err, iters2);
+        return 4;
+    }
     plsa_destroy(ctx);
     if (iters != 20 || n_ll != 5 || !(ll1 > ll0) || worst > 1e-4 || fabs(trace[0] - (float)ll0) > 1e-3 * fabs(ll0)) {
         fprintf(stderr, "unexpected: iters=%d n_ll=%d ll0=%g ll1=%g worst=%g\n", iters, n_ll, ll0, ll1, worst);

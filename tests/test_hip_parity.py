@@ -653,6 +653,7 @@ def test_native_rccl_communicator_single_rank(amd):
         kw = dict(n_iter=8, n_iter_per_test=3, tolerance=0.0, random_state=1)
         U1, V1, i1 = amd.plsa_fit(X, 32, sw, return_info=True, **kw)
         np.testing.assert_array_equal(c.allgather_components(eng)[0], V1)
+        np.testing.assert_array_equal(eng.comm_allgather_components(pinned=True)[0], V1)
         U2, V2, i2 = amd.sharded_plsa_fit(X, 32, sw, return_info=True, **kw)      # native PLSA_SHARDED loop
         assert i1["n_iter"] == i2["n_iter"]
         # (the sharded loop normalises from the all-reduced accumulator, the plain loop from the column

@@ -4,7 +4,7 @@
 R=$PWD
 mkdir -p $R/gpurun_out/prof
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/pytest_gpu.log; tail -2 gpurun_out/pytest_gpu.log
+timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -3
 timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 300 gpurun_out/bench_default.err
 for c in 2 1 5; do timeout 900 python bench.py --config $c --no-cpu-baseline --no-pmc > gpurun_out/bench_cfg$c.json 2> gpurun_out/bench_cfg$c.err; done
 # the N = 2 launch path on this single-GPU box: bench.py spawns its own ranks; RCCL refuses two ranks on one
