@@ -470,11 +470,13 @@ class GPUPLSA(BlockParallelPLSA):
 class DistributedPLSA(BlockParallelPLSA):
     """Drop-in name for enstop.distributed_plsa.DistributedPLSA (distributed_plsa.py:374-460).  The
     reference takes a dask array and sums per-tile partial factors with a dask graph
-    (distributed_plsa.py:99-131).  Here the distribution unit is the GPU: when torch.distributed is
-    initialised with more than one rank (one process per GPU), every rank passes the same X and the
-    documents are sharded over the ranks -- one all-reduce of the P(w|z) accumulator per EM iteration
-    (`sharded_plsa_fit`) -- and every rank receives the full result; in a single
-    process it is `PLSA`.  Dask arrays are materialised with `.compute()` first."""
+    (distributed_plsa.py:99-131).  Here the distribution unit is the GPU: with a communicator of more than
+    one rank in force (`enstop_amd.distributed.init()`: RCCL through the C ABI, one process per GPU; or a
+    caller's torch.distributed group), every rank passes the same X and the documents are sharded over the
+    ranks -- one all-reduce of the P(w|z) accumulator per EM iteration (`sharded_plsa_fit`, DESIGN.md section
+    6) -- and every rank receives the full result; in a single process it is `BlockParallelPLSA`.  Like the
+    reference's loop (distributed_plsa.py:277-278, 450) it never sees sample weights and its stop test has
+    no `change == 0` arm.  Dask arrays are materialised with `.compute()` first."""
 
     def fit_transform(self, X, y=None, sample_weight=None):
         if hasattr(X, "compute") and not issparse(X):
@@ -487,6 +489,6 @@ class DistributedPLSA(BlockParallelPLSA):
         if world <= 1:
             return super()._fit_factors(X, sample_weight)
         from .sharded import sharded_plsa_fit
-        return sharded_plsa_fit(X, self.n_components, sample_weight, self.init, self.n_iter,
+        return sharded_plsa_fit(X, self.n_components, None, self.init, self.n_iter,
                                 self.n_iter_per_test, self.tolerance, self.e_step_thresh, self.random_state,
-                                device=self.device, return_info=True)
+                                device=self.device, return_info=True, zero_arm=False)
