@@ -479,8 +479,10 @@ def test_device_random_init(amd):
         assert abs(U0.mean() - 1 / 20) < 1e-3 and U0.std() > 0.01
 
 
-def test_ensemble_topics_end_to_end(amd):
-    """EnsembleTopics on planted topics: GPU ensemble members -> host clustering -> GPU refit."""
+@pytest.mark.parametrize("combination", ["hellinger", "kl_divergence"])
+def test_ensemble_topics_end_to_end(amd, combination):
+    """EnsembleTopics on planted topics: GPU ensemble members -> divergence matrix and cluster
+    representatives on the GPU, tree step on the host -> GPU refit."""
     rs = np.random.RandomState(0)
     n, m, k_true = 600, 300, 4
     topics = rs.dirichlet(np.full(m, 0.03), size=k_true)
@@ -488,7 +490,7 @@ def test_ensemble_topics_end_to_end(amd):
     X = sp.csr_matrix(rs.poisson(80 * (mix @ topics)).astype(np.float32))
     X = X[np.asarray(X.sum(1)).ravel() > 0]
     model = amd.EnsembleTopics(n_components=k_true, n_starts=8, min_samples=2, min_cluster_size=3,
-                               topic_combination="hellinger", parallelism="none", n_iter=40,
+                               topic_combination=combination, parallelism="none", n_iter=40,
                                random_state=np.random.RandomState(3))
     emb = model.fit_transform(X)
     assert model.components_.shape[1] == m and model.n_components_ == model.components_.shape[0] >= 2
