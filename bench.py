@@ -252,7 +252,7 @@ def measure_traffic(args):
                    "--seed", str(args.seed)]
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                           timeout=float(os.environ.get("PLSA_BENCH_PMC_TIMEOUT", "420")), check=True)
+                           timeout=float(os.environ.get("PLSA_BENCH_PMC_TIMEOUT", "150")), check=True)
             agg = {}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
