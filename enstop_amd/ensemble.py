@@ -19,7 +19,7 @@ matrix follows umap.distances.hellinger's published definition (umap-learn >= 0.
 against that definition, not against a reference run.
 """
 import numpy as np
-from scipy.sparse import coo_matrix, csr_matrix, issparse
+from scipy.sparse import csr_matrix, issparse
 from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_array, check_random_state
 

@@ -19,11 +19,11 @@ anywhere, calling anything needs libplsa_hip.so and a gfx950 device.
 import os
 
 import numpy as np
-from scipy.sparse import coo_matrix, csr_matrix, issparse
+from scipy.sparse import csr_matrix, issparse
 from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_array, check_random_state
 
-from .engine import Engine, PLSA_SW_LL_ONLY, PLSA_STOP_NO_ZERO_ARM, default_flags, get_engine
+from .engine import PLSA_SW_LL_ONLY, PLSA_STOP_NO_ZERO_ARM, default_flags, get_engine
 from .utils import (_check_sample_weight, coherence, log_lift, mean_coherence, mean_log_lift, normalize,
                     standardize_input)
 

@@ -123,7 +123,7 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
     document pass, the log-likelihood is one scalar all-reduce per test, nothing synchronises with the
     host between tests.  Other communicators use the accumulate / all-reduce / finish split."""
     from . import comm as _comm
-    from .engine import PLSA_FUSED, PLSA_SHARDED, PLSA_STOP_NO_ZERO_ARM, get_engine
+    from .engine import PLSA_FUSED, PLSA_SHARDED, PLSA_STOP_NO_ZERO_ARM
     X = X.tocsr()
     n, m = X.shape
     rng = check_random_state(random_state)
