@@ -137,8 +137,19 @@ def test_row_ranges_by_nnz():
         r = row_ranges_by_nnz(indptr, parts)
         assert len(r) == parts and r[0][0] == 0 and r[-1][1] == 6
         assert all(r[i][1] == r[i + 1][0] for i in range(parts - 1)) and all(a <= b for a, b in r)
+        if parts <= 6:
+            assert all(a < b for a, b in r)
     r = row_ranges_by_nnz(indptr, 2)
     assert abs((indptr[r[0][1]] - indptr[r[0][0]]) - 50) <= 45
+    # every shard gets at least one row whenever there are enough rows (a rank without rows would leave
+    # its peers waiting in the all-reduce): one row holding nearly all non-zeros, more parts than "mass"
+    skew = np.array([0, 1, 2, 1000, 1001, 1002, 1003], np.int32)
+    for parts in (2, 3, 4, 6):
+        r = row_ranges_by_nnz(skew, parts)
+        assert all(b > a for a, b in r) and r[0][0] == 0 and r[-1][1] == 6, r
+    # fewer rows than parts: some range is necessarily empty (sharded_plsa_fit raises before any exchange)
+    r = row_ranges_by_nnz(np.array([0, 5, 9], np.int32), 4)
+    assert len(r) == 4 and any(b <= a for a, b in r)
 
 
 def test_topic_metrics_match_reference():

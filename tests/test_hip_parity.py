@@ -619,6 +619,16 @@ def test_sharded_fit_matches_reference_golden(amd, shards):
         close_factors(U, g["U"]); close_factors(V, g["V"])
 
 
+def test_sharded_fit_with_more_shards_than_documents_raises(amd):
+    """No rank may end up without rows (it would leave the others waiting in the all-reduce): the same
+    ValueError on every rank, before any exchange."""
+    X = sp.csr_matrix(np.array([[1, 0, 2], [0, 3, 0]], np.float32))
+    with pytest.raises(ValueError):
+        amd.sharded_plsa_fit(X, 2, None, n_iter=2, random_state=0, local_shards=3)
+    U, V = amd.sharded_plsa_fit(X, 2, None, n_iter=2, random_state=0, local_shards=2)
+    assert U.shape == (2, 2) and V.shape == (2, 3)
+
+
 def test_sharded_fit_matches_single_gpu_fit_midsize(amd):
     X = _corpus(5000, 3000, 0.02, seed=21, empty_rows=4)
     sw = np.ones(5000, np.float32)
