@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the wall time of the estimator-level calls goes (host preparation vs device work):
-PLSA.fit / transform and plsa_fit on host scipy matrices of config 2 and config 3 size."""
+PLSA.fit / transform and plsa_fit on host scipy matrices of config 1, 2 and 3 size."""
 import cProfile
 import io
 import os
@@ -16,7 +16,8 @@ from enstop_amd.engine import Engine                           # noqa: E402
 
 
 def main():
-    for name, (n, m, nnz_t, k) in {"cfg2": (100_000, 50_000, 10_000_000, 32), "cfg3": (1_000_000, 100_000, 100_000_000, 64)}.items():
+    for name, (n, m, nnz_t, k) in {"cfg1": (18_846, 173_762, 2_950_000, 20), "cfg2": (100_000, 50_000, 10_000_000, 32),
+                                   "cfg3": (1_000_000, 100_000, 100_000_000, 64)}.items():
         with Engine(0) as eng:
             eng.generate_synthetic(n, m, nnz_t, seed=0)
             X = eng.download_active_csr()
