@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """EM iterations/s of one BASELINE config WITHOUT per-kernel events (they cost ~13 % at 0.2 ms per iteration):
     python tools/iter_rate.py --config 1 [--steps 200] [--flags fused|materialised] [--events]
-Knobs are read from the environment by the engine (PLSA_COOP, PLSA_COL_SEG, ...)."""
+Knobs are read from the environment by the engine (PLSA_E_SEG, PLSA_COL_SEG, ...)."""
 import argparse
 import json
 import os
