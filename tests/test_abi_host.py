@@ -28,6 +28,18 @@ def test_header_symbols_exported_and_bound():
     assert sorted(_lib.SIGNATURES) == declared
 
 
+def test_every_entry_point_is_documented_with_the_interface_it_replaces():
+    """INTEGRATION.md names every symbol of include/plsa_hip.h (next to the reference interface it stands for,
+    or as plumbing / measurement without a counterpart); the library links RCCL directly."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [s for s in _declared_symbols() if s not in doc and s.replace("plsa_timing_", "_") not in doc]
+    assert not missing, missing
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", os.path.join(ROOT, "enstop_amd", "libplsa_hip.so")],
+                            capture_output=True, text=True).stdout
+    assert "librccl.so" in needed and "libamdhip64.so" in needed
+
+
 def test_library_has_gfx950_code_object():
     data = open(os.path.join(ROOT, "enstop_amd", "libplsa_hip.so"), "rb").read()
     assert b"gfx950" in data and b"k_e_step" in data and b"k_row_pass" in data
