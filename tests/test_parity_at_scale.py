@@ -5,7 +5,8 @@
   config 4  ensemble_of_topics(n_runs = 32) on the config-1 corpus            stack == serial members (bitwise),
                                                                               one member against the oracle
   config 5  5 M x 200 k, 500 M nnz, k = 128                                   size-independent properties
-  (config 3 is covered by test_hip_parity.py::test_full_size_properties and by bench.py)
+  config 3  its shape on the first 150 000 documents (15 M nnz, k = 64)              fit, both schedules, 2 iterations
+            (the full corpus: test_hip_parity.py::test_full_size_properties and bench.py)
 
 The corpora are produced by the engine's deterministic generator (plsa_generate_synthetic) and
 downloaded for the oracle.  Every comparison is made against three builds of the one oracle source:
@@ -188,6 +189,47 @@ def test_config1_fit_vs_oracle(amd, oracles):
 
 def test_config2_fit_vs_oracle(amd, oracles):
     _fit_case(amd, oracles, CONFIG2, "config2", n_iter=3, n_iter_per_test=1)
+
+
+def test_config3_shape_row_sample_vs_oracle(amd, oracles):
+    """Config 3's shape (100 k vocabulary, k = 64, ~100 entries per document) on the first 150 000 documents of
+    the config-3 corpus (15 M nnz: what the serial M-step of the oracle finishes in seconds); the full
+    corpus is covered by test_full_size_properties and bench.py."""
+    with amd.Engine() as eng:
+        eng.generate_synthetic(1_000_000, 100_000, 100_000_000, seed=0)
+        eng.bootstrap(np.arange(150_000, dtype=np.int64))
+        X = eng.download_active_csr()
+    n, m = X.shape
+    k = 64
+    r, c, v = coo_arrays(X)
+    U0, V0 = host_init(n, m, k, 42)
+    ones = np.ones(n, np.float32)
+    rec = REPORT.setdefault("config3_first_150k_docs", {"shape": [n, m], "nnz": int(X.nnz), "k": k, "n_iter": 2})
+    ref = {}
+    for variant in ("strict", "wide"):
+        U, V = U0.copy(), V0.copy()
+        _, _, trace, iters = oracles[variant].plsa_fit_inner(r, c, v, V, U, ones, n_iter=2, n_iter_per_test=1,
+                                                             tolerance=0.0, e_step_thresh=1e-32, return_trace=True)
+        ref[variant] = (U, V, trace)
+    rec["strict_vs_wide"] = {"U": errs(ref["strict"][0], ref["wide"][0]), "V": errs(ref["strict"][1], ref["wide"][1]),
+                             "ll_rel": ll_rel(ref["strict"][2], ref["wide"][2])}
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
+            eng.set_factors(U0, V0)
+            iters, trace = eng.fit(None, n_iter=2, n_iter_per_test=1, tolerance=0.0, e_step_thresh=1e-32, flags=flags,
+                                   trace=True)
+            U, V = eng.get_factors()
+            out = rec.setdefault(sched, {})
+            for variant in ("strict", "wide"):
+                out["vs_" + variant] = {"U": errs(U, ref[variant][0]), "V": errs(V, ref[variant][1]),
+                                        "ll_rel": ll_rel(trace, ref[variant][2])}
+            _flush_report()
+            e = out["vs_wide"]
+            assert e["U"]["peak_rel"] <= 1e-4 and e["V"]["peak_rel"] <= 1e-4 and e["ll_rel"] <= 1e-5, (sched, e)
+            s_, w_ = out["vs_strict"], rec["strict_vs_wide"]
+            for f in ("U", "V"):
+                assert s_[f]["peak_rel"] <= 1.5 * w_[f]["peak_rel"] + 2e-5, (sched, f, s_[f], w_[f])
 
 
 def test_config4_ensemble_on_20ng_shaped_corpus(amd, oracles):
