@@ -114,6 +114,16 @@ struct plsa_ctx {
     double *h_ll = nullptr;  // pinned
 
     DevBuf item_end, colsum_rows, colsum_rows2;
+    // column-pass schedule: visiting-order item records, chunk boundaries per XCD (measured, see ensure_balance)
+    DevBuf item_rec, xcd_lo, t_end;
+    int balance = -1;                // PLSA_BALANCE: -1 auto (large problems), 0 equal stretches, 1 always measure
+    bool bal_valid = false;          // xcd_lo matches the current structure
+    bool bal_have_frac = false;      // bal_frac holds measured boundaries (kept across bootstrap resamples as the start)
+    double bal_frac[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int bal_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    i64 bal_chunks = -1;
+    int bal_launches = 0;            // timed tuning launches spent on the current structure
+    double bal_end_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per-XCD finish times of the last timed launch
     int small_grid = 0;              // PLSA_SMALL_GRID: workgroups per CU of the column pass on small corpora (0 = no cap)
     int colsum_rows_used = 0;        // rows of colsum_rows written by the last column pass
 
@@ -520,6 +530,15 @@ int ensure_csc(plsa_ctx *c) {
         HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, bytes, d_key, d_key + ni,
                                                      c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, dbits, c->stream));
     }
+    // visiting-order records (one 16-byte load per item instead of an index chain)
+    CHK(ensure(c, c->item_rec, sizeof(int4) * ni));
+    if (n_items > 0) {
+        hipLaunchKernelGGL(plsa::k_item_records, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, c->stream,
+                           c->use_item_order ? c->item_order.as<int>() : nullptr, c->item_col.as<int>(),
+                           c->item_start.as<int>(), c->item_end.as<int>(), (i64)n_items, c->item_rec.as<int4>());
+        CHK(launch_check(c, "k_item_records"));
+    }
+    c->bal_valid = false;
     // columns whose item count makes a single group's serial reduction a tail (Zipf head words)
     CHK(ensure(c, c->heavy_cols, sizeof(int) * (size_t)(m + 1)));
     HIPCHK(c, hipMemsetAsync(c->heavy_cols.as<int>() + m, 0, sizeof(int), c->stream));
@@ -676,7 +695,73 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, floa
     return 0;
 }
 
-// vocabulary-owned pass (no atomics): partial k-vectors per column item (+ per-block sums of them, from
+// chunk boundaries of the column pass from the current fractions
+void balance_set_lo(plsa_ctx *c, int n_chunks) {
+    c->bal_lo[0] = 0;
+    for (int x = 1; x < 8; ++x) {
+        int v = (int)(c->bal_frac[x] * n_chunks + 0.5);
+        c->bal_lo[x] = std::min(n_chunks, std::max(c->bal_lo[x - 1], v));
+    }
+    c->bal_lo[8] = n_chunks;
+    c->bal_chunks = n_chunks;
+}
+
+// Measured XCD boundaries of the column pass (see k_col_pass).  `launch(timed)` enqueues one column pass on c->ls.
+// Equal stretches first (or the fractions measured for the previous structure on this context: a bootstrap
+// resample of the same corpus has the same profile and needs at most one refinement), then up to four timed
+// launches: every workgroup records its end time, an XCD's time is its last workgroup's, and every stretch is
+// resized by (mean time / own time), damped -- until the eight finish within 2 % of each other.  Results never
+// depend on the boundaries (partials are per item, norm_pwz rows per chunk), only the speed does.
+template <class Launch>
+int ensure_balance(plsa_ctx *c, int grid, int n_chunks, bool split, Launch &&launch) {
+    if (c->bal_valid && c->bal_chunks == n_chunks) return 0;
+    CHK(ensure(c, c->xcd_lo, sizeof(int) * 16));
+    const bool warm = c->bal_have_frac;
+    if (!warm) for (int x = 0; x <= 8; ++x) c->bal_frac[x] = x / 8.0;
+    balance_set_lo(c, n_chunks);
+    HIPCHK(c, hipMemcpyAsync(c->xcd_lo.p, c->bal_lo, sizeof(int) * 9, hipMemcpyHostToDevice, c->ls));
+    c->bal_launches = 0;
+    const bool tune = split && n_chunks >= 64 &&
+                      (c->balance > 0 || (c->balance < 0 && (double)c->nnz * c->kp >= c->overlap_full_limit));
+    if (tune) {
+        CHK(ensure(c, c->t_end, sizeof(unsigned long long) * ((size_t)grid + 1)));
+        std::vector<unsigned long long> te((size_t)grid + 1);
+        const int max_launches = warm ? 2 : 5;
+        for (int it = 0; it < max_launches; ++it) {
+            HIPCHK(c, hipMemsetAsync(c->t_end.p, 0, sizeof(unsigned long long) * ((size_t)grid + 1), c->ls));
+            CHK(launch(true));
+            HIPCHK(c, hipMemcpyAsync(te.data(), c->t_end.p, sizeof(unsigned long long) * ((size_t)grid + 1),
+                                     hipMemcpyDeviceToHost, c->ls));
+            HIPCHK(c, hipStreamSynchronize(c->ls));
+            c->bal_launches++;
+            unsigned long long t0 = ~0ull, last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int b = 0; b <= grid; ++b) if (te[b]) t0 = std::min(t0, te[b]);
+            for (int b = 0; b < grid; ++b) last[b & 7] = std::max(last[b & 7], te[b]);
+            double T[8], mean = 0.0, lo_t = 1e300, hi_t = 0.0;
+            for (int x = 0; x < 8; ++x) {
+                T[x] = std::max(1.0, (double)(last[x] - t0) / 100.0);       // us (100 MHz wall clock)
+                c->bal_end_us[x] = T[x];
+                mean += T[x] / 8.0; lo_t = std::min(lo_t, T[x]); hi_t = std::max(hi_t, T[x]);
+            }
+            if ((hi_t - lo_t) <= 0.02 * mean || it == max_launches - 1) break;
+            double size[8], tot = 0.0;
+            for (int x = 0; x < 8; ++x) {
+                size[x] = std::max(1e-6, (c->bal_frac[x + 1] - c->bal_frac[x]) * (1.0 + 0.8 * (mean / T[x] - 1.0)));
+                tot += size[x];
+            }
+            double acc = 0.0;
+            for (int x = 0; x < 8; ++x) { acc += size[x]; c->bal_frac[x + 1] = acc / tot; }
+            c->bal_frac[8] = 1.0;
+            balance_set_lo(c, n_chunks);
+            HIPCHK(c, hipMemcpyAsync(c->xcd_lo.p, c->bal_lo, sizeof(int) * 9, hipMemcpyHostToDevice, c->ls));
+        }
+        c->bal_have_frac = true;
+    }
+    c->bal_valid = true;
+    return 0;
+}
+
+// vocabulary-owned pass (no atomics): partial k-vectors per column item (+ per-chunk sums of them, from
 // which the column tail gets norm_pwz), then per-column sums -> Vacc
 // parts: 1 = the column pass itself, 2 = the un-normalised per-column sums of its partials (k_col_reduce),
 //        3 = both
@@ -688,38 +773,44 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int 
         using Sh = decltype(S);
         constexpr int LPN = Sh::LPN, GPB = 256 / LPN;
         const i64 n_visit = c->n_items;
+        const int n_chunks = (int)((n_visit + GPB - 1) / GPB);
         int grid = grid_for(c, n_visit, GPB);
-        // small corpora: one resident wave of workgroups (5 per CU at ~94 VGPRs), so that norm_pwz comes out
-        // of their ~1280 sum rows in one short single-workgroup launch (4096 rows took 22-29 us, traced)
+        // small corpora: one resident wave of workgroups (5 per CU at ~94 VGPRs)
         // (only when the items would fill the chip a few times at most: with more items the dynamic balance
         // of a large grid wins -- config 2's pass went 183 -> 218 us under the cap)
         if (c->small_grid > 0 && (double)c->nnz * c->kp < c->overlap_full_limit && grid <= 32 * c->prop.multiProcessorCount)
             grid = std::min(grid, c->small_grid * c->prop.multiProcessorCount);
         const int grid2 = grid_for(c, c->m, GPB);
-        const int *order = c->use_item_order ? c->item_order.as<int>() : nullptr;
         const int xcd_split = (c->xcd_split && grid >= 64) ? 1 : 0;
         if (parts & 1) {
-            rc = ensure(c, c->colsum_rows, sizeof(double) * (size_t)grid * c->kp);
+            rc = ensure(c, c->colsum_rows, sizeof(double) * (size_t)std::max(n_chunks, 1) * c->kp);
             if (rc) return;
             const size_t smem = sizeof(double) * (size_t)GPB * c->kp;
-            if (from_p) {
-                Scope s(c, "k_col_pass<P>");
-                hipLaunchKernelGGL((plsa::k_col_pass<Sh, true>), dim3(grid), dim3(256), smem, c->ls, order,
-                                   c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(),
-                                   n_visit, c->csc_row.as<int>(), c->csc_val.as<float>(),
-                                   c->csc_pos.as<int>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
-                                   p_base(c), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split,
-                                   c->colsum_rows.as<double>());
-            } else {
-                Scope s(c, "k_col_pass<fused>");
-                hipLaunchKernelGGL((plsa::k_col_pass<Sh, false>), dim3(grid), dim3(256), smem, c->ls, order,
-                                   c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(),
-                                   n_visit, c->csc_row.as<int>(), c->csc_val.as<float>(),
-                                   c->csc_pos.as<int>(), c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
-                                   p_base(c), d_sw, c->partial.as<float>(), c->kp, thresh, xcd_split,
-                                   c->colsum_rows.as<double>());
-            }
-            c->colsum_rows_used = grid;
+            auto launch = [&](bool timed) -> int {
+                Scope s(c, from_p ? "k_col_pass<P>" : "k_col_pass<fused>");
+                const int4 *rec = c->item_rec.as<int4>();
+                const int *lo = c->xcd_lo.as<int>(), *cr = c->csc_row.as<int>(), *cp = c->csc_pos.as<int>();
+                const float *cvl = c->csc_val.as<float>(), *U = c->U[c->cu].as<float>(), *Vt = c->Vt[c->cv].as<float>();
+                float *part = c->partial.as<float>();
+                double *sums = c->colsum_rows.as<double>();
+                unsigned long long *te = c->t_end.as<unsigned long long>();
+                const int kp = c->kp;
+                auto go = [&](auto FP, auto TM) {
+                    hipLaunchKernelGGL((plsa::k_col_pass<Sh, decltype(FP)::value, decltype(TM)::value>), dim3(grid), dim3(256),
+                                       smem, c->ls, rec, n_visit, lo, cr, cvl, cp, U, Vt, p_base(c), d_sw, part, kp, thresh,
+                                       xcd_split, sums, te);
+                };
+                using T = std::true_type;
+                using F = std::false_type;
+                if (from_p) { if (timed) go(T{}, T{}); else go(T{}, F{}); }
+                else { if (timed) go(F{}, T{}); else go(F{}, F{}); }
+                return launch_check(c, "k_col_pass");
+            };
+            rc = ensure_balance(c, grid, n_chunks, xcd_split != 0, launch);
+            if (rc) return;
+            rc = launch(false);
+            if (rc) return;
+            c->colsum_rows_used = n_chunks;
         }
         if (parts & 2) {
             // heavy columns (one block each) and the rest share one launch
@@ -782,8 +873,8 @@ int run_col_tail(plsa_ctx *c) {
     CHK(ensure(c, c->norm_pwz, sizeof(float) * (size_t)c->kp));
     const double *rows_in = c->colsum_rows.as<double>();
     int n_rows = rows;
-    if (rows > 2048) {               // many workgroups (large corpora): two stages, 64 workgroups first
-        const int nb = 64;
+    if (rows > 2048) {               // many chunks (large corpora): two stages
+        const int nb = rows > 65536 ? 256 : 64;
         CHK(ensure(c, c->colsum_rows2, sizeof(double) * (size_t)nb * c->kp));
         Scope s(c, "k_norm_reduce");
         hipLaunchKernelGGL(plsa::k_norm_reduce, dim3(nb), dim3(256), 0, c->ls, rows_in, rows, c->kp,
@@ -919,6 +1010,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_SORT_ROWS")) c->sort_rows = atoi(s) != 0;
     if (const char *s = getenv("PLSA_ITEM_ORDER")) c->use_item_order = atoi(s) != 0;
     if (const char *s = getenv("PLSA_XCD_SPLIT")) c->xcd_split = atoi(s) != 0;
+    if (const char *s = getenv("PLSA_BALANCE")) c->balance = atoi(s);
     if (const char *s = getenv("PLSA_CHUNKS_PER_LANE")) c->chunks_per_lane = atoi(s);
     if (const char *s = getenv("PLSA_E_ROWS")) c->e_rows = atoi(s);
     if (const char *s = getenv("PLSA_E_SEG")) c->eseg_override = atoi(s);
@@ -937,6 +1029,7 @@ void plsa_destroy(plsa_ctx *c) {
     release(c->comm_send); release(c->comm_recv); release(c->comm_small);
     if (c->comm_host) { (void)hipHostFree(c->comm_host); c->comm_host = nullptr; c->comm_host_cap = 0; }
     release(c->item_end); release(c->colsum_rows); release(c->colsum_rows2);
+    release(c->item_rec); release(c->xcd_lo); release(c->t_end);
     DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,

@@ -541,11 +541,20 @@ __device__ __forceinline__ void col_batch(int s0, int d_l, float x_l, int p_l, i
     }
 }
 
-template <class S, bool FROM_P>
-__global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int *__restrict__ item_order,
-                                                  const int *__restrict__ item_col,
-                                                  const int *__restrict__ item_start,
-                                                  const int *__restrict__ item_end, i64 n_items,
+// Schedule of the column pass.  The items are visited in ascending-first-document order (`item_rec`, one
+// {column, start, end, partial slot} record per visiting position) in CHUNKS of GPB = 256 / LPN consecutive items:
+// one chunk = one trip of a workgroup, one item per group.  Workgroup b runs on XCD b % 8 (observed dispatch rule; a
+// different placement only costs speed) and XCD x walks the chunks [xcd_lo[x], xcd_lo[x+1]) -- a contiguous stretch
+// of the list, so that all workgroups sharing an L2 gather from the same band of U rows.  The boundaries are
+// MEASURED (plsa_hip.hip::ensure_balance: the TIMED instantiation records every workgroup's end time and the
+// stretches are resized until the eight XCDs finish together): equal stretches left the XCD holding the
+// rare-word items -- they sort to the front of the list and all their gathers miss -- 35 % behind the fastest one
+// (round 3: 2.35 -> 2.06 ms at config 3 with 256-entry items, 1.93 ms with 128).
+// Per chunk the workgroup also writes the float64 sum of its GPB accumulators (`chunk_sums`, the rows norm_pwz is
+// added up from, in chunk order): every result is independent of the boundaries and of the grid.
+template <class S, bool FROM_P, bool TIMED>
+__global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int4 *__restrict__ item_rec, i64 n_items,
+                                                  const int *__restrict__ xcd_lo,
                                                   const int *__restrict__ csc_row,
                                                   const float *__restrict__ csc_val,
                                                   const int *__restrict__ csc_pos,
@@ -554,61 +563,70 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int *__restr
                                                   const float *__restrict__ P,
                                                   const float *__restrict__ sw,
                                                   float *__restrict__ partial, int kp_rt, float thresh,
-                                                  int xcd_split, double *__restrict__ colsum_rows) {
+                                                  int xcd_split, double *__restrict__ chunk_sums,
+                                                  unsigned long long *__restrict__ t_end) {
     constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR_COL;
     constexpr int GPB = 256 / LPN;
-    extern __shared__ double scol[];   // [GPB][kp]: block sum of the item accumulators (-> norm_pwz)
+    extern __shared__ double scol[];   // [GPB][kp]: sum of the chunk's accumulators (-> norm_pwz)
     const int kp = S::kp(kp_rt);
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
-    float4 csum[CH];
-#pragma unroll
-    for (int j = 0; j < CH; ++j) csum[j] = zero4();
-    // XCD-aware traversal: workgroup b runs on XCD b % 8 (observed dispatch rule; a different
-    // placement only costs speed).  Each XCD walks its own contiguous eighth of the doc-band-major
-    // item list, so all workgroups sharing an L2 gather from the same band of U rows.
+    const int n_chunks = (int)((n_items + GPB - 1) / GPB);
     const int xcd = xcd_split ? (int)(blockIdx.x & 7) : 0;
-    const i64 nq = xcd_split ? (gridDim.x + 7 - xcd) / 8 : gridDim.x;   // workgroups on this XCD
-    const i64 q = xcd_split ? (blockIdx.x >> 3) : blockIdx.x;
-    const i64 per = xcd_split ? (n_items + 7) / 8 : n_items;
-    const i64 lo = xcd * per, hi = min(n_items, lo + per);
-    for (i64 io = lo + q * GPB + gid; io < hi; io += nq * GPB) {
-        const int it = item_order ? item_order[io] : (int)io;
-        const int w = item_col[it];
-        const int j0 = item_start[it];
-        const int j1 = item_end[it];
-        float4 vt[CH], acc[CH];
-        load_row<S, true, PLSA_NT_STREAMS>(Vt + (i64)w * kp, li, kp, vt);
+    const int nq = xcd_split ? (int)((gridDim.x + 7 - xcd) / 8) : (int)gridDim.x;   // workgroups on this XCD
+    const int q = xcd_split ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int c_lo = xcd_split ? xcd_lo[xcd] : 0, c_hi = xcd_split ? xcd_lo[xcd + 1] : n_chunks;
+    if (TIMED && blockIdx.x == 0 && threadIdx.x == 0) t_end[gridDim.x] = wall_clock64();   // launch start
+    for (int chunk = c_lo + q; chunk < c_hi; chunk += nq) {
+        const i64 io = (i64)chunk * GPB + gid;
+        float4 acc[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) acc[j] = zero4();
-        int d_n = (j0 + li < j1) ? ldi(csc_row + j0 + li) : 0;
-        float x_n = (j0 + li < j1) ? ldf(csc_val + j0 + li) : 0.f;
-        int p_n = (FROM_P && j0 + li < j1) ? ldi(csc_pos + j0 + li) : 0;
-        for (int jb = j0; jb < j1; jb += LPN) {
-            const int d_l = d_n, p_l = p_n;
-            float x_l = x_n;
-            const int jn = jb + LPN + li;
-            d_n = jn < j1 ? ldi(csc_row + jn) : 0;
-            x_n = jn < j1 ? ldf(csc_val + jn) : 0.f;
-            if (FROM_P) p_n = jn < j1 ? ldi(csc_pos + jn) : 0;
-            if (sw) x_l *= sw[d_l];  // t = s * sample_weight[d]  (plsa.py:294), folded into the count
-            const int cnt = min(LPN, j1 - jb);
-            // full batches of UNR gathers, then the remainder two at a time: most vocabulary columns
-            // are short (Zipf tail) and must not pay for UNR padded gathers
-            int s0 = 0;
-            for (; s0 + UNR <= cnt; s0 += UNR)
-                col_batch<S, FROM_P, UNR>(s0, d_l, x_l, p_l, li, kp, thresh, U, P, vt, acc);
-            constexpr int TAIL = (UNR >= 2 && LPN >= 2) ? 2 : 1;
-            for (; s0 < cnt; s0 += TAIL)
-                col_batch<S, FROM_P, TAIL>(s0, d_l, x_l, p_l, li, kp, thresh, U, P, vt, acc);
-        }
+        if (io < n_items) {
+            const int4 rec = item_rec[io];
+            const int w = rec.x, j0 = rec.y, j1 = rec.z;
+            float4 vt[CH];
+            load_row<S, true, PLSA_NT_STREAMS>(Vt + (i64)w * kp, li, kp, vt);
+            int d_n = (j0 + li < j1) ? ldi(csc_row + j0 + li) : 0;
+            float x_n = (j0 + li < j1) ? ldf(csc_val + j0 + li) : 0.f;
+            int p_n = (FROM_P && j0 + li < j1) ? ldi(csc_pos + j0 + li) : 0;
+            for (int jb = j0; jb < j1; jb += LPN) {
+                const int d_l = d_n, p_l = p_n;
+                float x_l = x_n;
+                const int jn = jb + LPN + li;
+                d_n = jn < j1 ? ldi(csc_row + jn) : 0;
+                x_n = jn < j1 ? ldf(csc_val + jn) : 0.f;
+                if (FROM_P) p_n = jn < j1 ? ldi(csc_pos + jn) : 0;
+                if (sw) x_l *= sw[d_l];  // t = s * sample_weight[d]  (plsa.py:294), folded into the count
+                const int cnt = min(LPN, j1 - jb);
+                // full batches of UNR gathers, then the remainder two at a time: most vocabulary columns
+                // are short (Zipf tail) and must not pay for UNR padded gathers
+                int s0 = 0;
+                for (; s0 + UNR <= cnt; s0 += UNR)
+                    col_batch<S, FROM_P, UNR>(s0, d_l, x_l, p_l, li, kp, thresh, U, P, vt, acc);
+                constexpr int TAIL = (UNR >= 2 && LPN >= 2) ? 2 : 1;
+                for (; s0 < cnt; s0 += TAIL)
+                    col_batch<S, FROM_P, TAIL>(s0, d_l, x_l, p_l, li, kp, thresh, U, P, vt, acc);
+            }
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            if (S::ok(li, j, kp)) st4(partial + (i64)it * kp + S::c4(li, j), acc[j]);
-            csum[j].x += acc[j].x; csum[j].y += acc[j].y; csum[j].z += acc[j].z; csum[j].w += acc[j].w;
+            for (int j = 0; j < CH; ++j)
+                if (S::ok(li, j, kp)) st4(partial + (i64)rec.w * kp + S::c4(li, j), acc[j]);
         }
+        block_colsum<S>(acc, li, gid, kp, scol, chunk_sums + (i64)chunk * kp);
+        __syncthreads();               // scol is rewritten by the next chunk
     }
-    block_colsum<S>(csum, li, gid, kp, scol, colsum_rows + (i64)blockIdx.x * kp);
+    if (TIMED && threadIdx.x == 0) t_end[blockIdx.x] = wall_clock64();
+}
+
+// visiting-order item records of the column pass: rec[io] = {column, first entry, end, item id (partial slot)}
+__global__ void k_item_records(const int *__restrict__ item_order, const int *__restrict__ item_col,
+                               const int *__restrict__ item_start, const int *__restrict__ item_end, i64 n_items,
+                               int4 *__restrict__ rec) {
+    const i64 io = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (io < n_items) {
+        const int it = item_order ? item_order[io] : (int)io;
+        rec[io] = make_int4(item_col[it], item_start[it], item_end[it], it);
+    }
 }
 
 // adds the item partials of each column (fixed order) into the un-normalised Vt_new.
