@@ -116,6 +116,7 @@ struct plsa_ctx {
     DevBuf item_end, colsum_rows, colsum_rows2;
     // column-pass schedule: visiting-order item records, chunk boundaries per XCD (measured, see ensure_balance)
     DevBuf item_rec, xcd_lo, t_end;
+    int order_band = -1;             // PLSA_ORDER_BAND: documents per band of the visiting order (-1 auto, 0 first-document order)
     int balance = -1;                // PLSA_BALANCE: -1 auto (large problems), 0 equal stretches, 1 always measure
     bool bal_valid = false;          // xcd_lo matches the current structure
     bool bal_have_frac = false;      // bal_frac holds measured boundaries (kept across bootstrap resamples as the start)
@@ -464,7 +465,13 @@ int ensure_csc(plsa_ctx *c) {
         const i64 slots = (i64)c->prop.multiProcessorCount * 32 * (64 / std::max(1, c->lpn));
         i64 want = c->nnz / std::max<i64>(4 * slots, 1);
         int seg = 16;
-        while (seg * 2 <= want && seg < 256) seg *= 2;
+        // large corpora: with the XCD stretches balanced, SHORTER items win (an item then spans fewer documents
+        // and stays inside the band its XCD's L2 holds): config 3 (k = 64) 256 / 128 / 96 / 64 / 48 entries ->
+        // 268 / 269 / 271 / 274 / 272 iterations/s, config 5 (k = 128) 256 / 128 / 64 -> 22.6 / 23.2 / 22.7.
+        // Items of one length for every column: a chunk's groups (and a wave's) wait for their longest item --
+        // long items for the Zipf-head words only (256 entries, the others 64) cost 1.96 -> 3.0 ms at config 3
+        const int cap = c->kp <= 64 ? 64 : 128;
+        while (seg * 2 <= want && seg < cap) seg *= 2;
         c->seg = c->seg_override ? c->seg_override : seg;
     }
     const i64 nnz = c->nnz, m = c->m;
@@ -513,22 +520,22 @@ int ensure_csc(plsa_ctx *c) {
     CHK(ensure(c, c->item_start, sizeof(int) * ni));
     CHK(ensure(c, c->item_end, sizeof(int) * ni));
     CHK(ensure(c, c->item_order, sizeof(int) * ni));
-    CHK(ensure(c, c->tmp2, sizeof(int) * ni * 2));       // first documents, sorted
+    CHK(ensure(c, c->tmp2, sizeof(unsigned long long) * ni * 2));   // sort keys, sorted keys
     CHK(ensure(c, c->tmp1, sizeof(int) * ni));           // item ids
-    unsigned *d_key = c->tmp2.as<unsigned>();
+    unsigned long long *d_key = c->tmp2.as<unsigned long long>();
+    // band of the visiting order: 512 KB of P(z|d) rows (2048 documents at k = 64), PLSA_ORDER_BAND documents
+    const int band = c->order_band >= 0 ? c->order_band : std::max(64, (512 << 10) / (c->kp > 0 ? c->kp * 4 : 256));
     hipLaunchKernelGGL(plsa::k_item_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
                        c->colptr.as<int>(), c->item_first.as<int>(), (int)m, c->seg, c->csc_row.as<int>(),
-                       c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(), d_key, c->tmp1.as<int>());
+                       c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(), band, d_key, c->tmp1.as<int>());
     CHK(launch_check(c, "k_item_fill"));
-    if (n_items > 0) {   // visiting order: ascending first document (stable) -> doc-band-major
-        int dbits = 1;
-        while (((i64)1 << dbits) < c->n) ++dbits;
+    if (n_items > 0) {   // visiting order: band-major, Zipf-head words first inside a band (stable)
         size_t bytes = 0;
         HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, d_key, d_key + ni,
-                                                     c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, dbits, c->stream));
+                                                     c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, 64, c->stream));
         CHK(ensure(c, c->cubtmp, bytes));
         HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, bytes, d_key, d_key + ni,
-                                                     c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, dbits, c->stream));
+                                                     c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, 64, c->stream));
     }
     // visiting-order records (one 16-byte load per item instead of an index chain)
     CHK(ensure(c, c->item_rec, sizeof(int4) * ni));
@@ -721,8 +728,10 @@ int ensure_balance(plsa_ctx *c, int grid, int n_chunks, bool split, Launch &&lau
     balance_set_lo(c, n_chunks);
     HIPCHK(c, hipMemcpyAsync(c->xcd_lo.p, c->bal_lo, sizeof(int) * 9, hipMemcpyHostToDevice, c->ls));
     c->bal_launches = 0;
+    // auto: corpora from ~1e8 cells per iteration (config 2: 4279 -> 4540 iterations/s; the tuning launches of a
+    // 20NG-sized corpus would cost a bootstrap member more than they return)
     const bool tune = split && n_chunks >= 64 &&
-                      (c->balance > 0 || (c->balance < 0 && (double)c->nnz * c->kp >= c->overlap_full_limit));
+                      (c->balance > 0 || (c->balance < 0 && (double)c->nnz * c->kp >= 1e8));
     if (tune) {
         CHK(ensure(c, c->t_end, sizeof(unsigned long long) * ((size_t)grid + 1)));
         std::vector<unsigned long long> te((size_t)grid + 1);
@@ -874,7 +883,7 @@ int run_col_tail(plsa_ctx *c) {
     const double *rows_in = c->colsum_rows.as<double>();
     int n_rows = rows;
     if (rows > 2048) {               // many chunks (large corpora): two stages
-        const int nb = rows > 65536 ? 256 : 64;
+        const int nb = std::max(64, std::min(1024, rows / 64));
         CHK(ensure(c, c->colsum_rows2, sizeof(double) * (size_t)nb * c->kp));
         Scope s(c, "k_norm_reduce");
         hipLaunchKernelGGL(plsa::k_norm_reduce, dim3(nb), dim3(256), 0, c->ls, rows_in, rows, c->kp,
@@ -1011,6 +1020,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_ITEM_ORDER")) c->use_item_order = atoi(s) != 0;
     if (const char *s = getenv("PLSA_XCD_SPLIT")) c->xcd_split = atoi(s) != 0;
     if (const char *s = getenv("PLSA_BALANCE")) c->balance = atoi(s);
+    if (const char *s = getenv("PLSA_ORDER_BAND")) c->order_band = atoi(s);
     if (const char *s = getenv("PLSA_CHUNKS_PER_LANE")) c->chunks_per_lane = atoi(s);
     if (const char *s = getenv("PLSA_E_ROWS")) c->e_rows = atoi(s);
     if (const char *s = getenv("PLSA_E_SEG")) c->eseg_override = atoi(s);

@@ -464,6 +464,7 @@ __global__ __launch_bounds__(256) void k_col_dyn(const int4 *__restrict__ items,
 //    workgroup also writes the float64 sum of its 16 accumulators (what norm_pwz is made of), so the results do
 //    not depend on the boundaries.  TIMED: thread 0 records the block's end time (100 MHz wall clock).
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4_sel(const float *p, bool nt) { return nt ? plsa::ld4_nt(p) : plsa::ld4(p); }
 template <int MODE, int UNR, bool TIMED>
 __global__ __launch_bounds__(256) void k_col_chunks(const int4 *__restrict__ items, i64 n_items, const int *__restrict__ lo,
                                                     const int *__restrict__ csc_row, const float *__restrict__ csc_val,
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(256) void k_col_chunks(const int4 *__restrict__ ite
         if (io < n_items) {
             const int4 rec = items[io];
             const int w = rec.x, j0 = rec.y, j1 = rec.z;
+            const bool nt = rec.w != 0;
             const float4 vt = plsa::ld4(Vt + (i64)w * 64 + li * 4);
             int d_n = (j0 + li < j1) ? csc_row[j0 + li] : 0;
             float x_n = (j0 + li < j1) ? csc_val[j0 + li] : 0.f;
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(256) void k_col_chunks(const int4 *__restrict__ ite
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) {
                         xx[u] = __shfl(x_l, s0 + u, LPN);
-                        a[u] = plsa::ld4(U + (i64)__shfl(d_l, s0 + u, LPN) * 64 + li * 4);
+                        a[u] = ld4_sel(U + (i64)__shfl(d_l, s0 + u, LPN) * 64 + li * 4, nt);
                     }
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) nz_update<MODE>(vt, a[u], xx[u], thresh, acc);
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(256) void k_col_chunks(const int4 *__restrict__ ite
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         xx[u] = __shfl(x_l, s0 + u, LPN);
-                        a[u] = plsa::ld4(U + (i64)__shfl(d_l, s0 + u, LPN) * 64 + li * 4);
+                        a[u] = ld4_sel(U + (i64)__shfl(d_l, s0 + u, LPN) * 64 + li * 4, nt);
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) nz_update<MODE>(vt, a[u], xx[u], thresh, acc);
@@ -555,7 +557,7 @@ int main(int argc, char **argv) {
         valu_case<V_BPERM>("ds_bpermute_b32", 16, cus);
     }
     if (want("gather")) gather_cases(cus);
-    if (!want("row") && !want("col") && !want("timeline") && !want("dyn") && !want("balance") && !want("rowx")) return 0;
+    if (!want("row") && !want("col") && !want("timeline") && !want("dyn") && !want("balance") && !want("rowx") && !want("ntcol") && !want("order")) return 0;
 
     // ---- corpus ------------------------------------------------------------------------------------------
     i64 n = 1000000, m = 100000, nnz_t = 100000000;
@@ -641,10 +643,6 @@ int main(int argc, char **argv) {
         ROWV(2, 16, "row variant: gather-only, 16 in flight");
     }
     if (want("col")) {
-        report("k_col_pass<fused> (shipped)", time_ms([&] {
-            hipLaunchKernelGGL((plsa::k_col_pass<S, false>), dim3(grid_col), dim3(256), sizeof(double) * 16 * 64, g_stream, d_iord, d_icol, d_ist,
-                               d_iend, n_items, d_cscrow, d_cscval, (const int *)nullptr, d_U, d_Vt, (const float *)nullptr,
-                               (const float *)nullptr, d_part, 64, thresh, 1, d_colsum); }));
 #define COLV(MODE, UNR, NAME) report(NAME, time_ms([&] { hipLaunchKernelGGL((k_col_variant<MODE, UNR>), dim3(grid_col), dim3(256), 0, g_stream, \
         d_iord, d_icol, d_ist, d_iend, n_items, d_cscrow, d_cscval, d_U, d_Vt, d_part, thresh); }))
         COLV(0, 8, "col variant: full, 8 rows in flight");
@@ -797,6 +795,98 @@ int main(int argc, char **argv) {
                 double accs = 0;
                 for (int x = 0; x < 8; ++x) { accs += size[x]; lo[x + 1] = (int)(accs / tot * n_chunks + 0.5); }
                 lo[8] = n_chunks;
+            }
+            HC(hipFree(d_items)); HC(hipFree(d_p2)); HC(hipFree(d_cs)); HC(hipFree(d_lo)); HC(hipFree(d_te));
+        }
+    }
+    if (want("ntcol")) {
+        for (int seg : {64, 128}) {
+            for (int nt_below : {0, 1000, 10000, 100000}) {      // columns with fewer entries than this gather non-temporally
+                std::vector<int4> recs;
+                for (i64 c = 0; c < m; ++c)
+                    for (int st = colptr[c]; st < colptr[c + 1]; st += seg)
+                        recs.push_back(make_int4((int)c, st, std::min(st + seg, colptr[c + 1]), (colptr[c + 1] - colptr[c]) < nt_below ? 1 : 0));
+                const i64 ni = (i64)recs.size();
+                std::stable_sort(recs.begin(), recs.end(), [&](const int4 &a, const int4 &b) { return csc_row[a.y] < csc_row[b.y]; });
+                const int n_chunks = (int)((ni + 15) / 16);
+                int4 *d_items = dev(recs);
+                float *d_p2 = dev_alloc<float>((size_t)ni * 64);
+                double *d_cs = dev_alloc<double>((size_t)n_chunks * 64);
+                std::vector<int> lo(9);
+                for (int x = 0; x <= 8; ++x) lo[x] = (int)((i64)n_chunks * x / 8);
+                int *d_lo = dev(lo);
+                const int grid = std::min(n_chunks + 8, cus * 128) / 8 * 8;
+                unsigned long long *d_te = dev_alloc<unsigned long long>(grid);
+                std::vector<unsigned long long> te(grid);
+                double ms = 0, msg = 0;
+                for (int iter = 0; iter < 4; ++iter) {
+                    HC(hipMemcpyAsync(d_lo, lo.data(), sizeof(int) * 9, hipMemcpyHostToDevice, g_stream));
+                    ms = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<0, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); });
+                    msg = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<2, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); });
+                    HC(hipMemsetAsync(d_te, 0, sizeof(unsigned long long) * grid, g_stream));
+                    hipLaunchKernelGGL((k_col_chunks<0, 8, true>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te);
+                    HC(hipStreamSynchronize(g_stream));
+                    HC(hipMemcpy(te.data(), d_te, sizeof(unsigned long long) * grid, hipMemcpyDeviceToHost));
+                    unsigned long long t0 = ~0ull, last[8] = {0};
+                    for (int b = 0; b < grid; ++b) if (te[b]) { t0 = std::min(t0, te[b]); last[b & 7] = std::max(last[b & 7], te[b]); }
+                    double T[8], mean = 0, size[8], tot = 0, accs = 0;
+                    for (int x = 0; x < 8; ++x) { T[x] = std::max(1.0, (double)(last[x] - t0) / 100.0 + 100.0); mean += T[x] / 8; }
+                    for (int x = 0; x < 8; ++x) { size[x] = (lo[x + 1] - lo[x]) * (1.0 + 0.8 * (mean / T[x] - 1.0)); tot += size[x]; }
+                    for (int x = 0; x < 8; ++x) { accs += size[x]; lo[x + 1] = (int)(accs / tot * n_chunks + 0.5); }
+                    lo[8] = n_chunks;
+                }
+                printf("{\"test\": \"col_nt\", \"seg\": %d, \"nt_for_columns_below\": %d, \"ms\": %.4f, \"ms_gather_only\": %.4f}\n", seg, nt_below, ms, msg);
+                fflush(stdout);
+                HC(hipFree(d_items)); HC(hipFree(d_p2)); HC(hipFree(d_cs)); HC(hipFree(d_lo)); HC(hipFree(d_te));
+            }
+        }
+    }
+    if (want("order")) {
+        // visiting orders at 64-entry items, measured boundaries (4 rounds): does making a chunk's 16 items alike help?
+        //   band 0: ascending first document (shipped).   band B: (first document / B), then column length descending
+        const int seg = 64;
+        for (int band : {1024, 1536, 3072, 4096, -2048, -4096}) {
+            std::vector<int4> recs;
+            for (i64 c = 0; c < m; ++c)
+                for (int st = colptr[c]; st < colptr[c + 1]; st += seg) recs.push_back(make_int4((int)c, st, std::min(st + seg, colptr[c + 1]), 0));
+            const i64 ni = (i64)recs.size();
+            if (band == 0)
+                std::stable_sort(recs.begin(), recs.end(), [&](const int4 &a, const int4 &b) { return csc_row[a.y] < csc_row[b.y]; });
+            else
+                std::stable_sort(recs.begin(), recs.end(), [&](const int4 &a, const int4 &b) {
+                    const int B = band > 0 ? band : -band;      // negative: ascending column length inside a band
+                    const int ba = csc_row[a.y] / B, bb = csc_row[b.y] / B;
+                    if (ba != bb) return ba < bb;
+                    const int la = colptr[a.x + 1] - colptr[a.x], lb = colptr[b.x + 1] - colptr[b.x];
+                    return band > 0 ? la > lb : la < lb; });
+            const int n_chunks = (int)((ni + 15) / 16);
+            int4 *d_items = dev(recs);
+            float *d_p2 = dev_alloc<float>((size_t)ni * 64);
+            double *d_cs = dev_alloc<double>((size_t)n_chunks * 64);
+            std::vector<int> lo(9);
+            for (int x = 0; x <= 8; ++x) lo[x] = (int)((i64)n_chunks * x / 8);
+            int *d_lo = dev(lo);
+            const int grid = std::min(n_chunks + 8, cus * 128) / 8 * 8;
+            unsigned long long *d_te = dev_alloc<unsigned long long>(grid);
+            std::vector<unsigned long long> te(grid);
+            double ms = 0, msg = 0;
+            for (int iter = 0; iter < 4; ++iter) {
+                HC(hipMemcpyAsync(d_lo, lo.data(), sizeof(int) * 9, hipMemcpyHostToDevice, g_stream));
+                ms = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<0, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); });
+                msg = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<2, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); });
+                HC(hipMemsetAsync(d_te, 0, sizeof(unsigned long long) * grid, g_stream));
+                hipLaunchKernelGGL((k_col_chunks<0, 8, true>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te);
+                HC(hipStreamSynchronize(g_stream));
+                HC(hipMemcpy(te.data(), d_te, sizeof(unsigned long long) * grid, hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull, last[8] = {0};
+                for (int b = 0; b < grid; ++b) if (te[b]) { t0 = std::min(t0, te[b]); last[b & 7] = std::max(last[b & 7], te[b]); }
+                double T[8], mean = 0, size[8], tot = 0, accs = 0;
+                for (int x = 0; x < 8; ++x) { T[x] = std::max(1.0, (double)(last[x] - t0) / 100.0 + 100.0); mean += T[x] / 8; }
+                for (int x = 0; x < 8; ++x) { size[x] = (lo[x + 1] - lo[x]) * (1.0 + 0.8 * (mean / T[x] - 1.0)); tot += size[x]; }
+                for (int x = 0; x < 8; ++x) { accs += size[x]; lo[x + 1] = (int)(accs / tot * n_chunks + 0.5); }
+                lo[8] = n_chunks;
+                printf("{\"test\": \"col_order\", \"seg\": %d, \"band\": %d, \"round\": %d, \"ms\": %.4f, \"ms_gather_only\": %.4f}\n", seg, band, iter, ms, msg);
+                fflush(stdout);
             }
             HC(hipFree(d_items)); HC(hipFree(d_p2)); HC(hipFree(d_cs)); HC(hipFree(d_lo)); HC(hipFree(d_te));
         }
