@@ -7,9 +7,15 @@ A "step" is one EM iteration (E-step + M-step, plus the log-likelihood test at t
 schedule, plsa.py:630) over the whole synthetic corpus, driven through the C ABI (plsa_fit).
 N = 1 : one fit on the corpus.   N > 1 : the ensemble path -- one process per GPU, rank r fits
 bootstrap member r of the same corpus (device-side row gather), no collective on the EM path, one RCCL
-all-gather of the topic matrices at the end (inside the timed region; ncclAllGather issued from the C
-ABI, plsa_comm_allgather_components -- no PyTorch in the process).  `value` is the whole-job aggregate:
-(N * K) EM iterations / max-over-ranks wall time.
+all-gather of the topic matrices at the end (inside the timed region) -- the exchange the product itself
+uses: the member's topics go into the engine's device stack and enstop_amd.distributed's gather
+(plsa_comm_allgather_stack: one grouped ncclAllGather from the C ABI + one copy to pinned host memory; no
+PyTorch in the process).  `value` is the whole-job aggregate: (N * K) EM iterations / max-over-ranks wall time.
+
+`ensemble` (every N): a MEASURED ensemble through the product's own call -- enstop_amd.ensemble_of_topics on the
+host copy of the same corpus, two members per rank, 50 EM iterations each: upload, bootstrap row gather, CSC /
+item build (+ boundary tuning), MT19937 initialisation on the device, fit, stack, gather -- wall clock between
+two barriers, max over ranks -> `ensemble.fits_per_min`, with each rank's fit / gather / RCCL-init seconds.
 
 Launching N > 1: either an external launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (the driver's
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`), or plain
@@ -166,11 +172,47 @@ def quick_config(eng, cfg_id, steps, warmup, seed, with_cpu=False):
     return out
 
 
+def ensemble_leg(eng, comm, k, world, rank, args, rccl_init_s):
+    """MEASURED ensemble throughput through the product's own call (enstop_amd.ensemble_of_topics): every member
+    pays what a member of the reference pays (enstop_.py:84-115) -- bootstrap resample, structure build,
+    initialisation, 50 EM iterations -- plus upload of the corpus and the all-gather of the stack."""
+    import enstop_amd
+    from enstop_amd import enstop_ as product
+    eng.bootstrap(None)
+    X = eng.download_active_csr()                      # host copy of the corpus: what a caller of the API holds
+    n_runs = args.members_per_rank * world
+    kw = dict(n_runs=n_runs, n_iter=FITS_ITERS, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32,
+              random_state=args.seed + 7, n_jobs=4)
+    eng.synchronize()
+    comm.barrier()
+    t0 = time.perf_counter()
+    stack = enstop_amd.ensemble_of_topics(X, k, **kw)
+    eng.synchronize()
+    comm.barrier()
+    dt = time.perf_counter() - t0
+    assert stack.shape == (n_runs * k, X.shape[1]) and np.all(np.isfinite(stack))
+    sums = stack.sum(axis=1)
+    assert np.abs(sums - 1.0).max() < 1e-3, "a member's topics do not sum to one"
+    tm = dict(product.last_ensemble_timing)
+    mine = np.array([dt, tm.get("fit_s", 0.0), tm.get("gather_s", 0.0), rccl_init_s], np.float64)
+    per_rank = comm.allgather_array(mine)              # [world, 4]
+    wall = float(per_rank[:, 0].max())
+    return {"fits": n_runs, "members_per_rank": args.members_per_rank, "iters_per_member": FITS_ITERS,
+            "wall_s": round(wall, 4), "fits_per_min": round(n_runs / wall * 60.0, 2),
+            "per_rank": [{"rank": r, "wall_s": round(float(per_rank[r, 0]), 4), "fit_s": round(float(per_rank[r, 1]), 4),
+                          "gather_s": round(float(per_rank[r, 2]), 4), "rccl_init_s": round(float(per_rank[r, 3]), 4)}
+                         for r in range(world)],
+            "path": "enstop_amd.ensemble_of_topics(X_host, k, n_runs=%d, n_iter=%d, tolerance=0): upload + per member "
+                    "(device bootstrap gather, CSC / item build, MT19937 init on the device, fit, D2D into the stack) + "
+                    "distributed.gather_stack" % (n_runs, FITS_ITERS)}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without an external launcher: start the N ranks ourselves (one process
     per GPU), give them a private rendezvous file for the RCCL unique id, relay rank 0's JSON line."""
     tmpdir = tempfile.mkdtemp(prefix="plsa_bench_")
     base = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT="0",
+                PLSA_LAUNCH_NONCE=os.path.basename(tmpdir),
                 PLSA_COMM_ID_FILE=os.path.join(tmpdir, "rccl.id"), PLSA_BENCH_FILES_DIR=os.path.join(tmpdir, "x"),
                 HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs = []
@@ -287,6 +329,8 @@ def main():
                     choices=["fused", "materialised"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
+    ap.add_argument("--no-ensemble", action="store_true", help="skip the measured ensemble leg")
+    ap.add_argument("--members-per-rank", type=int, default=2)
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "files"],
                     help="files: TEST MODE for boxes with fewer GPUs than ranks (host-file exchange, shared GPUs)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -332,13 +376,18 @@ def main():
     n, m, k = cfg["n"], cfg["m"], cfg["k"]
     flags = (PLSA_FUSED if args.schedule == "fused" else 0)
 
-    eng = Engine(device)
+    os.environ.setdefault("ENSTOP_AMD_DEVICE", str(device))
+    from enstop_amd.engine import get_engine
+    eng = get_engine(device)          # the process-wide engine of this GPU: the one the product's own calls use
     info = eng.device_info()
     comm = plsa_comm.SingleComm()
+    rccl_init_s = 0.0
     if world > 1:
         if args.exchange == "rccl":
             # any failure here (duplicate GPU, bootstrap, ...) raises: non-zero exit status, no JSON line
+            t_init = time.perf_counter()
             comm = plsa_comm.init_from_env(eng)
+            rccl_init_s = time.perf_counter() - t_init
         else:
             comm = plsa_comm.install(plsa_comm.FileComm(os.environ.get("PLSA_BENCH_FILES_DIR", "/tmp/plsa_bench_x"),
                                                         rank, world))
@@ -356,14 +405,16 @@ def main():
         eng.synchronize()
         comm.barrier()
 
+    from enstop_amd import distributed as plsa_dist
+    stack_base = eng.stack_reserve(1, k, m) if world > 1 else None
+
     def gather_components():
-        """the np.vstack of enstop_.py:231 as one all-gather of the (k, m) topic matrices; the stack
-        lands in host memory on rank 0 (where the reference's single process holds it)"""
+        """the np.vstack of enstop_.py:231 through the product's own exchange: this member's topics go into the
+        engine's device stack, enstop_amd.distributed.gather_stack brings every rank's stack together"""
         if world == 1:
             return None
-        if isinstance(comm, plsa_comm.RcclComm):
-            return eng.comm_allgather_components(want_host=(rank == 0), pinned=True)
-        return comm.allgather_components(eng)
+        eng.copy_components_to_device(stack_base)
+        return plsa_dist.gather_stack(eng, world, k, m).reshape(world, k, m)
 
     # ---- warmup (untimed): W EM iterations + the collective --------------------------------------
     if args.warmup > 0:
@@ -456,7 +507,9 @@ def main():
         "rccl_ranks": world if isinstance(comm, plsa_comm.RcclComm) else 0,
         "exchange": exchange,
         "gcell_per_s": round(nnz_total * k * args.steps / dt / 1e9, 3),
-        "ensemble_fits_per_min": round(n_gpus * args.steps / dt / FITS_ITERS * 60.0, 3),
+        # derived from the iteration rate alone (no bootstrap / structure build / init / gather): the MEASURED
+        # figure is ensemble.fits_per_min below
+        "ensemble_fits_per_min_from_iteration_rate": round(n_gpus * args.steps / dt / FITS_ITERS * 60.0, 3),
         # north_star's roofline kernel: the per-nnz materialising E-step (HBM-bound)
         "roofline": roof("k_e_step", e_entry),
         # dominant kernel of the (fused) timed region against its own compulsory bytes; it is
@@ -473,6 +526,15 @@ def main():
             except Exception as e:       # the baseline must never cost the GPU measurement
                 out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+    # ---- measured ensemble: the product's own call, two members per rank (see the module docstring) -------------
+    if not args.no_ensemble:
+        try:
+            out["ensemble"] = ensemble_leg(eng, comm, k, world, rank, args, rccl_init_s)
+            out["ensemble_fits_per_min"] = out["ensemble"]["fits_per_min"]
+        except Exception as e:
+            if world > 1:
+                raise                                     # a rank that fails here would leave the others in a collective
+            out["ensemble"] = "failed: %r" % (e,)
     if rank == 0 and n_gpus == 1 and args.config == 3 and not args.no_cpu_baseline:
         # BASELINE.json configs[1] (100k x 50k, 10M nnz, k=32) on the same device, compact form, with the
         # CPU port on the WHOLE of that corpus beside it
@@ -486,7 +548,8 @@ def main():
     if world > 1:
         comm.barrier()
         plsa_comm.shutdown()
-    eng.close()
+    from enstop_amd.engine import reset_engines
+    reset_engines()
     # ---- HBM-side traffic of the roofline kernels: PMC passes in this run, else the committed profile ----
     if rank == 0:
         table = None

@@ -13,6 +13,7 @@ from .ensemble import EnsembleTopics, ensemble_fit
 from .sharded import sharded_plsa_fit
 from .engine import Engine, DeviceError, PLSA_FUSED
 from .utils import log_lift, mean_log_lift, coherence, mean_coherence
+from . import comm, distributed, engine       # enstop_amd.distributed.init() works without a separate import
 
 __all__ = ["PLSA", "StreamedPLSA", "BlockParallelPLSA", "GPUPLSA", "DistributedPLSA", "log_lift", "mean_log_lift", "coherence", "mean_coherence", "plsa_fit", "plsa_refit", "plsa_fit_inner", "plsa_refit_inner", "plsa_init",
            "plsa_e_step", "plsa_m_step", "plsa_m_step_w_sample_weight", "plsa_refit_m_step",

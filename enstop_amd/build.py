@@ -6,9 +6,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "plsa_hip.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "plsa_kernels.hpp"), os.path.join(HERE, "csrc", "plsa_synth.hpp"),
-        os.path.join(os.path.dirname(HERE), "include", "plsa_hip.h")]
+        os.path.join(HERE, "csrc", "mt_jump.hpp"), os.path.join(os.path.dirname(HERE), "include", "plsa_hip.h")]
 OUT = os.path.join(HERE, "libplsa_hip.so")
-HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))
 # -fno-slp-vectorize: the SLP vectoriser pairs the per-topic multiplies/adds into v_pk_*_f32, which then
 # need register-pair shuffles and keep the DPP moves of the group sums from folding into their adds;
 # without it the fused document pass is 9 % faster (1.68 -> 1.52 ms at config 3), everything else equal
@@ -22,7 +23,8 @@ def build(force=False, verbose=True):
             and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps)):
         return OUT
     # RCCL is linked directly: the multi-GPU exchange (plsa_comm_*) is part of the C ABI
-    cmd = [HIPCC] + FLAGS + [SRC, "-o", OUT, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    rocm_lib = os.path.join(ROCM, "lib")
+    cmd = [HIPCC] + FLAGS + [SRC, "-o", OUT, "-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

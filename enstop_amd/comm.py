@@ -25,6 +25,14 @@ import numpy as np
 ID_BYTES = 128
 
 
+def _run_order(g):
+    """[world, slots, k, m] as gathered rank by rank -> [slots * world, k, m] in run order (r = slot * world + rank)."""
+    world, slots = g.shape[:2]
+    out = np.empty((slots, world) + g.shape[2:], g.dtype)           # always a fresh array (g may view a pinned buffer)
+    out[...] = g.transpose(1, 0, 2, 3)
+    return out.reshape((slots * world,) + g.shape[2:])
+
+
 class SingleComm:
     """world = 1: every exchange is the identity."""
     rank, world, name = 0, 1, "single"
@@ -41,9 +49,15 @@ class SingleComm:
     def broadcast_array(self, a, root=0):
         return np.asarray(a)
 
-    def allgather_components(self, eng):
-        _, V = eng.get_factors(want_u=False)
-        return V[None]
+    def gather_host_stack(self, local):
+        """[slots, k, m] of this rank -> [slots * world, k, m] of all ranks in run order (host arrays)."""
+        return _run_order(self.allgather_array(np.asarray(local)))
+
+    def gather_stack(self, eng, slots, k, m):
+        """The stack of ALL ranks' members in run order, [slots * world, k, m]: `eng` holds this rank's
+        members in its device stack (Engine.stack_reserve; run r = slot r // world of rank r % world).
+        Communicators without a device path bring the local stack to the host (one copy) and exchange it there."""
+        return self.gather_host_stack(eng.comm_allgather_stack(slots, k, m, copy=False))
 
     def allreduce_accumulator(self, eng):
         pass
@@ -73,9 +87,9 @@ class RcclComm(SingleComm):
     def broadcast_array(self, a, root=0):
         return self.eng.comm_broadcast_host(np.ascontiguousarray(a), root)
 
-    def allgather_components(self, eng):
-        assert eng is self.eng
-        return eng.comm_allgather_components()
+    def gather_stack(self, eng, slots, k, m):
+        assert eng is self.eng            # one grouped ncclAllGather on the engine's stream + one copy to the host
+        return eng.comm_allgather_stack(slots, k, m)
 
     def allreduce_accumulator(self, eng):
         assert eng is self.eng
@@ -124,10 +138,6 @@ class TorchComm(SingleComm):
         self.dist.broadcast(t, src=root)
         return t.cpu().numpy().view(a.dtype).reshape(a.shape)
 
-    def allgather_components(self, eng):
-        _, V = eng.get_factors(want_u=False)
-        return self.allgather_array(V)
-
     def allreduce_accumulator(self, eng):
         torch, dist = self.torch, self.dist
         if self.on_device:
@@ -152,25 +162,40 @@ class FileComm(SingleComm):
     name = "files"
 
     def __init__(self, directory, rank, world, timeout=300.0):
-        self.dir, self.rank, self.world, self.timeout = directory, int(rank), int(world), timeout
+        # one sub-directory per launch (launch_token: the launcher's nonce / pid), so that a re-used base
+        # directory can never hand a rank the payload of an earlier run
+        self.dir = os.path.join(directory, "run_" + launch_token())
+        self.rank, self.world, self.timeout = int(rank), int(world), timeout
         self.seq = 0
-        os.makedirs(directory, exist_ok=True)
+        os.makedirs(self.dir, exist_ok=True)
+        stale = [f for f in os.listdir(self.dir) if f.endswith("_r%d.npy" % self.rank)]
+        if stale:
+            raise RuntimeError("FileComm: %s already holds exchange files of rank %d (%s ...): a previous run with the "
+                               "same launch token; remove the directory" % (self.dir, self.rank, stale[0]))
+
+    def _path(self, seq, r):
+        return os.path.join(self.dir, "x%06d_r%d.npy" % (seq, r))
 
     def _exchange(self, a):
         a = np.ascontiguousarray(a)
         self.seq += 1
-        mine = os.path.join(self.dir, "x%06d_r%d.npy" % (self.seq, self.rank))
+        mine = self._path(self.seq, self.rank)
         with open(mine + ".tmp", "wb") as f:
             np.save(f, a)
         os.replace(mine + ".tmp", mine)
         out, t0 = [], time.time()
         for r in range(self.world):
-            path = os.path.join(self.dir, "x%06d_r%d.npy" % (self.seq, r))
+            path = self._path(self.seq, r)
             while not os.path.exists(path):
                 if time.time() - t0 > self.timeout:
                     raise TimeoutError("FileComm: rank %d never wrote %s" % (r, path))
                 time.sleep(0.0005)
             out.append(np.load(path))
+        # every rank has written exchange `seq`, hence finished reading `seq - 1`: my older file can go
+        try:
+            os.unlink(self._path(self.seq - 1, self.rank))
+        except OSError:
+            pass
         return np.stack(out)
 
     def barrier(self):
@@ -185,10 +210,6 @@ class FileComm(SingleComm):
 
     def broadcast_array(self, a, root=0):
         return self._exchange(a)[root]
-
-    def allgather_components(self, eng):
-        _, V = eng.get_factors(want_u=False)
-        return self._exchange(V)
 
     def allreduce_accumulator(self, eng):
         g = self._exchange(eng.accumulator_get())
@@ -217,38 +238,77 @@ def current():
     return SingleComm()
 
 
+def launch_token():
+    """Identifies ONE launch of the ranks: the launcher's own nonce when it exports one (torchrun's
+    TORCHELASTIC_RUN_ID, PLSA_LAUNCH_NONCE from bench.py's spawner), always combined with the parent pid and the
+    parent's start time -- two launches from the same parent pid (containers restart at the same pid) differ in it."""
+    nonce = os.environ.get("PLSA_LAUNCH_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or "x"
+    nonce = "".join(ch if ch.isalnum() else "_" for ch in nonce)[:40]
+    return "%s_%d_%d" % (nonce, os.getppid(), int(_parent_start_ticks()))
+
+
+def _parent_start_ticks():
+    """Start time of the parent process in clock ticks since boot (/proc/<ppid>/stat field 22); 0 if unknown."""
+    try:
+        with open("/proc/%d/stat" % os.getppid()) as f:
+            return int(f.read().rsplit(")", 1)[1].split()[19])
+    except Exception:
+        return 0
+
+
+def _parent_start_epoch():
+    """Wall-clock start of the parent process (the launcher): nothing published before it belongs to this launch."""
+    try:
+        ticks = _parent_start_ticks()
+        with open("/proc/stat") as f:
+            btime = next(int(line.split()[1]) for line in f if line.startswith("btime"))
+        return btime + ticks / float(os.sysconf("SC_CLK_TCK"))
+    except Exception:
+        return 0.0
+
+
 def default_id_file():
     """Where the ranks of one launch meet.  PLSA_COMM_ID_FILE wins; otherwise a name that is unique per
-    launch: every worker of one launcher (torchrun, bench.py's own spawner) has the same parent process."""
+    launch (`launch_token`: every worker of one launcher -- torchrun, bench.py's own spawner -- has the same parent)."""
     explicit = os.environ.get("PLSA_COMM_ID_FILE")
     if explicit:
         return explicit
     tmp = os.environ.get("TMPDIR", "/tmp")
-    return os.path.join(tmp, "plsa_comm_%s_%s_%d.id" % (os.environ.get("MASTER_ADDR", "local"),
-                                                        os.environ.get("MASTER_PORT", "0"), os.getppid()))
+    return os.path.join(tmp, "plsa_comm_%s_%s_%s.id" % (os.environ.get("MASTER_ADDR", "local"),
+                                                        os.environ.get("MASTER_PORT", "0"), launch_token()))
 
 
 def rendezvous_id(rank, path=None, timeout=600.0):
-    """Rank 0 creates the RCCL unique id and publishes it atomically; the others wait for the file."""
+    """Rank 0 creates the RCCL unique id and publishes it atomically (after removing whatever an earlier, crashed
+    launch left at that path; the file is private to the user); the others wait for a file that is YOUNGER than
+    their launcher -- a stale id would otherwise be read before rank 0 replaces it and ncclCommInitRank would hang."""
     from . import _lib
     path = path or default_id_file()
     if rank == 0:
         import ctypes as C
+        for old in (path, path + ".tmp"):
+            try:
+                os.unlink(old)
+            except OSError:
+                pass
         buf = C.create_string_buffer(ID_BYTES)
         L = _lib.load()
         if L.plsa_comm_unique_id(buf):
             raise RuntimeError(L.plsa_last_error(None).decode())
-        with open(path + ".tmp", "wb") as f:
+        fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(buf.raw)
         os.replace(path + ".tmp", path)
         return buf.raw
+    not_before = _parent_start_epoch() - 1.0
     t0 = time.time()
     while True:
         try:
-            with open(path, "rb") as f:
-                data = f.read()
-            if len(data) == ID_BYTES:
-                return data
+            if os.stat(path).st_mtime >= not_before:
+                with open(path, "rb") as f:
+                    data = f.read()
+                if len(data) == ID_BYTES:
+                    return data
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout:

@@ -134,7 +134,7 @@ struct plsa_ctx {
     int comm_rank = 0, comm_world = 1;
     bool sharded = false;            // PLSA_SHARDED fit in progress: accumulators / likelihoods are all-reduced
     DevBuf comm_send, comm_recv, comm_small;
-    float *comm_host = nullptr;      // pinned landing buffer of plsa_comm_allgather_components_pinned
+    float *comm_host = nullptr;      // pinned landing buffer of plsa_comm_allgather_stack
     size_t comm_host_cap = 0;
 
     // timing
@@ -564,6 +564,9 @@ int upload_sw(plsa_ctx *c, const float *sw, const float **d_sw) {
     if (!sw) return 0;
     CHK(ensure(c, c->sw, sizeof(float) * (size_t)c->n));
     HIPCHK(c, hipMemcpyAsync(c->sw.p, sw, sizeof(float) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+    // `sw` is borrowed for the call only (it may be a temporary of the caller): the copy must have left the host
+    // buffer before any stream-ordered entry point (plsa_em_accumulate) returns
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     *d_sw = c->sw.as<float>();
     return 0;
 }
@@ -1459,7 +1462,10 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
         bool stopped = false;
         for (int i = 0; i < n_iter; ++i) {
             int blocks = 0;
-            if (c->overlap && (double)c->nnz * c->kp < c->overlap_full_limit) {
+            // PLSA_SHARDED: every collective of the communicator goes on c->stream in program order (accumulator
+            // all-reduce, then the likelihood all-reduce) -- no second stream, identical order on every rank
+            const bool overlap = c->overlap && !c->sharded;
+            if (overlap && (double)c->nnz * c->kp < c->overlap_full_limit) {
                 // small problems leave CUs idle inside each kernel (measured: config 1 0.50 -> 0.37 ms,
                 // config 2 0.43 -> 0.37 ms per iteration; neutral at config 3, -6 % at config 5):
                 // the document pass (VALU-heavy, gathers the small topic table) and the column chain
@@ -1479,7 +1485,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
                 CHK(run_row_pass(c, false, pending || first_ll_in_pass, d_sw, thresh, nullptr, &blocks));
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-            } else if (c->overlap) {
+            } else if (overlap) {
                 // large problems: both passes saturate the memory system on their own (running them
                 // side by side is neutral at config 3, -6 % at config 5), but the short chain of
                 // column sums / normalisation after the column pass leaves the chip nearly idle --
@@ -1701,42 +1707,48 @@ int plsa_comm_barrier(plsa_ctx *c) {
     return 0;
 }
 
-// the np.vstack of enstop_.py:231 across GPUs: every rank contributes its current P(w|z) [k, m]
-int plsa_comm_allgather_components(plsa_ctx *c, float *out_host) {
+// ---- member stack: the np.vstack of enstop_.py:231 without leaving the GPU ----------------------------
+// The topic matrices of the ensemble members a process fits are kept in one device block [slots][k][m]
+// (plsa_copy_components_to_device writes a slot -- from this context or from another context of the same
+// device: members of a small corpus are fitted by several contexts at once).
+int plsa_stack_reserve(plsa_ctx *c, int64_t slots, int64_t m, int32_t k, void **base_device) {
     HIPCHK(c, hipSetDevice(c->device));
-    CHK(need_factors(c));
-    const size_t count = (size_t)c->k * c->m;
-    CHK(ensure(c, c->comm_send, sizeof(float) * count));
-    CHK(ensure(c, c->comm_recv, sizeof(float) * count * (size_t)c->comm_world));
-    dim3 grid((unsigned)((c->m + 31) / 32), (unsigned)((c->kp + 31) / 32));
-    float *dst = c->comm ? c->comm_send.as<float>() : c->comm_recv.as<float>();
-    hipLaunchKernelGGL(plsa::k_vt_to_v, grid, dim3(256), 0, c->stream, c->Vt[c->cv].as<float>(), dst, c->k, (int)c->m, c->kp);
-    CHK(launch_check(c, "k_vt_to_v"));
-    if (c->comm) {
-        Scope s(c, "rccl_allgather_components");
-        NCCLCHK(c, ncclAllGather(c->comm_send.p, c->comm_recv.p, count, ncclFloat, c->comm, c->stream));
-    }
-    if (out_host)
-        HIPCHK(c, hipMemcpyAsync(out_host, c->comm_recv.p, sizeof(float) * count * (size_t)c->comm_world,
-                                 hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (slots < 1 || m < 1 || k < 1 || !base_device) return fail(c, "plsa_stack_reserve: bad arguments");
+    CHK(ensure(c, c->comm_send, sizeof(float) * (size_t)slots * (size_t)k * (size_t)m));
+    *base_device = c->comm_send.p;
     return 0;
 }
 
-// same exchange, landing in a page-locked host buffer owned by the context (a pageable destination
-// costs a staged copy: ~3x slower for the 205 MB stack of 8 x (64 x 100 k) topics); *host stays valid
-// until the next call on this context
-int plsa_comm_allgather_components_pinned(plsa_ctx *c, float **host) {
+// One exchange for the whole ensemble: slot s of every rank is all-gathered into [s][rank] (all slots in ONE
+// grouped RCCL launch), so the gathered block is the stack in RUN order -- run r was fitted by rank r % world
+// in slot r / world (enstop_amd/enstop_.py) -- and goes to a page-locked host buffer in one copy.  Without a
+// communicator (one process) it is the device stack itself.  *host: [slots * world][k][m], valid until the next
+// call on this context.
+int plsa_comm_allgather_stack(plsa_ctx *c, int64_t slots, int64_t m, int32_t k, float **host) {
     HIPCHK(c, hipSetDevice(c->device));
-    CHK(need_factors(c));
-    if (!host) return fail(c, "plsa_comm_allgather_components_pinned: NULL");
-    const size_t bytes = sizeof(float) * (size_t)c->k * c->m * (size_t)c->comm_world;
+    if (slots < 1 || m < 1 || k < 1 || !host) return fail(c, "plsa_comm_allgather_stack: bad arguments");
+    const size_t km = (size_t)k * (size_t)m, world = (size_t)c->comm_world;
+    if (c->comm_send.cap < sizeof(float) * (size_t)slots * km)
+        return fail(c, "plsa_comm_allgather_stack: no stack of %lld slots reserved (plsa_stack_reserve)", (long long)slots);
+    const size_t bytes = sizeof(float) * (size_t)slots * km * world;
     if (c->comm_host_cap < bytes) {
         if (c->comm_host) { HIPCHK(c, hipHostFree(c->comm_host)); c->comm_host = nullptr; c->comm_host_cap = 0; }
         HIPCHK(c, hipHostMalloc((void **)&c->comm_host, bytes, hipHostMallocDefault));
         c->comm_host_cap = bytes;
     }
-    CHK(plsa_comm_allgather_components(c, c->comm_host));
+    const float *src = c->comm_send.as<float>();
+    if (c->comm) {
+        CHK(ensure(c, c->comm_recv, bytes));
+        Scope s(c, "rccl_allgather_stack");
+        NCCLCHK(c, ncclGroupStart());
+        for (int64_t sl = 0; sl < slots; ++sl)
+            NCCLCHK(c, ncclAllGather(c->comm_send.as<float>() + (size_t)sl * km,
+                                     c->comm_recv.as<float>() + (size_t)sl * world * km, km, ncclFloat, c->comm, c->stream));
+        NCCLCHK(c, ncclGroupEnd());
+        src = c->comm_recv.as<float>();
+    }
+    HIPCHK(c, hipMemcpyAsync(c->comm_host, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     *host = c->comm_host;
     return 0;
 }

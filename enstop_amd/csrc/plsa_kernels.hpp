@@ -653,7 +653,7 @@ __device__ __forceinline__ void col_reduce_body(const int *__restrict__ item_fir
         const int i0 = item_first[c], i1 = item_first[c + 1];
 #pragma unroll
         for (int j = 0; j < CH; ++j) acc[j] = zero4();
-        constexpr int B = 4;
+        constexpr int B = 4;   // rows in flight per group (16 measured slower: 281 against 285 iterations/s at config 3)
         for (int it = i0 + gid; it < i1; it += GPB * B) {
             float4 p[B][CH];
 #pragma unroll

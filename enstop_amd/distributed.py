@@ -36,18 +36,20 @@ def broadcast_seed():
     return int(c.broadcast_array(seed, root=0)[0])
 
 
-def gather_topics(mine, n_runs, k, m, eng=None):
-    """mine: {run index -> (k, m) float32 topics computed by this rank}.  Returns the
-    (n_runs * k, m) stack in run order on every rank."""
+def gather_host_stack(local, n_runs):
+    """Host form of `gather_stack`: `local` [slots, k, m] holds this rank's members (slot s = run s * world + rank).
+    What the communicators without a device path do after bringing the device stack to the host."""
     c = _comm.current()
-    if c.world == 1:
-        return np.vstack([mine[r] for r in range(n_runs)])
-    per_rank = (n_runs + c.world - 1) // c.world
-    send = np.zeros((per_rank, k, m), np.float32)
-    for slot, r in enumerate(range(c.rank, n_runs, c.world)):
-        send[slot] = mine[r]
-    recv = c.allgather_array(send)                     # [world, per_rank, k, m]
-    out = np.empty((n_runs * k, m), np.float32)
-    for r in range(n_runs):
-        out[r * k:(r + 1) * k] = recv[r % c.world, r // c.world]
-    return out
+    g = c.gather_host_stack(local)
+    return g[:n_runs].reshape(n_runs * g.shape[1], g.shape[2])
+
+
+def gather_stack(eng, n_runs, k, m):
+    """The (n_runs * k, m) stack of all members in run order on every rank -- the np.vstack of
+    enstop/enstop_.py:231.  `eng` holds this rank's members in its device stack (slot s = run s * world + rank,
+    written by Engine.copy_components_to_device); with RCCL the stacks are exchanged device to device by ONE
+    grouped all-gather and reach the host in ONE copy (plsa_comm_allgather_stack)."""
+    c = _comm.current()
+    slots = (n_runs + c.world - 1) // c.world
+    g = c.gather_stack(eng, slots, k, m)                # [slots * world, k, m]
+    return g[:n_runs].reshape(n_runs * k, m)

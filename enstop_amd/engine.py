@@ -28,6 +28,10 @@ def default_device():
     if dev > 0:
         cnt = C.c_int(0)
         if _lib.load().plsa_device_count(C.byref(cnt)) == 0 and 0 < cnt.value <= dev:
+            if cnt.value != 1:
+                raise RuntimeError("LOCAL_RANK=%d but only %d GPUs are visible: start one rank per visible GPU, "
+                                   "narrow the devices to one per rank (HIP_VISIBLE_DEVICES), or set "
+                                   "ENSTOP_AMD_DEVICE" % (dev, cnt.value))
             dev = 0
     return dev
 
@@ -273,18 +277,22 @@ class Engine:
     def comm_barrier(self):
         self._ok(self._L.plsa_comm_barrier(self._h))
 
-    def comm_allgather_components(self, want_host=True, pinned=False):
-        """[world, k, m] float32: every rank's current P(w|z) (one ncclAllGather on the engine's stream).
-        pinned=True: a VIEW of a page-locked buffer owned by the engine, overwritten by the next call."""
+    def stack_reserve(self, slots, k, m):
+        """Device block [slots][k][m] for the topic matrices of the members this process fits; returns its
+        device address (slot s lives at base + 4 * s * k * m)."""
+        base = C.c_void_p()
+        self._ok(self._L.plsa_stack_reserve(self._h, int(slots), int(m), int(k), C.byref(base)))
+        return int(base.value)
+
+    def comm_allgather_stack(self, slots, k, m, copy=True):
+        """[slots * world, k, m] float32 in run order (run r = slot r // world of rank r % world): one grouped
+        ncclAllGather + one copy to page-locked host memory.  copy=False: a VIEW of that buffer, overwritten by
+        the next call on this engine."""
         _, world = self.comm_info()
-        _, m, _ = self.shape
-        if want_host and pinned:
-            p = C.POINTER(C.c_float)()
-            self._ok(self._L.plsa_comm_allgather_components_pinned(self._h, C.byref(p)))
-            return np.ctypeslib.as_array(p, shape=(world, self.k, m))
-        out = np.empty((world, self.k, m), np.float32) if want_host else None
-        self._ok(self._L.plsa_comm_allgather_components(self._h, ptr(out)))
-        return out
+        p = C.POINTER(C.c_float)()
+        self._ok(self._L.plsa_comm_allgather_stack(self._h, int(slots), int(m), int(k), C.byref(p)))
+        a = np.ctypeslib.as_array(p, shape=(int(slots) * world, int(k), int(m)))
+        return a.copy() if copy else a
 
     def comm_allgather_host(self, a):
         a = np.ascontiguousarray(a)

@@ -33,19 +33,28 @@ def concurrent_members(nnz, k, n_jobs):
     return int(min(n_jobs, CONCURRENT_MEMBERS_MAX))
 
 
-def _fit_members(A, k, runs, seeds, member_kw, device, n_jobs):
-    """{run -> topics} for the given runs of an ensemble on this process' GPU; run r draws from
-    RandomState(seeds[r]) whichever engine or thread fits it, so the result does not depend on `n_jobs`."""
+last_ensemble_timing = {}      # seconds spent by the last multi-member call of this process (bench.py reports it)
+
+
+def _fit_members(A, k, runs, seeds, member_kw, device, n_jobs, world=1, n_runs=None):
+    """Fits the given runs of an ensemble on this process' GPU and leaves their topic matrices in the device
+    stack of the process-wide engine (run r -> slot r // world); run r draws from RandomState(seeds[r]) whichever
+    engine or thread fits it, so the result does not depend on `n_jobs`.  Returns (engine, slots)."""
     jobs = min(concurrent_members(A.nnz, k, n_jobs), max(len(runs), 1))
     engines = get_member_engines(device, jobs)
     for e in engines[1:]:
         e.upload_csr(A)                  # (the first one holds the corpus already)
-    out, errors = {}, []
+    m = A.shape[1]
+    # every rank reserves the same number of slots (the all-gather is slot by slot), filled or not
+    slots = max(1, max((r // world for r in runs), default=0) + 1) if n_runs is None else max(1, (n_runs + world - 1) // world)
+    base = engines[0].stack_reserve(slots, k, m)
+    errors = []
 
     def work(j):
         try:
             for r in runs[j::jobs]:
-                out[r] = _member_on_engine(engines[j], k, random_state=np.random.RandomState(seeds[r]), **member_kw)
+                _member_on_engine(engines[j], k, random_state=np.random.RandomState(seeds[r]),
+                                  stack_dst=base + 4 * (r // world) * k * m, **member_kw)
         except BaseException as e:       # re-raised in the caller's thread
             errors.append(e)
     if jobs == 1:
@@ -58,12 +67,13 @@ def _fit_members(A, k, runs, seeds, member_kw, device, n_jobs):
             t.join()
     if errors:
         raise errors[0]
-    return out
+    return engines[0]
 
 
 def _member_on_engine(eng, k, bootstrap=True, random_state=None, init="random", n_iter=100,
-                      n_iter_per_test=10, tolerance=0.001, e_step_thresh=1e-16, flags=None):
-    """One ensemble member on a corpus already uploaded to `eng`; returns P(w|z) [k, m]."""
+                      n_iter_per_test=10, tolerance=0.001, e_step_thresh=1e-16, flags=None, stack_dst=None):
+    """One ensemble member on a corpus already uploaded to `eng`; returns P(w|z) [k, m] -- or, with
+    `stack_dst` (a device address), leaves it there and returns None."""
     n_base = eng.base_rows
     if bootstrap:
         rng = check_random_state(random_state)                       # enstop_.py:86
@@ -76,6 +86,9 @@ def _member_on_engine(eng, k, bootstrap=True, random_state=None, init="random", 
     # re-seeds it (enstop_.py:101,113 + plsa.py:707)
     _fit_on_engine(eng, k, None, init, n_iter, n_iter_per_test, tolerance, e_step_thresh,
                    random_state, flags)
+    if stack_dst is not None:
+        eng.copy_components_to_device(stack_dst)
+        return None
     _, V = eng.get_factors(want_u=False)
     return V
 
@@ -175,5 +188,11 @@ def _ensemble_of_plsa_topics(X, k, n_jobs=4, n_runs=16, parallelism="dask", **kw
     else:
         base_seed = int(random_state)
     runs = list(range(rank, n_runs, world))
-    mine = _fit_members(A, k, runs, {r: base_seed + r for r in runs}, member_kw, kwargs.get("device", None), n_jobs)
-    return distributed.gather_topics(mine, n_runs, k, A.shape[1], eng)
+    import time
+    t0 = time.perf_counter()
+    stack_eng = _fit_members(A, k, runs, {r: base_seed + r for r in runs}, member_kw, kwargs.get("device", None),
+                             n_jobs, world, n_runs)
+    t1 = time.perf_counter()
+    out = distributed.gather_stack(stack_eng, n_runs, k, A.shape[1])
+    last_ensemble_timing.update(fit_s=t1 - t0, gather_s=time.perf_counter() - t1, members=len(runs), rank=rank, world=world)
+    return out

@@ -9,14 +9,17 @@ normalisation on every rank.  The log-likelihood test is a scalar all-reduce eve
 iterations.  The loop reproduces plsa_fit_inner's stop semantics (plsa.py:630-638) with the same
 one-pass-late decision as the single-GPU fused driver.
 
-Product path (RCCL communicator, `distributed.init()`): the whole loop runs inside the C ABI --
-`plsa_fit(..., PLSA_SHARDED)` -- with the accumulator all-reduce enqueued on the engine's second stream
-underneath the document pass and no host synchronisation between likelihood tests.  The same loop also
-exists as three ABI calls (`plsa_em_accumulate`, `plsa_allreduce_accumulator` or any external all-reduce
-of the buffer `plsa_accumulator_device` exposes, `plsa_em_finish`), driven by `sharded_em` below: that
-form runs (a) on a caller's torch.distributed group and (b) inside one process over several engines on
-one device (tests: N shards without N GPUs).
+The loop is three ABI calls per iteration (`plsa_em_accumulate`, `plsa_allreduce_accumulator` -- RCCL on the
+engine's stream -- or any external all-reduce of the buffer `plsa_accumulator_device` exposes,
+`plsa_em_finish`), driven by `sharded_em` below; that form runs on the RCCL communicator (`distributed.init()`),
+on a caller's torch.distributed group, and inside one process over several engines on one device (tests: N
+shards without N GPUs).  The same loop also exists entirely inside the C ABI -- `plsa_fit(..., PLSA_SHARDED)`:
+every collective of the communicator on the context's one stream, no host synchronisation between likelihood
+tests -- behind ENSTOP_AMD_SHARDED_INLOOP=1: opt-in until a run on two real GPUs has compared it with the
+split form (a one-rank communicator is all a single-GPU box can host).
 """
+import os
+
 import numpy as np
 from sklearn.utils import check_random_state
 
@@ -118,10 +121,8 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
     same X and arguments; returns the full (P(z|d), P(w|z)) on every rank.  Same initial factors as
     `plsa_fit` for the same seed.
 
-    With the RCCL communicator the whole loop runs inside the C ABI (`plsa_fit` with PLSA_SHARDED): the
-    all-reduce of the P(w|z) accumulator is enqueued on the engine's second stream underneath the
-    document pass, the log-likelihood is one scalar all-reduce per test, nothing synchronises with the
-    host between tests.  Other communicators use the accumulate / all-reduce / finish split."""
+    Every communicator drives the accumulate / all-reduce / finish split; with the RCCL communicator and
+    ENSTOP_AMD_SHARDED_INLOOP=1 the whole loop runs inside the C ABI instead (`plsa_fit` with PLSA_SHARDED)."""
     from . import comm as _comm
     from .engine import PLSA_FUSED, PLSA_SHARDED, PLSA_STOP_NO_ZERO_ARM
     X = X.tocsr()
@@ -133,7 +134,7 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
     if sample_weight is not None and np.any(np.asarray(sample_weight) != 1.0):
         sw_all = np.asarray(sample_weight, np.float32)
 
-    native = False
+    native = on_comm_engine = False
     if local_shards:
         ranges = row_ranges_by_nnz(X.indptr, local_shards)
         engines = [Engine(device) for _ in ranges]
@@ -142,9 +143,13 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
     else:
         c = _comm.current()
         ranges = row_ranges_by_nnz(X.indptr, c.world)
-        native = isinstance(c, _comm.RcclComm)
+        # ENSTOP_AMD_SHARDED_INLOOP=1: the whole loop inside the C ABI (plsa_fit with PLSA_SHARDED).  Opt-in until a
+        # run on two real GPUs has pinned it against the split path below; the default with RCCL is the same three
+        # ABI calls per iteration every other communicator uses (accumulate / all-reduce / finish)
+        native = isinstance(c, _comm.RcclComm) and os.environ.get("ENSTOP_AMD_SHARDED_INLOOP", "0") == "1"
+        on_comm_engine = isinstance(c, _comm.RcclComm)
         # the RCCL communicator belongs to one engine: the sharded fit runs on that engine
-        engines = [c.eng if native else Engine(device)]
+        engines = [c.eng if on_comm_engine else Engine(device)]
         comm = RankComm(c)
         mine = [c.rank]
     if any(b <= a for a, b in ranges):
@@ -176,7 +181,7 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
                 U[a:b] = parts[r, :b - a]
     finally:
         for e in engines:
-            if not native:
+            if local_shards or not on_comm_engine:
                 e.close()
     if return_info:
         return U, V, dict(n_iter=iters, log_likelihood_trace=trace)

@@ -139,7 +139,11 @@ int plsa_refit(plsa_ctx *ctx, const float *sw, int32_t n_iter, int32_t n_iter_pe
  *   <all-reduce(sum) of the accumulator across ranks -- the caller's RCCL call on the pointer from
  *    plsa_accumulator_device, or plsa_accumulator_get/set through the host>
  *   plsa_em_finish       norm_pwz, division, buffer swap (identical on every rank)
- * Skipping plsa_em_finish discards the iteration (late stop decision, see plsa_fit).             */
+ * Skipping plsa_em_finish discards the iteration (late stop decision, see plsa_fit).
+ * Stream contract: `sw` has been copied when plsa_em_accumulate returns (the host buffer may be freed); the kernels
+ * of plsa_em_accumulate / plsa_em_finish are only ENQUEUED on the context's stream -- plsa_allreduce_accumulator and
+ * plsa_accumulator_get/set are ordered behind them on that stream; a caller that touches plsa_accumulator_device's
+ * buffer from a stream of its own calls plsa_synchronize first (ll_partial != NULL implies that synchronisation). */
 int plsa_em_accumulate(plsa_ctx *ctx, const float *sw, float thresh, double *ll_partial);
 int plsa_em_finish(plsa_ctx *ctx);
 int plsa_accumulator_device(plsa_ctx *ctx, void **ptr, int64_t *n_floats);
@@ -153,11 +157,18 @@ int plsa_accumulator_set(plsa_ctx *ctx, const float *host);
  *   plsa_comm_unique_id   rank 0 creates the 128-byte RCCL id (ncclGetUniqueId); the caller ships it to
  *                         the other ranks (file, environment, any side channel: enstop_amd/comm.py)
  *   plsa_comm_init        ncclCommInitRank on the context's device; collective over all ranks
- *   plsa_comm_allgather_components   every rank's current P(w|z) [k, m] -> [world, k, m] (device buffer;
- *                         copied to out_host when not NULL): ONE ncclAllGather on the context's stream
+ *   plsa_stack_reserve    device block [slots][k][m] for the topic matrices of the members THIS process fits
+ *                         (the per-thread results that enstop_.py:209-231 collects); a member's P(w|z) is stored
+ *                         into a slot with plsa_copy_components_to_device(member_ctx, base + slot * k * m)
+ *   plsa_comm_allgather_stack   the np.vstack itself: slot s of every rank -> [s][rank] in ONE grouped
+ *                         ncclAllGather launch on the context's stream, then one copy into a page-locked host
+ *                         buffer owned by the context.  Run r of the ensemble is fitted by rank r % world in
+ *                         slot r / world, so *host is the stack in run order, [slots * world][k][m] (valid until
+ *                         the next call on ctx).  Without a communicator: the local stack.
  *   plsa_allreduce_accumulator       in-place ncclAllReduce(sum) of the un-normalised P(w|z) accumulator,
  *                         stream-ordered between plsa_em_accumulate and plsa_em_finish; plsa_fit with
- *                         PLSA_SHARDED issues the same call itself underneath the document pass
+ *                         PLSA_SHARDED issues the same call itself -- every collective of a communicator goes on
+ *                         the context's one stream, in the same program order on every rank
  *   plsa_comm_allgather_host / _allreduce_f64 (op 0 sum, 1 max) / _broadcast_host / _barrier
  *                         small host payloads staged through HBM (seeds, timings, member stacks)
  * Without a communicator (world = 1) every call degenerates to the identity.                          */
@@ -167,9 +178,8 @@ int plsa_comm_init(plsa_ctx *ctx, const void *id128, int32_t rank, int32_t world
 int plsa_comm_destroy(plsa_ctx *ctx);
 int plsa_comm_info(plsa_ctx *ctx, int32_t *rank, int32_t *world);
 int plsa_comm_barrier(plsa_ctx *ctx);
-int plsa_comm_allgather_components(plsa_ctx *ctx, float *out_host /* [world, k, m] or NULL */);
-/* same, into a page-locked buffer owned by the context (*host valid until the next call on ctx) */
-int plsa_comm_allgather_components_pinned(plsa_ctx *ctx, float **host);
+int plsa_stack_reserve(plsa_ctx *ctx, int64_t slots, int64_t m, int32_t k, void **base_device);
+int plsa_comm_allgather_stack(plsa_ctx *ctx, int64_t slots, int64_t m, int32_t k, float **host);
 int plsa_comm_allgather_host(plsa_ctx *ctx, const void *send, int64_t bytes, void *recv /* world * bytes */);
 int plsa_comm_allreduce_f64(plsa_ctx *ctx, double *inout, int64_t count, int32_t op);
 int plsa_comm_broadcast_host(plsa_ctx *ctx, void *buf, int64_t bytes, int32_t root);

@@ -53,12 +53,16 @@ int main(void) {
     CHECK(plsa_comm_unique_id(id));
     CHECK(plsa_comm_init(ctx, id, 0, 1));
     CHECK(plsa_comm_info(ctx, &rank, &world));
-    float *stack = malloc(sizeof(float) * k * m), *pinned = NULL;
-    CHECK(plsa_comm_allgather_components(ctx, stack));
-    CHECK(plsa_comm_allgather_components_pinned(ctx, &pinned));
+    /* two members of an ensemble in the device stack, one grouped all-gather, one copy to pinned host memory */
+    void *base = NULL;
+    float *pinned = NULL;
+    CHECK(plsa_stack_reserve(ctx, 2, m, k, &base));
+    CHECK(plsa_copy_components_to_device(ctx, base));
+    CHECK(plsa_copy_components_to_device(ctx, (float *)base + (size_t)k * m));
+    CHECK(plsa_comm_allgather_stack(ctx, 2, m, k, &pinned));
     double gather_err = 0;
-    for (int64_t i = 0; i < (int64_t)k * m; i++) { if (fabs(stack[i] - V[i]) > gather_err) gather_err = fabs(stack[i] - V[i]);
-                                                   if (fabs(pinned[i] - V[i]) > gather_err) gather_err = fabs(pinned[i] - V[i]); }
+    for (int64_t i = 0; i < (int64_t)k * m; i++) { if (fabs(pinned[i] - V[i]) > gather_err) gather_err = fabs(pinned[i] - V[i]);
+                                                   if (fabs(pinned[(int64_t)k * m + i] - V[i]) > gather_err) gather_err = fabs(pinned[(int64_t)k * m + i] - V[i]); }
     int32_t iters2 = 0;
     CHECK(plsa_fit(ctx, NULL, 3, 5, 0.0, 1e-32f, PLSA_FUSED | PLSA_SHARDED, &iters2, NULL, NULL));
     double red[2] = {1.5, -2.0};

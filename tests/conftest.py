@@ -22,7 +22,21 @@ def load_golden(name):
 def golden_csr(g, prefix=""):
     import scipy.sparse as sp
     shape = tuple(int(v) for v in g[prefix + "shape"])
-    return sp.csr_matrix((g[prefix + "data"], g[prefix + "indices"], g[prefix + "indptr"]), shape=shape)
+    data = g[prefix + "data"] if prefix + "data" in g else g[prefix + "data_u8"].astype(np.float64)   # counts stored as uint8
+    return sp.csr_matrix((data, g[prefix + "indices"], g[prefix + "indptr"]), shape=shape)
+
+
+def peak_rel(a, b):
+    """largest deviation relative to the largest entry of b (the north-star factor tolerance is stated this way)"""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def elem_rel(a, b, floor=1e-3):
+    """largest ELEMENTWISE relative deviation over the entries of b that are at least `floor` of its largest"""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    sel = np.abs(b) >= floor * np.abs(b).max()
+    return float((np.abs(a - b)[sel] / np.abs(b)[sel]).max()) if sel.any() else 0.0
 
 
 def coo_arrays(X):

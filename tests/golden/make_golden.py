@@ -222,6 +222,30 @@ def gen_fit(name, n, m, k, density, seed, n_iter, n_iter_per_test, tol, thresh=1
     print("   %s: iters=%d ll[0]=%.6g ll[-1]=%.6g" % (name, rec.n_e, rec.ll[0], rec.ll[-1]))
 
 
+def gen_fit_big(name, n=5000, m=6000, k=4, density=0.05, seed=1, n_iter=2, fit_seed=7):
+    """A plsa_fit large enough for the reference's float32 `norm_pwz[z] += s` (plsa.py:193: ONE running
+    sum over all non-zeros per topic) to be visibly inexact: 1.5 M non-zeros, k = 4, two iterations --
+    the strict and the all-float64 builds of oracle/plsa_oracle.c differ by 3e-4 of the largest P(w|z)
+    entry here.  ~2 minutes of pure-Python reference time; CSR stored as int32 / uint8 to keep the file small."""
+    rs = np.random.RandomState(seed)
+    X = sp.random(n, m, density=density, random_state=rs, format="csr", dtype=np.float64)
+    X.data = np.ceil(X.data * 6)
+    X.sort_indices()
+    assert (np.diff(X.indptr) > 0).all()
+    sw = np.ones(n, np.float32)
+    U0, V0 = ref.plsa_init(X, k, init="random", rng=np.random.RandomState(fit_seed))
+    U0 = U0.astype(np.float32, order="C"); V0 = V0.astype(np.float32, order="C")
+    with Recorder() as rec, np.errstate(divide="ignore"):
+        U, V = ref.plsa_fit(X, k, sw, init="random", n_iter=n_iter, n_iter_per_test=10,
+                            tolerance=0.0, e_step_thresh=1e-32, random_state=fit_seed)
+    save(name, indptr=X.indptr.astype(np.int32), indices=X.indices.astype(np.int32),
+         data_u8=X.data.astype(np.uint8), shape=np.array(X.shape, dtype=np.int64), k=np.int64(k), sw=sw,
+         n_iter=np.int64(n_iter), n_iter_per_test=np.int64(10), tol=np.float64(0.0), thresh=np.float64(1e-32),
+         fit_seed=np.int64(fit_seed), U0=U0, V0=V0, U=U, V=V,
+         ll_trace=np.array(rec.ll, np.float32), iters=np.int64(rec.n_e))
+    print("   %s: nnz=%d iters=%d ll=%s" % (name, X.nnz, rec.n_e, rec.ll))
+
+
 def gen_refit(name, n, m, k, density, seed, n_iter, n_iter_per_test, tol, weighted=False):
     X = make_counts(n, m, density, seed)
     _, topics = random_factors(n, m, k, seed + 5)
@@ -408,6 +432,9 @@ def gen_combine(name, seed, t=24, m=150, min_samples=3):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "big":       # only the slow one
+        gen_fit_big("fit_k4_big")
+        sys.exit(0)
     gen_kernels("kernels_k6", n=40, m=50, k=6, density=0.15, seed=100, thresh=1e-32)
     gen_kernels("kernels_k8_thresh", n=36, m=44, k=8, density=0.2, seed=110, thresh=2.5e-3, zero_doc=3)
     gen_kernels("kernels_k20", n=64, m=200, k=20, density=0.06, seed=120, thresh=1e-16)
@@ -441,3 +468,5 @@ if __name__ == "__main__":
     gen_combine("combine_t24", seed=800)
 
     gen_fit_inner_ll_only("fit_inner_ll_only_weights", seed=900)
+
+    gen_fit_big("fit_k4_big")

@@ -27,7 +27,11 @@ WORKER = textwrap.dedent("""
     # member r is a deterministic function of r only (what per-run RandomState(seed + r) gives)
     mine = {r: np.full((k, m), float(r), np.float32) + np.arange(m, dtype=np.float32)[None, :] * 0.01
             for r in range(rank, n_runs, world)}
-    stack = distributed.gather_topics(mine, n_runs, k, m)
+    # this rank's member stack as it sits on the device: run r in slot r // world (unfilled slots hold anything)
+    local = np.full(((n_runs + world - 1) // world, k, m), -7.0, np.float32)
+    for r, v in mine.items():
+        local[r // world] = v
+    stack = distributed.gather_host_stack(local, n_runs)
     expect = np.vstack([np.full((k, m), float(r), np.float32) + np.arange(m, dtype=np.float32)[None, :] * 0.01
                         for r in range(n_runs)])
     assert stack.shape == (n_runs * k, m)
@@ -68,7 +72,10 @@ def test_gather_topics_world2_gloo(tmp_path, n_runs):
 def test_single_process_gather_is_vstack():
     from enstop_amd import distributed
     mine = {r: np.random.RandomState(r).rand(2, 5).astype(np.float32) for r in range(3)}
-    np.testing.assert_array_equal(distributed.gather_topics(mine, 3, 2, 5), np.vstack([mine[r] for r in range(3)]))
+    local = np.stack([mine[r] for r in range(3)])
+    got = distributed.gather_host_stack(local, 3)
+    np.testing.assert_array_equal(got, np.vstack([mine[r] for r in range(3)]))
+    assert not np.shares_memory(got, local)
     assert distributed.rank_world() == (0, 1)
 
 
@@ -82,7 +89,10 @@ FILE_WORKER = textwrap.dedent("""
     assert distributed.rank_world() == (rank, world)
     n_runs, k, m = 5, 3, 7
     mine = {r: np.full((k, m), float(r), np.float32) for r in range(rank, n_runs, world)}
-    stack = distributed.gather_topics(mine, n_runs, k, m)
+    local = np.full(((n_runs + world - 1) // world, k, m), -7.0, np.float32)
+    for r, v in mine.items():
+        local[r // world] = v
+    stack = distributed.gather_host_stack(local, n_runs)
     np.testing.assert_array_equal(stack, np.vstack([np.full((k, m), float(r), np.float32) for r in range(n_runs)]))
     assert c.allreduce_f64([rank + 1.0, 10.0])[0] == 3.0 and c.allreduce_f64([rank + 1.0], "max")[0] == 2.0
     got = c.broadcast_array(np.arange(4) + 100 * rank, root=1)
@@ -129,11 +139,58 @@ def test_rendezvous_file_for_waiting_ranks(tmp_path, monkeypatch):
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29999")
     monkeypatch.delenv("PLSA_COMM_ID_FILE", raising=False)
+    monkeypatch.delenv("PLSA_LAUNCH_NONCE", raising=False)
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
     name = comm.default_id_file()
     assert "127.0.0.1" in name and "29999" in name and str(os.getppid()) in name
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run/42")                 # the launcher's nonce is part of the name
+    assert "run_42" in comm.default_id_file() and comm.default_id_file() != name
     monkeypatch.setenv("PLSA_COMM_ID_FILE", "/some/where.id")
     assert comm.default_id_file() == "/some/where.id"
     assert isinstance(comm.current(), comm.SingleComm) and comm.current().world == 1
+
+
+def test_stale_rendezvous_file_is_ignored(tmp_path):
+    """A crashed earlier launch may leave a 128-byte id at the very path this launch uses (same parent pid in a
+    container).  Waiting ranks must not take it: they only accept a file younger than their launcher, and rank 0
+    removes what it finds before it publishes."""
+    import threading
+    import time
+    from enstop_amd import comm
+    path = str(tmp_path / "rccl.id")
+    stale = bytes([7]) * 128
+    with open(path, "wb") as f:
+        f.write(stale)
+    old = comm._parent_start_epoch() - 3600.0                          # published an hour before the launcher started
+    os.utime(path, (old, old))
+    with pytest.raises(TimeoutError):
+        comm.rendezvous_id(1, path, timeout=0.3)                        # the stale file is not accepted
+    fresh = bytes(range(128))
+
+    def publish():                                                      # what rank 0 does (without needing a GPU)
+        time.sleep(0.2)
+        os.unlink(path)
+        fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(fresh)
+        os.replace(path + ".tmp", path)
+    t = threading.Thread(target=publish)
+    t.start()
+    assert comm.rendezvous_id(1, path, timeout=30) == fresh
+    t.join()
+    assert (os.stat(path).st_mode & 0o777) == 0o600
+
+
+def test_file_comm_refuses_left_over_files(tmp_path, monkeypatch):
+    from enstop_amd import comm
+    monkeypatch.setenv("PLSA_LAUNCH_NONCE", "abc")
+    c = comm.FileComm(str(tmp_path / "x"), 0, 1)
+    c.barrier(); c.barrier()
+    assert len([f for f in os.listdir(c.dir) if f.endswith(".npy")]) == 1   # older exchanges are deleted
+    with pytest.raises(RuntimeError):
+        comm.FileComm(str(tmp_path / "x"), 0, 1)                             # same launch token, files present
+    monkeypatch.setenv("PLSA_LAUNCH_NONCE", "def")
+    comm.FileComm(str(tmp_path / "x"), 0, 1).barrier()                      # a new launch gets a fresh directory
 
 
 def test_bench_refuses_gpus_world_mismatch(tmp_path):

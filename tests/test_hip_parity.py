@@ -6,11 +6,13 @@ Tolerances (BASELINE.json north_star): 1e-5 relative on the log-likelihood, 1e-4
 matrices (measured relative to the largest entry of the matrix, the scale at which a probability
 table is meaningful).  Kernel-level single steps are held to much tighter bounds.
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from conftest import load_golden, golden_csr, coo_arrays
+from conftest import load_golden, golden_csr, coo_arrays, peak_rel, elem_rel, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -126,6 +128,12 @@ def test_fit_vs_reference(amd, case, mode):
     close_ll(info["log_likelihood_trace"], g["ll_trace"])
     close_factors(U, g["U"])
     close_factors(V, g["V"])
+    # ... and ELEMENTWISE over every entry that is at least 1e-3 of the largest (a peak-relative bound alone says
+    # nothing about the small entries).  With a large threshold (fit_k8_thresh, 2e-3) single responsibilities
+    # flip on last-bit differences, between builds of the reference itself too: that case keeps the peak bound only
+    if float(g["thresh"]) <= 1e-16:
+        assert elem_rel(U, g["U"]) <= 1e-3, elem_rel(U, g["U"])
+        assert elem_rel(V, g["V"]) <= 1e-3, elem_rel(V, g["V"])
 
 
 @pytest.mark.parametrize("mode", ["materialised", "fused"])
@@ -226,6 +234,7 @@ def test_fit_vs_oracle(amd, oracle, k, mode):
     close_ll(info["log_likelihood_trace"], trace)
     close_factors(U, Uo)
     close_factors(V, Vo)
+    assert elem_rel(U, Uo) <= 1e-3 and elem_rel(V, Vo) <= 1e-3, (elem_rel(U, Uo), elem_rel(V, Vo))
     # rows of an empty document stay exactly zero (plsa.py:200-202 guard)
     empty = np.diff(X.indptr) == 0
     assert empty.sum() == 3 and np.all(U[empty] == 0.0)
@@ -664,9 +673,23 @@ def test_native_rccl_communicator_single_rank(amd):
         sw = (0.5 + rs.rand(3000)).astype(np.float32)
         kw = dict(n_iter=8, n_iter_per_test=3, tolerance=0.0, random_state=1)
         U1, V1, i1 = amd.plsa_fit(X, 32, sw, return_info=True, **kw)
-        np.testing.assert_array_equal(c.allgather_components(eng)[0], V1)
-        np.testing.assert_array_equal(eng.comm_allgather_components(pinned=True)[0], V1)
-        U2, V2, i2 = amd.sharded_plsa_fit(X, 32, sw, return_info=True, **kw)      # native PLSA_SHARDED loop
+        # the ensemble exchange of the product: members stored into the device stack, ONE grouped ncclAllGather,
+        # ONE copy to page-locked host memory (plsa_stack_reserve / plsa_comm_allgather_stack)
+        m_ = X.shape[1]
+        base = eng.stack_reserve(2, 32, m_)
+        eng.copy_components_to_device(base)
+        eng.copy_components_to_device(base + 4 * 32 * m_)
+        np.testing.assert_array_equal(c.gather_stack(eng, 2, 32, m_), np.stack([V1, V1]))
+        np.testing.assert_array_equal(amd.distributed.gather_stack(eng, 2, 32, m_), np.vstack([V1, V1]))
+        monkey_env = dict(os.environ)
+        os.environ["ENSTOP_AMD_SHARDED_INLOOP"] = "1"
+        try:
+            U2, V2, i2 = amd.sharded_plsa_fit(X, 32, sw, return_info=True, **kw)      # PLSA_SHARDED loop inside the ABI
+        finally:
+            os.environ.clear(); os.environ.update(monkey_env)
+        U3, V3, i3 = amd.sharded_plsa_fit(X, 32, sw, return_info=True, **kw)          # default: three calls per iteration
+        assert i3["n_iter"] == i2["n_iter"]
+        np.testing.assert_array_equal(V3, V2); np.testing.assert_array_equal(U3, U2)
         assert i1["n_iter"] == i2["n_iter"]
         # (the sharded loop normalises from the all-reduced accumulator, the plain loop from the column
         # pass' own sums: same value, different float64 summation order)
@@ -1124,8 +1147,15 @@ def test_device_all_pairs_kl_vs_reference(amd):
     T = rs.dirichlet(np.full(3001, 0.05), size=150).astype(np.float32)
     T[T < 1e-7] = 0.0
     T[7] = 0.0
-    from enstop_amd.ensemble import all_pairs_kl_divergence
-    ref = all_pairs_kl_divergence(T)
+    # float64 statement of enstop_.py:234-253 written here (not the product's host function):
+    # D[i, j] = sum over the words with a[w] > 0 and b[w] > 0 of a[w] * (log2 a[w] - log2 b[w])
+    A = T.astype(np.float64)
+    ref = np.zeros((A.shape[0], A.shape[0]))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        L = np.where(A > 0, np.log2(A), 0.0)
+        for i in range(A.shape[0]):
+            both = (A[i] > 0)[None, :] & (A > 0)
+            ref[i] = np.where(both, A[i][None, :] * (L[i][None, :] - L), 0.0).sum(axis=1)
     got = amd.engine.get_engine().all_pairs_kl(T)
     assert np.abs(got - ref).max() <= 5e-6 * np.abs(ref).max()
 
@@ -1176,3 +1206,50 @@ def test_zero_threshold_with_denormal_products(amd, oracle, mode):
                        flags=MODES[mode])
     assert np.all(np.isfinite(U)) and np.all(np.isfinite(V))
     close_factors(U, Uo, tol=2e-4); close_factors(V, Vo, tol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference-generated fit at which the reference's float32 arithmetic is visibly inexact
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", list(MODES))
+def test_big_fit_vs_reference_and_exact_arithmetic(amd, mode):
+    """fit_k4_big: 1.5 M non-zeros, k = 4, two iterations, produced by the reference itself (make_golden.py big).
+    tests/test_oracle_golden.py shows on the CPU that the strict oracle reproduces it bit for bit and that the
+    all-float64 build of the same algorithm is > 1e-4 away from it.  Here: the HIP engine agrees with EXACT
+    arithmetic to 1e-5 and its distance to the reference is the reference's own distance to exact arithmetic --
+    above ~1e6 non-zeros "within 1e-4 of the reference" is not attainable by anything more accurate than it."""
+    from oracle.plsa_oracle import Oracle
+    g = load_golden("fit_k4_big")
+    X = golden_csr(g)
+    kw = dict(n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+              e_step_thresh=float(g["thresh"]), random_state=int(g["fit_seed"]))
+    wide = Oracle(variant="wide")
+    wide.set_threads(8)
+    Uw, Vw, trace_w, _ = wide.plsa_fit(X, int(g["k"]), g["sw"], return_trace=True, **kw)
+    U, V, info = amd.plsa_fit(X, int(g["k"]), g["sw"], flags=MODES[mode], return_info=True, **kw)
+    assert info["n_iter"] == int(g["iters"])
+    ref_vs_exact = peak_rel(g["V"], Vw)
+    assert ref_vs_exact > 1e-4                                          # the reference's own error (CPU test)
+    assert peak_rel(V, Vw) <= 1e-5 and peak_rel(U, Uw) <= 1e-5, (peak_rel(V, Vw), peak_rel(U, Uw))
+    assert elem_rel(V, Vw) <= 1e-4 and elem_rel(U, Uw) <= 1e-4
+    assert peak_rel(V, g["V"]) <= 1.5 * ref_vs_exact, (peak_rel(V, g["V"]), ref_vs_exact)
+    assert peak_rel(U, g["U"]) <= 1.5 * max(peak_rel(g["U"], Uw), 1e-5)
+    np.testing.assert_allclose(info["log_likelihood_trace"], trace_w, rtol=1e-6)
+    # the reference's log-likelihood is ONE float32 running sum over 1.5 M terms (plsa.py:322, 375-384): 2e-3 off
+    # the exact value here -- 200 times the north-star tolerance -- and HIP is that far from it, no further
+    ll = info["log_likelihood_trace"].astype(np.float64)
+    ref_ll_err = np.abs(g["ll_trace"].astype(np.float64) - trace_w).max() / np.abs(trace_w).max()
+    assert ref_ll_err > 1e-4
+    assert np.abs(ll - g["ll_trace"]).max() / np.abs(trace_w).max() <= 1.5 * ref_ll_err
+
+
+def test_fuzz_slice(amd):
+    """A bounded slice (200 cases, ~1 minute) of tests/fuzz_parity.py -- seeded random corpora with odd k, empty /
+    heavy rows and columns, thresholds, sample weights, early stopping, refit, under five structure-knob sets and
+    both schedules, each against the pinned oracle -- inside the collected suite."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "200", "3"],
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "mismatches 0" in out.stdout

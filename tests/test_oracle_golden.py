@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import load_golden, golden_csr, coo_arrays
+from conftest import load_golden, golden_csr, coo_arrays, peak_rel
 
 KERNEL_CASES = ["kernels_k6", "kernels_k8_thresh", "kernels_k20", "kernels_k33"]
 FIT_CASES = ["fit_k8_tol0", "fit_k5_earlystop", "fit_k4_weighted", "fit_k8_thresh",
@@ -158,3 +158,26 @@ def test_wide_accumulator_variants_track_the_checker(variant):
         assert np.abs(U - g["U"]).max() <= 2e-5 * g["U"].max()
         assert np.abs(V - g["V"]).max() <= 2e-5 * g["V"].max()
         np.testing.assert_allclose(trace, g["ll_trace"], rtol=3e-6)
+
+
+def test_big_fit_pins_the_float32_stagnation(oracle):
+    """fit_k4_big (1.5 M non-zeros, k = 4, two iterations, generated by the reference itself): large enough for the
+    reference's single float32 running sum `norm_pwz[z] += s` (plsa.py:193) to be visibly inexact.
+    (i) the strict oracle still reproduces the reference bit for bit, (ii) the all-float64 build of the same
+    algorithm is more than 1e-4 of the largest P(w|z) entry away from it: at this size and beyond, "matches the
+    reference" and "matches exact arithmetic" are different statements, and the reference is the inexact side."""
+    from oracle.plsa_oracle import Oracle
+    g = load_golden("fit_k4_big")
+    X = golden_csr(g)
+    kw = dict(n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+              e_step_thresh=float(g["thresh"]), random_state=int(g["fit_seed"]), return_trace=True)
+    U, V, trace, iters = oracle.plsa_fit(X, int(g["k"]), g["sw"], **kw)
+    assert iters == int(g["iters"]) == 2
+    np.testing.assert_array_equal(U, g["U"])
+    np.testing.assert_array_equal(V, g["V"])
+    np.testing.assert_allclose(trace, g["ll_trace"], rtol=2e-5)   # float32 sum of 1.5 M terms: NumPy log vs logf
+    wide = Oracle(variant="wide")
+    wide.set_threads(1)
+    Uw, Vw, _, _ = wide.plsa_fit(X, int(g["k"]), g["sw"], **kw)
+    assert peak_rel(g["V"], Vw) > 1e-4, peak_rel(g["V"], Vw)
+    assert peak_rel(g["V"], Vw) < 1e-3 and peak_rel(g["U"], Uw) < 1e-4

@@ -891,5 +891,39 @@ int main(int argc, char **argv) {
             HC(hipFree(d_items)); HC(hipFree(d_p2)); HC(hipFree(d_cs)); HC(hipFree(d_lo)); HC(hipFree(d_te));
         }
     }
+    if (want("rowx")) {
+        // does the order of a document's entries matter?  as stored (by word id = random w.r.t. frequency) vs sorted by
+        // the word's document frequency, descending / ascending (hot words first / last)
+        for (int mode = 0; mode < 3; ++mode) {
+            std::vector<int> col2(col);
+            std::vector<float> val2(val);
+            if (mode > 0) {
+                std::vector<std::pair<int, int>> tmp;
+                for (i64 d = 0; d < n; ++d) {
+                    const int j0 = indptr[d], j1 = indptr[d + 1];
+                    tmp.resize(j1 - j0);
+                    for (int j = j0; j < j1; ++j) tmp[j - j0] = {colptr[col[j] + 1] - colptr[col[j]], j};
+                    if (mode == 1) std::stable_sort(tmp.begin(), tmp.end(), [](auto &a, auto &b) { return a.first > b.first; });
+                    else std::stable_sort(tmp.begin(), tmp.end(), [](auto &a, auto &b) { return a.first < b.first; });
+                    for (int j = j0; j < j1; ++j) { col2[j] = col[tmp[j - j0].second]; val2[j] = val[tmp[j - j0].second]; }
+                }
+            }
+            int *d_col2 = dev(col2);
+            float *d_val2 = dev(val2);
+            const char *nm = mode == 0 ? "by word id" : (mode == 1 ? "frequent words first" : "rare words first");
+            for (int rep = 0; rep < 2; ++rep) {
+                const double a = time_ms([&] { hipLaunchKernelGGL((k_row_variant<0, 4>), dim3(grid_row), dim3(256), 0, g_stream, d_indptr, d_col2, d_val2, (int)n, d_order, d_U, d_Vt, d_Un, thresh); });
+                const double b = time_ms([&] { hipLaunchKernelGGL((k_row_variant<2, 4>), dim3(grid_row), dim3(256), 0, g_stream, d_indptr, d_col2, d_val2, (int)n, d_order, d_U, d_Vt, d_Un, thresh); });
+                const double c8 = time_ms([&] { hipLaunchKernelGGL((k_row_variant<0, 8>), dim3(grid_row), dim3(256), 0, g_stream, d_indptr, d_col2, d_val2, (int)n, d_order, d_U, d_Vt, d_Un, thresh); });
+                const double s1 = time_ms([&] {
+                    hipLaunchKernelGGL((plsa::k_row_pass<S, false, false>), dim3(grid_row), dim3(256), 0, g_stream, d_indptr, d_col2, d_val2, (int)n,
+                               d_order, d_U, d_Vt, (const float *)nullptr, d_Un, (const float *)nullptr, (float *)nullptr, 64, thresh, d_ll,
+                               (const int *)nullptr, (const int *)nullptr, 64, (i64)0, (float *)nullptr); });
+                printf("{\"test\": \"row_entry_order\", \"order\": \"%s\", \"rep\": %d, \"full_unr4_ms\": %.4f, \"gather_only_unr4_ms\": %.4f, \"full_unr8_ms\": %.4f, \"shipped_ms\": %.4f}\n", nm, rep, a, b, c8, s1);
+                fflush(stdout);
+            }
+            HC(hipFree(d_col2)); HC(hipFree(d_val2));
+        }
+    }
     return 0;
 }
