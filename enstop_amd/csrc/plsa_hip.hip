@@ -116,6 +116,7 @@ struct plsa_ctx {
     DevBuf item_end, colsum_rows, colsum_rows2;
     // column-pass schedule: visiting-order item records, chunk boundaries per XCD (measured, see ensure_balance)
     DevBuf item_rec, xcd_lo, t_end;
+    bool graph = false;              // PLSA_GRAPH=1: hipGraph replay of the iterations between two likelihood tests
     int order_band = -1;             // PLSA_ORDER_BAND: documents per band of the visiting order (-1 auto, 0 first-document order)
     int balance = -1;                // PLSA_BALANCE: -1 auto (large problems), 0 equal stretches, 1 always measure
     bool bal_valid = false;          // xcd_lo matches the current structure
@@ -718,7 +719,7 @@ void balance_set_lo(plsa_ctx *c, int n_chunks) {
 
 // Measured XCD boundaries of the column pass (see k_col_pass).  `launch(timed)` enqueues one column pass on c->ls.
 // Equal stretches first (or the fractions measured for the previous structure on this context: a bootstrap
-// resample of the same corpus has the same profile and needs at most one refinement), then up to four timed
+// resample of the same corpus has the same profile and gets one measurement + one correction), then up to five timed
 // launches: every workgroup records its end time, an XCD's time is its last workgroup's, and every stretch is
 // resized by (mean time / own time), damped -- until the eight finish within 2 % of each other.  Results never
 // depend on the boundaries (partials are per item, norm_pwz rows per chunk), only the speed does.
@@ -738,7 +739,7 @@ int ensure_balance(plsa_ctx *c, int grid, int n_chunks, bool split, Launch &&lau
     if (tune) {
         CHK(ensure(c, c->t_end, sizeof(unsigned long long) * ((size_t)grid + 1)));
         std::vector<unsigned long long> te((size_t)grid + 1);
-        const int max_launches = warm ? 2 : 5;
+        const int max_launches = warm ? 1 : 5;     // a resample of the same corpus: one measurement, one correction
         for (int it = 0; it < max_launches; ++it) {
             HIPCHK(c, hipMemsetAsync(c->t_end.p, 0, sizeof(unsigned long long) * ((size_t)grid + 1), c->ls));
             CHK(launch(true));
@@ -755,7 +756,7 @@ int ensure_balance(plsa_ctx *c, int grid, int n_chunks, bool split, Launch &&lau
                 c->bal_end_us[x] = T[x];
                 mean += T[x] / 8.0; lo_t = std::min(lo_t, T[x]); hi_t = std::max(hi_t, T[x]);
             }
-            if ((hi_t - lo_t) <= 0.02 * mean || it == max_launches - 1) break;
+            if ((hi_t - lo_t) <= 0.02 * mean) break;
             double size[8], tot = 0.0;
             for (int x = 0; x < 8; ++x) {
                 size[x] = std::max(1e-6, (c->bal_frac[x + 1] - c->bal_frac[x]) * (1.0 + 0.8 * (mean / T[x] - 1.0)));
@@ -999,8 +1000,15 @@ int plsa_create(int device, plsa_ctx **out) {
         return fail(nullptr, "libplsa_hip is built for gfx950 (MI355X) only; device %d is %s", device,
                     arch.c_str());
     }
+    // the second stream carries the short column tail underneath the document pass: highest priority, so that its
+    // few workgroups are placed as soon as slots free up instead of queueing behind the pass' 32 k workgroups
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const char *prio_env = getenv("PLSA_TAIL_PRIORITY");
+    const bool tail_prio = !prio_env || atoi(prio_env) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        (tail_prio ? hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi)
+                   : hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&c->h_ll, sizeof(double) * 2, hipHostMallocDefault) != hipSuccess) {
@@ -1024,6 +1032,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_XCD_SPLIT")) c->xcd_split = atoi(s) != 0;
     if (const char *s = getenv("PLSA_BALANCE")) c->balance = atoi(s);
     if (const char *s = getenv("PLSA_ORDER_BAND")) c->order_band = atoi(s);
+    if (const char *s = getenv("PLSA_GRAPH")) c->graph = atoi(s) != 0;
     if (const char *s = getenv("PLSA_CHUNKS_PER_LANE")) c->chunks_per_lane = atoi(s);
     if (const char *s = getenv("PLSA_E_ROWS")) c->e_rows = atoi(s);
     if (const char *s = getenv("PLSA_E_SEG")) c->eseg_override = atoi(s);
@@ -1460,8 +1469,8 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
     } else {
         bool pending = false;  // a test is due on the factors currently in (cu, cv)
         bool stopped = false;
-        for (int i = 0; i < n_iter; ++i) {
-            int blocks = 0;
+        // one fused EM iteration from the factors in (cu, cv) into the alternate buffers (no swap here)
+        auto enqueue_iteration = [&](bool want_ll, int *blocks) -> int {
             // PLSA_SHARDED: every collective of the communicator goes on c->stream in program order (accumulator
             // all-reduce, then the likelihood all-reduce) -- no second stream, identical order on every rank
             const bool overlap = c->overlap && !c->sharded;
@@ -1483,7 +1492,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 c->ls = c->stream;
                 if (rc) return rc;
                 HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
-                CHK(run_row_pass(c, false, pending || first_ll_in_pass, d_sw, thresh, nullptr, &blocks));
+                CHK(run_row_pass(c, false, want_ll, d_sw, thresh, nullptr, blocks));
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
             } else if (overlap) {
                 // large problems: both passes saturate the memory system on their own (running them
@@ -1498,13 +1507,54 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 c->ls = c->stream;
                 if (rc) return rc;
                 HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
-                CHK(run_row_pass(c, false, pending || first_ll_in_pass, d_sw, thresh, nullptr, &blocks));
+                CHK(run_row_pass(c, false, want_ll, d_sw, thresh, nullptr, blocks));
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
             } else {
-                CHK(run_row_pass(c, false, pending || first_ll_in_pass, d_sw, thresh, nullptr, &blocks));
+                CHK(run_row_pass(c, false, want_ll, d_sw, thresh, nullptr, blocks));
                 CHK(run_col_pass(c, false, d_sw_m, thresh, 1));
                 CHK(run_col_tail(c));
             }
+            return 0;
+        };
+        // PLSA_GRAPH (flag or environment): the iterations between two likelihood tests replayed from a hipGraph
+        // of TWO iterations (the double buffers alternate, a pair returns to the starting buffers; the single
+        // eager iteration of a likelihood test flips the parity, hence one graph per starting pair), captured
+        // from the launch sequence above.  Kernel arguments are baked into the graph, so it lives for this
+        // call only.  Off by default: measured neutral (the host is not the bound, and a dependent kernel
+        // boundary costs the same 1.5 us eager or replayed)
+        const bool use_graph = ((flags & PLSA_GRAPH) || c->graph) && !c->sharded && !c->timing;
+        hipGraphExec_t gexecs[4] = {nullptr, nullptr, nullptr, nullptr};   // one per starting buffer pair (cu, cv)
+        struct GraphGuard {
+            hipGraphExec_t (&g)[4];
+            ~GraphGuard() { for (auto e : g) if (e) (void)hipGraphExecDestroy(e); }
+        } graph_guard{gexecs};
+        for (int i = 0; i < n_iter; ++i) {
+            int blocks = 0;
+            const bool want_ll = pending || first_ll_in_pass;
+            if (use_graph && !want_ll && i + 1 < n_iter && (i % n_iter_per_test) != 0) {
+                // iterations i and i + 1, neither carries a likelihood test
+                hipGraphExec_t &gexec = gexecs[c->cu * 2 + c->cv];
+                if (!gexec) {
+                    hipGraph_t graph = nullptr;
+                    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                    int rc = enqueue_iteration(false, &blocks);
+                    c->cu ^= 1; c->cv ^= 1;
+                    if (!rc) rc = enqueue_iteration(false, &blocks);
+                    c->cu ^= 1; c->cv ^= 1;
+                    const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
+                    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+                    HIPCHK(c, e_end);
+                    const hipError_t e_inst = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(graph);
+                    HIPCHK(c, e_inst);
+                }
+                HIPCHK(c, hipGraphLaunch(gexec, c->stream));
+                iters += 2;
+                ++i;
+                pending = (i % n_iter_per_test == 0);
+                continue;
+            }
+            CHK(enqueue_iteration(want_ll, &blocks));
             if (first_ll_in_pass) {
                 CHK(finish_ll(c, blocks, &ll));
                 prev = (float)ll;

@@ -40,6 +40,8 @@ enum {
                            enstop/plsa.py:591, 606-628, 631                                         */
     PLSA_STOP_NO_ZERO_ARM = 16, /* plsa_fit: stop test of enstop/block_parallel_plsa.py:329-331
                            (`change / |cur| < tolerance` only, no `change == 0` arm)               */
+    PLSA_GRAPH     = 128, /* plsa_fit (fused): replay the iterations between two likelihood tests from a hipGraph
+                           of two iterations captured from the same launch sequence; results identical           */
     PLSA_SHARDED   = 64 /* plsa_fit: the context's rows are ONE SHARD of the corpus; the P(w|z)
                            accumulator and the log-likelihood are all-reduced over the context's RCCL
                            communicator every iteration (plsa_comm_init); every rank passes the same
