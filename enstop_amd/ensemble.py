@@ -103,8 +103,14 @@ def labels_from_mutual_reachability(mutual_reachability, min_cluster_size):
     three routines (`mst_from_mutual_reachability`, `make_single_linkage`, `tree_to_labels`).  This tree
     step is the one part of the topic combination whose parity is unpinned (hdbscan is not installable
     in the build image)."""
-    from sklearn.cluster._hdbscan._linkage import make_single_linkage, mst_from_mutual_reachability
-    from sklearn.cluster._hdbscan._tree import tree_to_labels
+    try:      # private scikit-learn modules (present in 1.3 ... 1.7): say so instead of an AttributeError deep inside
+        from sklearn.cluster._hdbscan._linkage import make_single_linkage, mst_from_mutual_reachability
+        from sklearn.cluster._hdbscan._tree import tree_to_labels
+    except ImportError as e:
+        import sklearn
+        raise ImportError("topic_combination='kl_divergence' uses the HDBSCAN internals of scikit-learn 1.3-1.7 "
+                          "(sklearn.cluster._hdbscan._linkage / ._tree); scikit-learn %s does not provide them: %s"
+                          % (sklearn.__version__, e))
     mr = np.ascontiguousarray(mutual_reachability, dtype=np.float64).copy()
     mst = mst_from_mutual_reachability(mr)
     mst = mst[np.argsort(mst["distance"])]

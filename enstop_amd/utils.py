@@ -31,7 +31,24 @@ def standardize_input(input_matrix):
 # sample-weight validation: scikit-learn's own validator, as the reference imports it by default
 # (enstop/plsa.py:9, enstop_.py:8; its vendored copy enstop/utils.py:285-335 is only a fallback for
 # scikit-learn versions that predate the function)
-from sklearn.utils.validation import _check_sample_weight  # noqa: E402,F401
+try:
+    from sklearn.utils.validation import _check_sample_weight  # noqa: E402,F401
+except ImportError:          # a private name: keep working if a scikit-learn release moves it
+    def _check_sample_weight(sample_weight, X, dtype=None):
+        """Fallback with the contract of enstop/utils.py:285-335: None -> ones, a number -> constant vector,
+        otherwise a 1-D float array of length n_samples."""
+        n = X.shape[0]
+        dtype = np.float64 if dtype is None else dtype
+        if sample_weight is None:
+            return np.ones(n, dtype=dtype)
+        if isinstance(sample_weight, (int, float, np.integer, np.floating)):
+            return np.full(n, sample_weight, dtype=dtype)
+        sw = np.asarray(sample_weight, dtype=dtype)
+        if sw.ndim != 1:
+            raise ValueError("Sample weights must be 1D array or scalar")
+        if sw.shape != (n,):
+            raise ValueError("sample_weight.shape == {}, expected {}!".format(sw.shape, (n,)))
+        return sw
 
 
 # ------------------------------------------------------------------------------------------------
