@@ -134,7 +134,7 @@ struct plsa_ctx {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     bool sharded = false;            // PLSA_SHARDED fit in progress: accumulators / likelihoods are all-reduced
-    DevBuf comm_send, comm_recv, comm_small;
+    DevBuf comm_send, comm_recv, comm_small, comm_stack;   // comm_stack: the member stack (plsa_stack_reserve)
     float *comm_host = nullptr;      // pinned landing buffer of plsa_comm_allgather_stack
     size_t comm_host_cap = 0;
 
@@ -526,9 +526,11 @@ int ensure_csc(plsa_ctx *c) {
     unsigned long long *d_key = c->tmp2.as<unsigned long long>();
     // band of the visiting order: 512 KB of P(z|d) rows (2048 documents at k = 64), PLSA_ORDER_BAND documents
     const int band = c->order_band >= 0 ? c->order_band : std::max(64, (512 << 10) / (c->kp > 0 ? c->kp * 4 : 256));
-    hipLaunchKernelGGL(plsa::k_item_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                       c->colptr.as<int>(), c->item_first.as<int>(), (int)m, c->seg, c->csc_row.as<int>(),
-                       c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(), band, d_key, c->tmp1.as<int>());
+    if (n_items > 0)
+        hipLaunchKernelGGL(plsa::k_item_fill, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, c->stream,
+                           c->colptr.as<int>(), c->item_first.as<int>(), (int)m, c->seg, c->csc_row.as<int>(),
+                           c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(), band, d_key,
+                           c->tmp1.as<int>(), n_items);
     CHK(launch_check(c, "k_item_fill"));
     if (n_items > 0) {   // visiting order: band-major, Zipf-head words first inside a band (stable)
         size_t bytes = 0;
@@ -1048,7 +1050,7 @@ void plsa_destroy(plsa_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
-    release(c->comm_send); release(c->comm_recv); release(c->comm_small);
+    release(c->comm_send); release(c->comm_recv); release(c->comm_small); release(c->comm_stack);
     if (c->comm_host) { (void)hipHostFree(c->comm_host); c->comm_host = nullptr; c->comm_host_cap = 0; }
     release(c->item_end); release(c->colsum_rows); release(c->colsum_rows2);
     release(c->item_rec); release(c->xcd_lo); release(c->t_end);
@@ -1764,8 +1766,8 @@ int plsa_comm_barrier(plsa_ctx *c) {
 int plsa_stack_reserve(plsa_ctx *c, int64_t slots, int64_t m, int32_t k, void **base_device) {
     HIPCHK(c, hipSetDevice(c->device));
     if (slots < 1 || m < 1 || k < 1 || !base_device) return fail(c, "plsa_stack_reserve: bad arguments");
-    CHK(ensure(c, c->comm_send, sizeof(float) * (size_t)slots * (size_t)k * (size_t)m));
-    *base_device = c->comm_send.p;
+    CHK(ensure(c, c->comm_stack, sizeof(float) * (size_t)slots * (size_t)k * (size_t)m));
+    *base_device = c->comm_stack.p;
     return 0;
 }
 
@@ -1778,7 +1780,7 @@ int plsa_comm_allgather_stack(plsa_ctx *c, int64_t slots, int64_t m, int32_t k, 
     HIPCHK(c, hipSetDevice(c->device));
     if (slots < 1 || m < 1 || k < 1 || !host) return fail(c, "plsa_comm_allgather_stack: bad arguments");
     const size_t km = (size_t)k * (size_t)m, world = (size_t)c->comm_world;
-    if (c->comm_send.cap < sizeof(float) * (size_t)slots * km)
+    if (c->comm_stack.cap < sizeof(float) * (size_t)slots * km)
         return fail(c, "plsa_comm_allgather_stack: no stack of %lld slots reserved (plsa_stack_reserve)", (long long)slots);
     const size_t bytes = sizeof(float) * (size_t)slots * km * world;
     if (c->comm_host_cap < bytes) {
@@ -1786,13 +1788,13 @@ int plsa_comm_allgather_stack(plsa_ctx *c, int64_t slots, int64_t m, int32_t k, 
         HIPCHK(c, hipHostMalloc((void **)&c->comm_host, bytes, hipHostMallocDefault));
         c->comm_host_cap = bytes;
     }
-    const float *src = c->comm_send.as<float>();
+    const float *src = c->comm_stack.as<float>();
     if (c->comm) {
         CHK(ensure(c, c->comm_recv, bytes));
         Scope s(c, "rccl_allgather_stack");
         NCCLCHK(c, ncclGroupStart());
         for (int64_t sl = 0; sl < slots; ++sl)
-            NCCLCHK(c, ncclAllGather(c->comm_send.as<float>() + (size_t)sl * km,
+            NCCLCHK(c, ncclAllGather(c->comm_stack.as<float>() + (size_t)sl * km,
                                      c->comm_recv.as<float>() + (size_t)sl * world * km, km, ncclFloat, c->comm, c->stream));
         NCCLCHK(c, ncclGroupEnd());
         src = c->comm_recv.as<float>();
