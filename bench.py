@@ -511,6 +511,11 @@ def main():
         # figure is ensemble.fits_per_min below
         "ensemble_fits_per_min_from_iteration_rate": round(n_gpus * args.steps / dt / FITS_ITERS * 60.0, 3),
         # north_star's roofline kernel: the per-nnz materialising E-step (HBM-bound)
+        "roofline_note": "`roofline` is north_star's roofline kernel, the per-nnz materialising E-step (timed in the second "
+                         "leg: the headline `value` runs the fused schedule, which never launches it); "
+                         "`roofline_dominant_fused` is the dominant kernel of the timed region against its COMPULSORY bytes -- "
+                         "that kernel is bound by gathered factor rows missing the L2s, not by compulsory HBM bytes: "
+                         "profiles/r03_speed_of_light.md puts both fused passes at 95-100 % of the measured row-gather bound",
         "roofline": roof("k_e_step", e_entry),
         # dominant kernel of the (fused) timed region against its own compulsory bytes; it is
         # gather/VALU-bound, not an HBM-roofline claim

@@ -20,7 +20,7 @@ downloaded for the oracle.  Every comparison is made against three builds of the
 Asserted: HIP == wide and HIP == n64 inside the north-star tolerances (factors 1e-4 of the largest entry,
 log-likelihood 1e-5 relative; measured ~1e-6), and HIP's distance to strict is no larger than strict's
 own distance to wide (i.e. the gap IS the reference's rounding, not a defect of the port).
-Every figure is written to gpurun_out/r02_parity_at_scale.json (copied to profiles/ by hand).
+Every figure is written to gpurun_out/r03_parity_at_scale.json (copied to profiles/ by hand).
 """
 import json
 import os
@@ -43,7 +43,7 @@ CONFIG2 = dict(n=100_000, m=50_000, nnz=10_000_000, k=32)
 def _flush_report():
     try:
         os.makedirs(REPORT_DIR, exist_ok=True)
-        with open(os.path.join(REPORT_DIR, "r02_parity_at_scale.json"), "w") as f:
+        with open(os.path.join(REPORT_DIR, "r03_parity_at_scale.json"), "w") as f:
             json.dump(REPORT, f, indent=1, sort_keys=True)
     except OSError:
         pass
