@@ -774,6 +774,13 @@ def test_native_rccl_two_ranks(tmp_path):
         assert i1["n_iter"] == i2["n_iter"], (i1["n_iter"], i2["n_iter"])
         np.testing.assert_allclose(i2["log_likelihood_trace"], i1["log_likelihood_trace"], rtol=1e-6)
         assert np.abs(U1 - U2).max() <= 2e-5 * U1.max() and np.abs(V1 - V2).max() <= 2e-5 * V1.max()
+        # the same loop entirely inside the C ABI (PLSA_SHARDED; opt-in until this very comparison has run on two GPUs)
+        os.environ["ENSTOP_AMD_SHARDED_INLOOP"] = "1"
+        U3, V3, i3 = enstop_amd.sharded_plsa_fit(X, 20, sw, return_info=True, **kw)
+        del os.environ["ENSTOP_AMD_SHARDED_INLOOP"]
+        assert i3["n_iter"] == i2["n_iter"]
+        np.testing.assert_allclose(i3["log_likelihood_trace"], i2["log_likelihood_trace"], rtol=1e-6)
+        assert np.abs(U3 - U2).max() <= 2e-6 * U2.max() and np.abs(V3 - V2).max() <= 2e-6 * V2.max()
         T = enstop_amd.ensemble_of_topics(X, 6, n_runs=5, n_iter=5, random_state=3)
         ref = [enstop_amd.plsa_topics(X, 6, n_iter=5, random_state=np.random.RandomState(3 + r)) for r in range(5)]
         np.testing.assert_array_equal(T, np.vstack(ref))
