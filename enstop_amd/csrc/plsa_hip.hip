@@ -53,6 +53,7 @@ struct plsa_ctx {
     hipStream_t stream2 = nullptr;   // column-side chain of the fused iteration (overlaps the document pass)
     hipStream_t ls = nullptr;        // stream the kernel wrappers currently launch on
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_row = nullptr, ev_tail = nullptr;   // pipelined small-corpus iteration: document pass done / column chain done
     bool overlap = true;
     double overlap_full_limit = 2e9;   // nnz * kp below which both passes run side by side (PLSA_OVERLAP_FULL_LIMIT)
     std::string err;
@@ -116,6 +117,7 @@ struct plsa_ctx {
     DevBuf item_end, colsum_rows, colsum_rows2;
     // column-pass schedule: visiting-order item records, chunk boundaries per XCD (measured, see ensure_balance)
     DevBuf item_rec, xcd_lo, t_end;
+    bool pipeline = true;            // PLSA_PIPELINE=0: fork/join form of the small-corpus iteration (A/B)
     bool graph = false;              // PLSA_GRAPH=1: hipGraph replay of the iterations between two likelihood tests
     int order_band = -1;             // PLSA_ORDER_BAND: documents per band of the visiting order (-1 auto, 0 first-document order)
     int balance = -1;                // PLSA_BALANCE: -1 auto (large problems), 0 equal stretches, 1 always measure
@@ -1013,6 +1015,8 @@ int plsa_create(int device, plsa_ctx **out) {
                    : hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_row, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&c->h_ll, sizeof(double) * 2, hipHostMallocDefault) != hipSuccess) {
         delete c;
         return fail(nullptr, "stream / pinned buffer creation failed");
@@ -1035,6 +1039,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_BALANCE")) c->balance = atoi(s);
     if (const char *s = getenv("PLSA_ORDER_BAND")) c->order_band = atoi(s);
     if (const char *s = getenv("PLSA_GRAPH")) c->graph = atoi(s) != 0;
+    if (const char *s = getenv("PLSA_PIPELINE")) c->pipeline = atoi(s) != 0;
     if (const char *s = getenv("PLSA_CHUNKS_PER_LANE")) c->chunks_per_lane = atoi(s);
     if (const char *s = getenv("PLSA_E_ROWS")) c->e_rows = atoi(s);
     if (const char *s = getenv("PLSA_E_SEG")) c->eseg_override = atoi(s);
@@ -1065,6 +1070,8 @@ void plsa_destroy(plsa_ctx *c) {
     if (c->h_ll) (void)hipHostFree(c->h_ll);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_row) (void)hipEventDestroy(c->ev_row);
+    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1471,6 +1478,19 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
     } else {
         bool pending = false;  // a test is due on the factors currently in (cu, cv)
         bool stopped = false;
+        const bool graph_requested = ((flags & PLSA_GRAPH) || c->graph) && !c->sharded && !c->timing;
+        // small corpora: column chain and document pass as two pipelines that exchange events (see below)
+        const bool pipelined = c->overlap && !c->sharded && !graph_requested && c->pipeline &&
+                               (double)c->nnz * c->kp < c->overlap_full_limit;
+        if (pipelined) {      // everything enqueued so far (factors, corpus) precedes both pipelines
+            HIPCHK(c, hipEventRecord(c->ev_row, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_row, 0));
+            HIPCHK(c, hipEventRecord(c->ev_tail, c->stream2));
+        }
+        struct PipelineJoin {    // whatever way the loop is left, the column chain has finished before the call returns
+            plsa_ctx *c; bool on;
+            ~PipelineJoin() { if (on) { (void)hipStreamSynchronize(c->stream2); } }
+        } pipeline_join{c, pipelined};
         // one fused EM iteration from the factors in (cu, cv) into the alternate buffers (no swap here)
         auto enqueue_iteration = [&](bool want_ll, int *blocks) -> int {
             // PLSA_SHARDED: every collective of the communicator goes on c->stream in program order (accumulator
@@ -1486,6 +1506,23 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 CHK(ensure_ritems(c));
                 const int *unused = nullptr;
                 if (!c->use_ritems) CHK(ensure_roworder(c, &unused));
+                if (pipelined) {
+                    // The column chain of successive iterations is one dependency chain (column pass -> tail -> next
+                    // column pass): it stays back to back on the second stream, and the two streams only exchange
+                    // "document pass i done" / "column chain i done" events.  A fork + join through the first stream
+                    // put two cross-stream hops (17 us of 121 at config 1) between tail i and column pass i+1.
+                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_tail, 0));      // P(w|z) of the previous chain
+                    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_row, 0));      // P(z|d) of the previous document pass
+                    c->ls = c->stream2;
+                    int rc = run_col_pass(c, false, d_sw_m, thresh, 1);
+                    if (!rc) rc = run_col_tail(c);
+                    c->ls = c->stream;
+                    if (rc) return rc;
+                    HIPCHK(c, hipEventRecord(c->ev_tail, c->stream2));
+                    CHK(run_row_pass(c, false, want_ll, d_sw, thresh, nullptr, blocks));
+                    HIPCHK(c, hipEventRecord(c->ev_row, c->stream));
+                    return 0;
+                }
                 HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
                 HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
                 c->ls = c->stream2;
@@ -1524,7 +1561,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
         // from the launch sequence above.  Kernel arguments are baked into the graph, so it lives for this
         // call only.  Off by default: measured neutral (the host is not the bound, and a dependent kernel
         // boundary costs the same 1.5 us eager or replayed)
-        const bool use_graph = ((flags & PLSA_GRAPH) || c->graph) && !c->sharded && !c->timing;
+        const bool use_graph = graph_requested;
         hipGraphExec_t gexecs[4] = {nullptr, nullptr, nullptr, nullptr};   // one per starting buffer pair (cu, cv)
         struct GraphGuard {
             hipGraphExec_t (&g)[4];
@@ -1574,6 +1611,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
             iters++;
             pending = (i % n_iter_per_test == 0);
         }
+        if (pipelined) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_tail, 0));   // the last column chain precedes whatever follows
         if (!stopped && pending && trace) {  // test of the last iteration: result-neutral
             CHK(run_loglik(c, d_sw, &ll));
             if (ll_trace) ll_trace[nll] = (float)ll;
