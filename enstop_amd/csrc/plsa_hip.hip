@@ -798,7 +798,10 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int 
         if (c->small_grid > 0 && (double)c->nnz * c->kp < c->overlap_full_limit && grid <= 32 * c->prop.multiProcessorCount)
             grid = std::min(grid, c->small_grid * c->prop.multiProcessorCount);
         const int grid2 = grid_for(c, c->m, GPB);
-        const int xcd_split = (c->xcd_split && grid >= 64) ? 1 : 0;
+        // a P(z|d) table that fits every XCD's L2 (20NG shape: 1.5 MB) has no band to keep local: plain grid-stride
+        // over the list, balanced by the dispatcher (config 1: 8990 -> 9490 iterations/s)
+        const bool u_fits_l2 = (double)c->n * c->kp * 4.0 <= 2.0 * 1024 * 1024;
+        const int xcd_split = (c->xcd_split && grid >= 64 && !u_fits_l2) ? 1 : 0;
         if (parts & 1) {
             rc = ensure(c, c->colsum_rows, sizeof(double) * (size_t)std::max(n_chunks, 1) * c->kp);
             if (rc) return;
