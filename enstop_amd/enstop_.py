@@ -4,8 +4,8 @@
 The reference fans the members out over dask/joblib *threads* of one process.  Here a member is one
 fit on one GPU: within a process the members assigned to it run back to back on its device (the
 corpus is uploaded once, each bootstrap resample is a device-side row gather); across GPUs the
-launcher starts one process per device (torchrun) and the topic matrices are all-gathered over RCCL
-(`distributed.gather_topics`).  Members are dealt round-robin, run r -> rank r mod world_size, and
+launcher starts one process per device (torchrun); every member's topics go into the process' device stack and the
+stacks are all-gathered over RCCL (`distributed.gather_stack`).  Members are dealt round-robin, run r -> rank r mod world_size, and
 each member draws from its own RandomState stream so the stack does not depend on the device count.
 """
 import numpy as np

@@ -53,7 +53,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("n_runs", [4, 5])
-def test_gather_topics_world2_gloo(tmp_path, n_runs):
+def test_gather_stack_world2_gloo(tmp_path, n_runs):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
