@@ -434,6 +434,7 @@ def main():
     assert it == args.steps, "early stop inside the timed region (%d of %d)" % (it, args.steps)
     report = eng.timing_report()
     eng.timing(False)
+    schedule = eng.balance_info()            # measured XCD boundaries of the column pass (results do not depend on them)
     if stack is not None and rank == 0:
         assert stack.shape == (world, k, m) and np.all(np.isfinite(stack))
         _, V_mine = eng.get_factors(want_u=False)
@@ -521,6 +522,7 @@ def main():
         # gather/VALU-bound, not an HBM-roofline claim
         "roofline_dominant_fused": roof(*dom),
         "kernels": kernels,
+        "column_pass_schedule": schedule,
         "materialised_leg": mat,
         "device": info["name"] or "AMD Instinct MI355X", "arch": info["arch"], "generate_s": round(t_gen, 2),
     }

@@ -71,6 +71,8 @@ SIGNATURES = {
     "plsa_comm_broadcast_host": (C.c_int, [_ctx, _vp, _i64, _i32]),
     "plsa_allreduce_accumulator": (C.c_int, [_ctx]),
     "plsa_placement_info": (C.c_int, [_ctx, C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "plsa_schedule_info": (C.c_int, [_ctx, C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(_i32), C.POINTER(_i32),
+                                     C.POINTER(C.c_int64)]),
     "plsa_release_scratch": (C.c_int, [_ctx]),
     "plsa_timing_enable": (C.c_int, [_ctx, _i32]),
     "plsa_timing_reset": (C.c_int, [_ctx]),

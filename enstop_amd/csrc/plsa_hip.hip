@@ -1902,6 +1902,16 @@ int plsa_placement_info(plsa_ctx *c, int32_t *candidates, double *best_gbps, dou
     return 0;
 }
 
+int plsa_schedule_info(plsa_ctx *c, int32_t *xcd_lo, double *xcd_end_us, int32_t *timed_launches, int32_t *item_len,
+                       int64_t *n_items) {
+    if (xcd_lo) for (int x = 0; x <= 8; ++x) xcd_lo[x] = c->bal_valid ? c->bal_lo[x] : 0;
+    if (xcd_end_us) for (int x = 0; x < 8; ++x) xcd_end_us[x] = c->bal_launches > 0 ? c->bal_end_us[x] : 0.0;
+    if (timed_launches) *timed_launches = c->bal_launches;
+    if (item_len) *item_len = c->csc_valid ? c->seg : 0;
+    if (n_items) *n_items = c->csc_valid ? c->n_items : 0;
+    return 0;
+}
+
 int plsa_release_scratch(plsa_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));

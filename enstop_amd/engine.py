@@ -352,6 +352,15 @@ class Engine:
         self._ok(self._L.plsa_placement_info(self._h, C.byref(n), C.byref(a), C.byref(b)))
         return dict(candidates=n.value, kept_fill_GBps=round(a.value, 1), worst_fill_GBps=round(b.value, 1))
 
+    def balance_info(self):
+        """Column-pass schedule of the current structure: measured chunk boundaries per XCD, per-XCD finish times of
+        the last timed launch, timed launches spent, item length, number of items."""
+        lo = (C.c_int32 * 9)(); t = (C.c_double * 8)()
+        n, seg, items = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+        self._ok(self._L.plsa_schedule_info(self._h, lo, t, C.byref(n), C.byref(seg), C.byref(items)))
+        return dict(xcd_chunk_boundaries=list(lo), xcd_finish_us=[round(v, 1) for v in t], timed_launches=n.value,
+                    item_entries=seg.value, n_items=items.value)
+
     def release_scratch(self):
         """Free the materialised P and other large scratch buffers (re-created on demand)."""
         self._ok(self._L.plsa_release_scratch(self._h))

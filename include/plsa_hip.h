@@ -193,6 +193,15 @@ int plsa_allreduce_accumulator(plsa_ctx *ctx);
  * bandwidth of the kept / the worst candidate (0 when no probing took place).                    */
 int plsa_placement_info(plsa_ctx *ctx, int32_t *candidates, double *best_gbps, double *worst_gbps);
 
+/* Schedule of the column pass for the current structure (diagnostics; bench.py reports it): the visiting list is
+ * walked in chunks, XCD x takes the chunks [xcd_lo[x], xcd_lo[x+1]); the boundaries are MEASURED -- timed launches
+ * of the pass itself, stretches resized until the eight XCDs finish together (csrc/plsa_hip.hip::ensure_balance).
+ * xcd_end_us: per-XCD finish times of the last timed launch (0 when none ran: small corpora, PLSA_BALANCE=0).
+ * Results never depend on the boundaries.  No counterpart in the reference (its loops are per-thread ranges of
+ * numba.prange, enstop/plsa.py:91).  Any pointer may be NULL.                                               */
+int plsa_schedule_info(plsa_ctx *ctx, int32_t *xcd_lo /*[9]*/, double *xcd_end_us /*[8]*/, int32_t *timed_launches,
+                       int32_t *item_len, int64_t *n_items);
+
 /* frees the large scratch buffers (materialised P, column-pass partials); they are re-created on demand */
 int plsa_release_scratch(plsa_ctx *ctx);
 

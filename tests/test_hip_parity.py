@@ -1260,3 +1260,38 @@ def test_fuzz_slice(amd):
                          capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "mismatches 0" in out.stdout
+
+
+def test_schedule_knobs_do_not_change_results(amd):
+    """Round-3 scheduling machinery changes WHEN work runs, never WHAT is computed: measured XCD boundaries of the
+    column pass (PLSA_BALANCE), the event-linked pipelines of small corpora (PLSA_PIPELINE), hipGraph replay
+    (PLSA_GRAPH) -- factors, iteration count and likelihood trace are bit-identical with each switched the other way.
+    Two corpora: one large enough for the boundary tuning (nnz * k >= 1e8), one small enough for the pipelines."""
+    from enstop_amd.engine import reset_engines
+    rs = np.random.RandomState(4)
+    big = sp.random(30000, 20000, density=0.005, format="csr", random_state=rs, dtype=np.float32)
+    big.data = np.ceil(big.data * 4).astype(np.float32)
+    small = sp.random(3000, 2500, density=0.02, format="csr", random_state=rs, dtype=np.float32)
+    small.data = np.ceil(small.data * 4).astype(np.float32)
+    cases = [(big, 64, dict(n_iter=7, n_iter_per_test=3, tolerance=0.0, random_state=2)),
+             (small, 20, dict(n_iter=23, n_iter_per_test=4, tolerance=1e-7, random_state=5))]
+    saved = dict(os.environ)
+    try:
+        ref = []
+        reset_engines()
+        for X, k, kw in cases:
+            ref.append(amd.plsa_fit(X, k, np.ones(X.shape[0], np.float32), return_info=True, **kw))
+        assert amd.engine.get_engine().balance_info()["timed_launches"] >= 0
+        for knob, val in (("PLSA_BALANCE", "0"), ("PLSA_BALANCE", "1"), ("PLSA_PIPELINE", "0"), ("PLSA_GRAPH", "1")):
+            os.environ[knob] = val
+            reset_engines()                       # knobs are read when a context is created
+            for (X, k, kw), (U0, V0, i0) in zip(cases, ref):
+                U, V, info = amd.plsa_fit(X, k, np.ones(X.shape[0], np.float32), return_info=True, **kw)
+                assert info["n_iter"] == i0["n_iter"], (knob, val)
+                np.testing.assert_array_equal(info["log_likelihood_trace"], i0["log_likelihood_trace"])
+                np.testing.assert_array_equal(U, U0, err_msg="%s=%s" % (knob, val))
+                np.testing.assert_array_equal(V, V0, err_msg="%s=%s" % (knob, val))
+            del os.environ[knob]
+    finally:
+        os.environ.clear(); os.environ.update(saved)
+        reset_engines()
