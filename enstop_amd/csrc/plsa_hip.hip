@@ -721,6 +721,20 @@ void balance_set_lo(plsa_ctx *c, int n_chunks) {
     c->bal_chunks = n_chunks;
 }
 
+// Grid of the column pass: ONE chunk per workgroup (the dispatcher then walks each XCD's stretch strictly in list
+// order; with a capped grid a workgroup's later chunks lay a whole grid ahead of the window its XCD was working on:
+// 32 k / 64 k / 128 k workgroups at config 3 -> 1.86 / 1.83 / 1.79 ms).  With the XCD split every XCD gets grid / 8
+// workgroups, so the grid is eight times the longest stretch; the others' surplus workgroups exit at once.
+int col_grid(plsa_ctx *c, int n_chunks, bool split) {
+    i64 g = n_chunks;
+    if (split) {
+        int longest = 1;
+        for (int x = 0; x < 8; ++x) longest = std::max(longest, c->bal_lo[x + 1] - c->bal_lo[x]);
+        g = 8 * (i64)longest;
+    }
+    return (int)std::max<i64>(1, std::min<i64>(g, (i64)1 << 22));
+}
+
 // Measured XCD boundaries of the column pass (see k_col_pass).  `launch(timed)` enqueues one column pass on c->ls.
 // Equal stretches first (or the fractions measured for the previous structure on this context: a bootstrap
 // resample of the same corpus has the same profile and gets one measurement + one correction), then up to five timed
@@ -728,7 +742,7 @@ void balance_set_lo(plsa_ctx *c, int n_chunks) {
 // resized by (mean time / own time), damped -- until the eight finish within 2 % of each other.  Results never
 // depend on the boundaries (partials are per item, norm_pwz rows per chunk), only the speed does.
 template <class Launch>
-int ensure_balance(plsa_ctx *c, int grid, int n_chunks, bool split, Launch &&launch) {
+int ensure_balance(plsa_ctx *c, int n_chunks, bool split, Launch &&launch) {
     if (c->bal_valid && c->bal_chunks == n_chunks) return 0;
     CHK(ensure(c, c->xcd_lo, sizeof(int) * 16));
     const bool warm = c->bal_have_frac;
@@ -741,10 +755,13 @@ int ensure_balance(plsa_ctx *c, int grid, int n_chunks, bool split, Launch &&lau
     const bool tune = split && n_chunks >= 64 &&
                       (c->balance > 0 || (c->balance < 0 && (double)c->nnz * c->kp >= 1e8));
     if (tune) {
-        CHK(ensure(c, c->t_end, sizeof(unsigned long long) * ((size_t)grid + 1)));
-        std::vector<unsigned long long> te((size_t)grid + 1);
+        const size_t cap = (size_t)8 * (size_t)n_chunks + 16;      // any boundaries: at most 8 x n_chunks workgroups
+        CHK(ensure(c, c->t_end, sizeof(unsigned long long) * cap));
+        std::vector<unsigned long long> te;
         const int max_launches = warm ? 1 : 5;     // a resample of the same corpus: one measurement, one correction
         for (int it = 0; it < max_launches; ++it) {
+            const int grid = col_grid(c, n_chunks, split);
+            te.assign((size_t)grid + 1, 0);
             HIPCHK(c, hipMemsetAsync(c->t_end.p, 0, sizeof(unsigned long long) * ((size_t)grid + 1), c->ls));
             CHK(launch(true));
             HIPCHK(c, hipMemcpyAsync(te.data(), c->t_end.p, sizeof(unsigned long long) * ((size_t)grid + 1),
@@ -791,22 +808,20 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int 
         constexpr int LPN = Sh::LPN, GPB = 256 / LPN;
         const i64 n_visit = c->n_items;
         const int n_chunks = (int)((n_visit + GPB - 1) / GPB);
-        int grid = grid_for(c, n_visit, GPB);
-        // small corpora: one resident wave of workgroups (5 per CU at ~94 VGPRs)
-        // (only when the items would fill the chip a few times at most: with more items the dynamic balance
-        // of a large grid wins -- config 2's pass went 183 -> 218 us under the cap)
-        if (c->small_grid > 0 && (double)c->nnz * c->kp < c->overlap_full_limit && grid <= 32 * c->prop.multiProcessorCount)
-            grid = std::min(grid, c->small_grid * c->prop.multiProcessorCount);
         const int grid2 = grid_for(c, c->m, GPB);
         // a P(z|d) table that fits every XCD's L2 (20NG shape: 1.5 MB) has no band to keep local: plain grid-stride
         // over the list, balanced by the dispatcher (config 1: 8990 -> 9490 iterations/s)
         const bool u_fits_l2 = (double)c->n * c->kp * 4.0 <= 2.0 * 1024 * 1024;
-        const int xcd_split = (c->xcd_split && grid >= 64 && !u_fits_l2) ? 1 : 0;
+        const int xcd_split = (c->xcd_split && n_chunks >= 64 && !u_fits_l2) ? 1 : 0;
         if (parts & 1) {
             rc = ensure(c, c->colsum_rows, sizeof(double) * (size_t)std::max(n_chunks, 1) * c->kp);
             if (rc) return;
             const size_t smem = sizeof(double) * (size_t)GPB * c->kp;
             auto launch = [&](bool timed) -> int {
+                int grid = col_grid(c, n_chunks, xcd_split != 0);
+                // PLSA_SMALL_GRID (experiment knob): cap the pass of a small corpus at that many workgroups per CU
+                if (c->small_grid > 0 && (double)c->nnz * c->kp < c->overlap_full_limit)
+                    grid = std::min(grid, c->small_grid * c->prop.multiProcessorCount);
                 Scope s(c, from_p ? "k_col_pass<P>" : "k_col_pass<fused>");
                 const int4 *rec = c->item_rec.as<int4>();
                 const int *lo = c->xcd_lo.as<int>(), *cr = c->csc_row.as<int>(), *cp = c->csc_pos.as<int>();
@@ -826,7 +841,7 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int 
                 else { if (timed) go(F{}, T{}); else go(F{}, F{}); }
                 return launch_check(c, "k_col_pass");
             };
-            rc = ensure_balance(c, grid, n_chunks, xcd_split != 0, launch);
+            rc = ensure_balance(c, n_chunks, xcd_split != 0, launch);
             if (rc) return;
             rc = launch(false);
             if (rc) return;
