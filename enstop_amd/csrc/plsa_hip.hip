@@ -470,10 +470,11 @@ int ensure_csc(plsa_ctx *c) {
         int seg = 16;
         // large corpora: with the XCD stretches balanced, SHORTER items win (an item then spans fewer documents
         // and stays inside the band its XCD's L2 holds): config 3 (k = 64) 256 / 128 / 96 / 64 / 48 entries ->
-        // 268 / 269 / 271 / 274 / 272 iterations/s, config 5 (k = 128) 256 / 128 / 64 -> 22.6 / 23.2 / 22.7.
+        // 268 / 269 / 271 / 274 / 272 iterations/s before the band-major order, flat from 48 to 128 with it; config 5
+        // (k = 128) 256 / 128 / 64 -> 25.3 / 27.6 / 28.6.
         // Items of one length for every column: a chunk's groups (and a wave's) wait for their longest item --
         // long items for the Zipf-head words only (256 entries, the others 64) cost 1.96 -> 3.0 ms at config 3
-        const int cap = c->kp <= 64 ? 64 : 128;
+        const int cap = 64;
         while (seg * 2 <= want && seg < cap) seg *= 2;
         c->seg = c->seg_override ? c->seg_override : seg;
     }
