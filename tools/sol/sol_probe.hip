@@ -961,7 +961,7 @@ int main(int argc, char **argv) {
         // visiting orders at 64-entry items, measured boundaries (4 rounds): does making a chunk's 16 items alike help?
         //   band 0: ascending first document (shipped).   band B: (first document / B), then column length descending
         const int seg = 64;
-        for (int band : {1024, 1536, 3072, 4096, -2048, -4096}) {
+        for (int band : {0, 1024, 2048, 4096}) {
             std::vector<int4> recs;
             for (i64 c = 0; c < m; ++c)
                 for (int st = colptr[c]; st < colptr[c + 1]; st += seg) recs.push_back(make_int4((int)c, st, std::min(st + seg, colptr[c + 1]), 0));
@@ -982,11 +982,13 @@ int main(int argc, char **argv) {
             std::vector<int> lo(9);
             for (int x = 0; x <= 8; ++x) lo[x] = (int)((i64)n_chunks * x / 8);
             int *d_lo = dev(lo);
-            const int grid = std::min(n_chunks + 8, cus * 128) / 8 * 8;
+            int grid = (n_chunks / 8 + 8) * 8;      // one chunk per workgroup: 8 x the longest stretch (recomputed every round)
             unsigned long long *d_te = dev_alloc<unsigned long long>(grid);
             std::vector<unsigned long long> te(grid);
             double ms = 0, msg = 0;
             for (int iter = 0; iter < 4; ++iter) {
+                { int longest = 1; for (int x = 0; x < 8; ++x) longest = std::max(longest, lo[x + 1] - lo[x]); grid = 8 * longest; }
+                if ((int)te.size() < grid) { te.resize(grid); HC(hipFree(d_te)); d_te = dev_alloc<unsigned long long>(grid); }
                 HC(hipMemcpyAsync(d_lo, lo.data(), sizeof(int) * 9, hipMemcpyHostToDevice, g_stream));
                 ms = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<0, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); });
                 msg = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<2, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); });

@@ -32,7 +32,7 @@ for p in probe:
     if p.get("test") == "pass" and "gather-only, 8" in p["kernel"]:
         floor["row" if p["kernel"].startswith("row") else "col_unbalanced_256"] = p["ms"]
 for p in probe:
-    if p.get("test") == "col_order" and p["band"] == 1536 and p["round"] == 3:
+    if p.get("test") == "col_order" and p["band"] == 2048 and p["round"] == 3:
         floor["col"] = p["ms_gather_only"]
         floor["col_full_in_probe"] = p["ms"]
 
