@@ -6,7 +6,8 @@
  *
  * Parity status: PINNED.  Every function below is checked in tests/test_oracle_golden.py
  * against the .npz fixtures under tests/golden/ produced by running the reference's own
- * enstop/plsa.py + enstop/enstop_.py in the build container (tests/golden/make_golden.py).
+ * enstop/plsa.py + enstop/enstop_.py + enstop/streamed_plsa.py in the build container
+ * (tests/golden/make_golden.py).
  * The E-step, both M-steps and the refit M-step reproduce those fixtures bit-for-bit when the
  * library is built strict (no -ffast-math) and run on one thread; the log-likelihood agrees to
  * float32 rounding (NumPy's float32 log and libm logf differ in the last ulp).
@@ -263,6 +264,156 @@ int oracle_refit_inner(const int32_t *rows, const int32_t *cols, const float *va
     if (n_ll) *n_ll = nll;
     if (iters) *iters = it;
     free(P); free(norm_pdz);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * enstop/streamed_plsa.py -- the block-streamed loops (checker arithmetic only: float32 everywhere,
+ * whatever the build's acc_t / norm_t; pinned bit for bit by tests/golden/stream*.npz).
+ * ------------------------------------------------------------------------------------------------- */
+
+/* streamed_plsa.py:102-119  plsa_e_step_on_a_block: P block row (nz - block_start) */
+static void streamed_e_block(const int32_t *rows, const int32_t *cols, const float *V, const float *U,
+                             float *Pb, int64_t b0, int64_t b1, int64_t m, int64_t k, float thresh) {
+#pragma omp parallel for schedule(static)
+    for (int64_t nz = b0; nz < b1; nz++) {
+        const int64_t d = rows[nz], w = cols[nz];
+        float *p = Pb + (nz - b0) * k;
+        float norm = 0.0f;
+        for (int64_t z = 0; z < k; z++) {
+            float v = V[z * m + w] * U[d * k + z];
+            if (v > thresh) { p[z] = v; norm += v; } else { p[z] = 0.0f; }
+        }
+        for (int64_t z = 0; z < k; z++)
+            if (norm > 0.0f) p[z] /= norm;
+    }
+}
+
+/* streamed_plsa.py:204-219 (plsa_partial_m_step_on_a_block), :304-320 (..._w_sample_weight; sw != NULL),
+ * :774-785 (plsa_partial_refit_m_step_on_a_block; nV == NULL) */
+static void streamed_m_block(const int32_t *rows, const int32_t *cols, const float *vals, float *nV, float *nU,
+                             const float *Pb, const float *sw, float *norm_pwz, float *norm_pdz,
+                             int64_t b0, int64_t b1, int64_t m, int64_t k) {
+    for (int64_t nz = b0; nz < b1; nz++) {
+        const int64_t d = rows[nz], w = cols[nz];
+        const float x = vals[nz];
+        const float *p = Pb + (nz - b0) * k;
+        for (int64_t z = 0; z < k; z++) {
+            float s = x * p[z];
+            float t = sw ? s * sw[d] : s;
+            if (nV) { nV[z * m + w] += t; norm_pwz[z] += t; }
+            nU[d * k + z] += s;
+            norm_pdz[d] += s;
+        }
+    }
+}
+
+/* streamed_plsa.py:469-603  plsa_fit_inner_blockwise with :322-391 / :394-465 (plsa_em_step*) inlined:
+ * `n_blocks = nnz // block_size + 1` (:342), factors double-buffered (prev zeroed and handed back as the
+ * next "next", :386-391), stop test WITHOUT the `change == 0` arm (:596-597).  V, U receive the result. */
+int oracle_streamed_fit_inner(const int32_t *rows, const int32_t *cols, const float *vals, int64_t nnz,
+                              float *V, float *U, const float *sw, int64_t n, int64_t m, int64_t k,
+                              int64_t block_size, int32_t n_iter, int32_t n_iter_per_test, double tolerance,
+                              float thresh, int32_t use_sample_weights, float *ll_trace, int32_t *n_ll,
+                              int32_t *iters) {
+    float *Pb = (float *)calloc((size_t)(block_size * k) + 1, sizeof(float));      /* :543 */
+    float *norm_pwz = (float *)calloc((size_t)k + 1, sizeof(float));
+    float *norm_pdz = (float *)calloc((size_t)n + 1, sizeof(float));
+    float *bufV = (float *)calloc((size_t)(k * m) + 1, sizeof(float));             /* :552-553 */
+    float *bufU = (float *)calloc((size_t)(n * k) + 1, sizeof(float));
+    if (!Pb || !norm_pwz || !norm_pdz || !bufV || !bufU) {
+        free(Pb); free(norm_pwz); free(norm_pdz); free(bufV); free(bufU); return -1;
+    }
+    float *pV = V, *pU = U, *nV = bufV, *nU = bufU;
+    int32_t nll = 0, it = 0;
+    float prev = oracle_log_likelihood(rows, cols, vals, nnz, pV, pU, sw, m, k);   /* :548 */
+    if (ll_trace) ll_trace[nll] = prev;
+    nll++;
+    const int64_t n_blocks = nnz / block_size + 1;
+    for (int32_t i = 0; i < n_iter; i++) {
+        memset(norm_pdz, 0, sizeof(float) * (size_t)n);                             /* :345-346 */
+        memset(norm_pwz, 0, sizeof(float) * (size_t)k);
+        for (int64_t b = 0; b < n_blocks; b++) {
+            const int64_t b0 = b * block_size;
+            const int64_t b1 = nnz < b0 + block_size ? nnz : b0 + block_size;
+            streamed_e_block(rows, cols, pV, pU, Pb, b0, b1, m, k, thresh);
+            streamed_m_block(rows, cols, vals, nV, nU, Pb, use_sample_weights ? sw : NULL, norm_pwz, norm_pdz,
+                             b0, b1, m, k);
+        }
+        for (int64_t z = 0; z < k; z++) {                                           /* :378-384 */
+            if (norm_pwz[z] > 0.0f)
+                for (int64_t w = 0; w < m; w++) nV[z * m + w] /= norm_pwz[z];
+            for (int64_t d = 0; d < n; d++)
+                if (norm_pdz[d] > 0.0f) nU[d * k + z] /= norm_pdz[d];
+        }
+        memset(pV, 0, sizeof(float) * (size_t)(k * m));                             /* :388-389 */
+        memset(pU, 0, sizeof(float) * (size_t)(n * k));
+        { float *t = pV; pV = nV; nV = t; t = pU; pU = nU; nU = t; }               /* :391, :558-590 */
+        it++;
+        if (i % n_iter_per_test == 0) {
+            float cur = oracle_log_likelihood(rows, cols, vals, nnz, pV, pU, sw, m, k);
+            if (ll_trace) ll_trace[nll] = cur;
+            nll++;
+            float change = fabsf(cur - prev);
+            if ((double)(change / fabsf(cur)) < tolerance) break;                   /* :596-597 */
+            prev = cur;
+        }
+    }
+    if (pV != V) memcpy(V, pV, sizeof(float) * (size_t)(k * m));
+    if (pU != U) memcpy(U, pU, sizeof(float) * (size_t)(n * k));
+    if (n_ll) *n_ll = nll;
+    if (iters) *iters = it;
+    free(Pb); free(norm_pwz); free(norm_pdz); free(bufV); free(bufU);
+    return 0;
+}
+
+/* streamed_plsa.py:851-956  plsa_refit_inner_blockwise with :788-847 (plsa_refit_em_step) inlined.  The caller's
+ * e_step_thresh is NOT forwarded (:932-943): the E-step runs with plsa_refit_em_step's default 1e-32 (:798);
+ * the stop test only acts on a positive log-likelihood (:949) -- all n_iter iterations run. */
+int oracle_streamed_refit_inner(const int32_t *rows, const int32_t *cols, const float *vals, int64_t nnz,
+                                const float *topics, float *U, const float *sw, int64_t n, int64_t m, int64_t k,
+                                int64_t block_size, int32_t n_iter, int32_t n_iter_per_test, double tolerance,
+                                float thresh_ignored, float *ll_trace, int32_t *n_ll, int32_t *iters) {
+    (void)thresh_ignored;
+    float *Pb = (float *)calloc((size_t)(block_size * k) + 1, sizeof(float));
+    float *norm_pdz = (float *)calloc((size_t)n + 1, sizeof(float));
+    float *bufU = (float *)calloc((size_t)(n * k) + 1, sizeof(float));
+    if (!Pb || !norm_pdz || !bufU) { free(Pb); free(norm_pdz); free(bufU); return -1; }
+    float *pU = U, *nU = bufU;
+    int32_t nll = 0, it = 0;
+    float prev = oracle_log_likelihood(rows, cols, vals, nnz, topics, pU, sw, m, k);
+    if (ll_trace) ll_trace[nll] = prev;
+    nll++;
+    const int64_t n_blocks = nnz / block_size + 1;
+    for (int32_t i = 0; i < n_iter; i++) {
+        memset(norm_pdz, 0, sizeof(float) * (size_t)n);
+        for (int64_t b = 0; b < n_blocks; b++) {
+            const int64_t b0 = b * block_size;
+            const int64_t b1 = nnz < b0 + block_size ? nnz : b0 + block_size;
+            streamed_e_block(rows, cols, topics, pU, Pb, b0, b1, m, k, 1e-32f);
+            streamed_m_block(rows, cols, vals, NULL, nU, Pb, NULL, NULL, norm_pdz, b0, b1, m, k);
+        }
+        for (int64_t z = 0; z < k; z++)
+            for (int64_t d = 0; d < n; d++)
+                if (norm_pdz[d] > 0.0f) nU[d * k + z] /= norm_pdz[d];
+        memset(pU, 0, sizeof(float) * (size_t)(n * k));
+        { float *t = pU; pU = nU; nU = t; }
+        it++;
+        if (i % n_iter_per_test == 0) {
+            float cur = oracle_log_likelihood(rows, cols, vals, nnz, topics, pU, sw, m, k);
+            if (ll_trace) ll_trace[nll] = cur;
+            nll++;
+            if (cur > 0.0f) {
+                float change = fabsf(cur - prev);
+                if ((double)(change / fabsf(cur)) < tolerance) break;
+                prev = cur;
+            }
+        }
+    }
+    if (pU != U) memcpy(U, pU, sizeof(float) * (size_t)(n * k));
+    if (n_ll) *n_ll = nll;
+    if (iters) *iters = it;
+    free(Pb); free(norm_pdz); free(bufU);
     return 0;
 }
 

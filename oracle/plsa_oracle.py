@@ -56,6 +56,14 @@ class Oracle:
                                          C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.oracle_refit_inner.restype = C.c_int
         L.oracle_normalize_rows.argtypes = [_f64p, _i64, _i64]
+        L.oracle_streamed_fit_inner.argtypes = [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _f32p, _i64, _i64, _i64,
+                                                _i64, C.c_int32, C.c_int32, C.c_double, C.c_float, C.c_int32,
+                                                C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.oracle_streamed_fit_inner.restype = C.c_int
+        L.oracle_streamed_refit_inner.argtypes = [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _f32p, _i64, _i64, _i64,
+                                                  _i64, C.c_int32, C.c_int32, C.c_double, C.c_float,
+                                                  C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.oracle_streamed_refit_inner.restype = C.c_int
 
     # -- threading ------------------------------------------------------------------------
     def set_threads(self, t):
@@ -185,3 +193,56 @@ class Oracle:
                                      np.ascontiguousarray(sample_weight, np.float32),
                                      n_iter, n_iter_per_test, tolerance, e_step_thresh,
                                      return_trace=return_trace)
+
+    # -- enstop/streamed_plsa.py: plsa_fit (:606-699) and plsa_refit (:959-1039) -----------------
+    def streamed_plsa_fit(self, X, k, sample_weight, init="random", block_size=65536, n_iter=100,
+                          n_iter_per_test=10, tolerance=0.001, e_step_thresh=1e-32, random_state=None,
+                          return_trace=False):
+        from sklearn.utils import check_random_state
+        rng = check_random_state(random_state)
+        n, m = X.shape
+        assert isinstance(init, str) and init == "random"
+        V = rng.rand(k, m)                                       # plsa_init, shared with plsa.py (:680)
+        U = rng.rand(n, k)
+        self.normalize(V, axis=1)
+        self.normalize(U, axis=1)
+        U = U.astype(np.float32, order="C")
+        V = V.astype(np.float32, order="C")
+        sw = np.ascontiguousarray(sample_weight, np.float32)
+        A = X.tocoo().astype(np.float32)
+        trace = np.zeros(n_iter + 2, np.float32)
+        nll, iters = C.c_int32(0), C.c_int32(0)
+        rc = self.lib.oracle_streamed_fit_inner(
+            np.ascontiguousarray(A.row, np.int32), np.ascontiguousarray(A.col, np.int32),
+            np.ascontiguousarray(A.data, np.float32), A.nnz, V, U, sw, n, m, k, int(block_size), n_iter,
+            n_iter_per_test, float(tolerance), np.float32(e_step_thresh), int(bool(np.any(sw != 1.0))),
+            trace.ctypes.data, C.byref(nll), C.byref(iters))
+        if rc:
+            raise MemoryError("oracle_streamed_fit_inner")
+        if return_trace:
+            return U, V, trace[: nll.value].copy(), iters.value
+        return U, V
+
+    def streamed_plsa_refit(self, X, topics, sample_weight, block_size=65536, n_iter=50, n_iter_per_test=10,
+                            tolerance=0.005, e_step_thresh=1e-32, random_state=None, return_trace=False):
+        from sklearn.utils import check_random_state
+        A = X.tocoo().astype(np.float32)
+        k = topics.shape[0]
+        rng = check_random_state(random_state)
+        U = rng.rand(A.shape[0], k)                              # streamed_plsa.py:1020-1022
+        self.normalize(U, axis=1)
+        U = U.astype(np.float32)
+        topics = np.ascontiguousarray(topics, np.float32)
+        trace = np.zeros(n_iter + 2, np.float32)
+        nll, iters = C.c_int32(0), C.c_int32(0)
+        rc = self.lib.oracle_streamed_refit_inner(
+            np.ascontiguousarray(A.row, np.int32), np.ascontiguousarray(A.col, np.int32),
+            np.ascontiguousarray(A.data, np.float32), A.nnz, topics, U,
+            np.ascontiguousarray(sample_weight, np.float32), A.shape[0], A.shape[1], k, int(block_size),
+            n_iter, n_iter_per_test, float(tolerance), np.float32(e_step_thresh), trace.ctypes.data,
+            C.byref(nll), C.byref(iters))
+        if rc:
+            raise MemoryError("oracle_streamed_refit_inner")
+        if return_trace:
+            return U, trace[: nll.value].copy(), iters.value
+        return U

@@ -23,7 +23,14 @@ def golden_csr(g, prefix=""):
     import scipy.sparse as sp
     shape = tuple(int(v) for v in g[prefix + "shape"])
     data = g[prefix + "data"] if prefix + "data" in g else g[prefix + "data_u8"].astype(np.float64)   # counts stored as uint8
-    return sp.csr_matrix((data, g[prefix + "indices"], g[prefix + "indptr"]), shape=shape)
+    if prefix + "indices" in g:
+        indices = g[prefix + "indices"]
+    else:                                   # column ids stored as differences inside each row (compresses better)
+        indptr = g[prefix + "indptr"].astype(np.int64)
+        c = np.cumsum(g[prefix + "indices_rowdelta"].astype(np.int64))
+        before = np.concatenate([[0], c])[indptr[:-1]]            # running sum in front of each row
+        indices = (c - np.repeat(before, np.diff(indptr))).astype(np.int32)
+    return sp.csr_matrix((data, indices, g[prefix + "indptr"]), shape=shape)
 
 
 def peak_rel(a, b):

@@ -367,6 +367,160 @@ def gen_blockfit(name, n, m, k, density, seed, n_iter, n_iter_per_test, tol, blo
     print("   %s: iters=%d" % (name, count["em"]))
 
 
+def gen_fit_cfg1(name="fit_cfg1_shape", corpus="gpurun_out/r04/cfg1_corpus.npz", k=20, n_iter=2, fit_seed=7,
+                 n_cols=4000):
+    """The reference itself at BASELINE config 1's exact shape: the 18 846 x 173 762 / 2.95 M-nnz corpus of
+    `plsa_generate_synthetic(seed=0)` (downloaded once from the GPU box with tools/dump_synthetic_corpus.py:
+    the generator runs in HBM), enstop/plsa.py plsa_fit, k = 20, two iterations, tolerance 0.  ~7 minutes
+    of pure-Python reference time.  Stored: the corpus (so that CPU-only tests can run the oracle on it and
+    the GPU test can check the generator still produces it), P(z|d) in full, the log-likelihood trace, the
+    row sums of P(w|z) and `n_cols` of its columns (the 1000 most frequent words + a seeded random sample)."""
+    root = os.path.dirname(os.path.dirname(HERE))
+    c = np.load(os.path.join(root, corpus))
+    n, m = (int(v) for v in c["shape"])
+    X = sp.csr_matrix((c["data_u16"].astype(np.float64), c["indices"], c["indptr"]), shape=(n, m))
+    assert X.has_sorted_indices and (np.diff(X.indptr) > 0).all()
+    sw = np.ones(n, np.float32)
+    import time
+    t0 = time.time()
+    with Recorder() as rec, np.errstate(divide="ignore"):
+        U, V = ref.plsa_fit(X, k, sw, init="random", n_iter=n_iter, n_iter_per_test=10, tolerance=0.0,
+                            e_step_thresh=1e-32, random_state=fit_seed)
+    print("   reference run: %.0f s" % (time.time() - t0))
+    freq = np.asarray((X > 0).sum(axis=0)).ravel()
+    head = np.argsort(-freq, kind="stable")[:1000]
+    rest = np.setdiff1d(np.arange(m), head)
+    cols = np.sort(np.concatenate([head, np.random.RandomState(1).choice(rest, n_cols - 1000, replace=False)]))
+    # int32 column deltas inside a row compress far better than the raw sorted ids
+    idx = c["indices"].astype(np.int64)
+    delta = np.diff(idx, prepend=0)
+    delta[c["indptr"][:-1]] = idx[c["indptr"][:-1]]
+    save(name, indptr=c["indptr"].astype(np.int32), indices_rowdelta=delta.astype(np.int32),
+         data_u8=c["data_u16"].astype(np.uint8), shape=c["shape"], corpus_sha256=c["sha256"],
+         corpus_seed=c["seed"], k=np.int64(k), n_iter=np.int64(n_iter), n_iter_per_test=np.int64(10),
+         tol=np.float64(0.0), thresh=np.float64(1e-32), fit_seed=np.int64(fit_seed), U=U,
+         V_cols=cols.astype(np.int32), V_sample=np.ascontiguousarray(V[:, cols]),
+         V_rowsum64=V.astype(np.float64).sum(axis=1), V_max=V.max(axis=1),
+         V_abs_checksum64=np.float64(np.abs(V.astype(np.float64)).sum()),
+         ll_trace=np.array(rec.ll, np.float32), iters=np.int64(rec.n_e))
+    np.save(os.path.join(root, "gpurun_out", "r04", "cfg1_reference_V_full.npy"), V)   # scratch, not committed
+    print("   %s: nnz=%d iters=%d ll=%s" % (name, X.nnz, rec.n_e, rec.ll))
+
+
+class StreamRecorder:
+    """Counts EM steps / records the log-likelihood trace of enstop/streamed_plsa.py's loops (the module
+    binds `log_likelihood` by name at import, so the wrappers are installed on the module itself)."""
+
+    def __init__(self, sp_mod):
+        self.m = sp_mod
+        self.ll, self.n_em = [], 0
+        self.saved = {}
+
+    def __enter__(self):
+        m = self.m
+
+        def count(f):
+            def g(*a, **k):
+                self.n_em += 1
+                return f(*a, **k)
+            return g
+
+        def ll_w(*a):
+            v = self.saved["log_likelihood"](*a)
+            self.ll.append(np.float32(v))
+            return v
+        for name in ("plsa_em_step", "plsa_em_step_w_sample_weights", "plsa_refit_em_step"):
+            self.saved[name] = getattr(m, name)
+            setattr(m, name, count(self.saved[name]))
+        self.saved["log_likelihood"] = m.log_likelihood
+        m.log_likelihood = ll_w
+        return self
+
+    def __exit__(self, *exc):
+        for name, f in self.saved.items():
+            setattr(self.m, name, f)
+
+
+def gen_streamfit(name, n, m, k, density, seed, n_iter, n_iter_per_test, tol, block_size, thresh=1e-32,
+                  weighted=False, fit_seed=7):
+    """enstop/streamed_plsa.py plsa_fit (:606-699) -> plsa_fit_inner_blockwise (:469-603): E-step and partial
+    M-step over blocks of `block_size` non-zeros (:349-375), sample weights as plsa.py (:304-320), stop test
+    WITHOUT the `change == 0` arm (:596-597).  Iterations counted at plsa_em_step*."""
+    import enstop.streamed_plsa as st
+    X = make_counts(n, m, density, seed)
+    rs = np.random.RandomState(seed + 3)
+    sw = (0.5 + rs.rand(n)).astype(np.float32) if weighted else np.ones(n, np.float32)
+    with StreamRecorder(st) as rec, np.errstate(divide="ignore", invalid="ignore"):
+        U, V = st.plsa_fit(X, k, sw, init="random", block_size=block_size, n_iter=n_iter,
+                           n_iter_per_test=n_iter_per_test, tolerance=tol, e_step_thresh=thresh,
+                           random_state=fit_seed)
+    # the same call through enstop/plsa.py: recorded so that the tests can state where the two modules
+    # agree bit for bit (same summation order) and where they part (the `change == 0` arm)
+    with Recorder() as rec2, np.errstate(divide="ignore", invalid="ignore"):
+        U2, V2 = ref.plsa_fit(X, k, sw, init="random", n_iter=n_iter, n_iter_per_test=n_iter_per_test,
+                              tolerance=tol, e_step_thresh=thresh, random_state=fit_seed)
+    save(name, **csr_parts(X), k=np.int64(k), sw=sw, n_iter=np.int64(n_iter),
+         n_iter_per_test=np.int64(n_iter_per_test), tol=np.float64(tol), thresh=np.float64(thresh),
+         block_size=np.int64(block_size), fit_seed=np.int64(fit_seed), U=np.asarray(U, np.float32),
+         V=np.asarray(V, np.float32), ll_trace=np.array(rec.ll, np.float32), iters=np.int64(rec.n_em),
+         plsa_py_iters=np.int64(rec2.n_e), plsa_py_same_factors=np.bool_(
+             np.array_equal(U, U2) and np.array_equal(V, V2)))
+    print("   %s: nnz=%d blocks=%d iters=%d (plsa.py: %d, same factors: %s)" % (
+        name, X.nnz, X.nnz // block_size + 1, rec.n_em, rec2.n_e,
+        np.array_equal(U, U2) and np.array_equal(V, V2)))
+
+
+def gen_streamrefit(name, n, m, k, density, seed, n_iter, n_iter_per_test, tol, block_size, thresh=1e-32,
+                    weighted=False):
+    """enstop/streamed_plsa.py plsa_refit (:959-1039) -> plsa_refit_inner_blockwise (:851-956).  Quirks the
+    fixture pins: the loop never stops early (`if current_log_likelihood > 0`, :949) and `e_step_thresh` is
+    NOT handed to plsa_refit_em_step (:932-943), which runs with its default 1e-32 whatever the caller
+    passed -- `U_default_thresh` is the same call with e_step_thresh=1e-32."""
+    import enstop.streamed_plsa as st
+    X = make_counts(n, m, density, seed)
+    _, topics = random_factors(n, m, k, seed + 5)
+    rs = np.random.RandomState(seed + 6)
+    sw = (0.5 + rs.rand(n)).astype(np.float32) if weighted else np.ones(n, np.float32)
+    with StreamRecorder(st) as rec, np.errstate(divide="ignore", invalid="ignore"):
+        U = st.plsa_refit(X, topics, sw, block_size=block_size, n_iter=n_iter, n_iter_per_test=n_iter_per_test,
+                          tolerance=tol, e_step_thresh=thresh, random_state=np.random.RandomState(42))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        Ud = st.plsa_refit(X, topics, sw, block_size=block_size, n_iter=n_iter, n_iter_per_test=n_iter_per_test,
+                           tolerance=tol, e_step_thresh=1e-32, random_state=np.random.RandomState(42))
+        # enstop/plsa.py's refit on the same call (it DOES honour e_step_thresh, plsa.py:893)
+        Up = ref.plsa_refit(X, topics, sw, n_iter=n_iter, n_iter_per_test=n_iter_per_test, tolerance=tol,
+                            e_step_thresh=thresh, random_state=np.random.RandomState(42))
+    save(name, **csr_parts(X), k=np.int64(k), topics=topics, sw=sw, n_iter=np.int64(n_iter),
+         n_iter_per_test=np.int64(n_iter_per_test), tol=np.float64(tol), thresh=np.float64(thresh),
+         block_size=np.int64(block_size), U=np.asarray(U, np.float32), U_default_thresh=np.asarray(Ud, np.float32),
+         U_plsa_py=np.asarray(Up, np.float32), ll_trace=np.array(rec.ll, np.float32), iters=np.int64(rec.n_em))
+    print("   %s: iters=%d thresh ignored: %s, equals plsa.py: %s" % (
+        name, rec.n_em, np.array_equal(U, Ud), np.array_equal(U, Up)))
+
+
+def gen_streamestimator(name, seed, empty_rows=(0, 17, 47)):
+    """StreamedPLSA.fit_transform / transform (streamed_plsa.py:1167-1268): int input with empty rows
+    (float64 `embedding_`, :1216), weighted fit, transform with and without sample_weight (:1237)."""
+    import enstop.streamed_plsa as st
+    n, m, k = 48, 64, 5
+    X = make_counts(n, m, 0.15, seed, empty_rows=empty_rows).astype(np.int64)
+    model = st.StreamedPLSA(n_components=k, block_size=100, n_iter=30, n_iter_per_test=10, tolerance=0.0,
+                            random_state=11)
+    Xt = make_counts(20, m, 0.2, seed + 9).astype(np.int64)
+    swt = np.linspace(0.5, 2.0, Xt.shape[0])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        emb = model.fit_transform(X)
+        tr = model.transform(Xt)
+        tr_w = model.transform(Xt, sample_weight=swt)
+    parts = csr_parts(X)
+    save(name, indptr=parts["indptr"], indices=parts["indices"], data=X.data.copy(), shape=parts["shape"],
+         k=np.int64(k), block_size=np.int64(100), embedding=np.asarray(emb),
+         embedding_dtype=np.array(str(np.asarray(emb).dtype)), components=model.components_,
+         t_indptr=Xt.indptr.astype(np.int32), t_indices=Xt.indices.astype(np.int32),
+         t_data=Xt.data.astype(np.int64), t_shape=np.array(Xt.shape, np.int64), t_sw=swt,
+         transformed=tr, transformed_weighted=tr_w)
+
+
 def gen_combine(name, seed, t=24, m=150, min_samples=3):
     """Topic combination, enstop/enstop_.py:234-253 (KL), :283-296 (mutual reachability), :299-308 /
     :340-345 / :385-393 (cluster representatives).  Third-party calls are placeholders that record their
@@ -431,9 +585,35 @@ def gen_combine(name, seed, t=24, m=150, min_samples=3):
          labels=labels, probabilities=probs, rep_kl=rep_kl, rep_hellinger=rep_hell, rep_umap=rep_umap)
 
 
+def gen_stream_all():
+    # block sizes far below nnz: several blocks per EM step, incl. nnz an exact multiple of the block
+    gen_streamfit("streamfit_k6", n=70, m=90, k=6, density=0.12, seed=700, n_iter=25, n_iter_per_test=10, tol=0.0,
+                  block_size=128)
+    gen_streamfit("streamfit_k4_weighted", n=50, m=60, k=4, density=0.2, seed=220, n_iter=21, n_iter_per_test=5,
+                  tol=0.0, block_size=100, weighted=True)
+    gen_streamfit("streamfit_k5_earlystop", n=50, m=70, k=5, density=0.15, seed=210, n_iter=100,
+                  n_iter_per_test=10, tol=1e-3, block_size=65536)
+    gen_streamfit("streamfit_k8_thresh", n=40, m=64, k=8, density=0.2, seed=230, n_iter=15, n_iter_per_test=10,
+                  tol=0.0, block_size=77, thresh=2e-3)
+    # k = 1: the log-likelihood stops changing; plsa.py stops through `change == 0`, this loop runs on
+    gen_streamfit("streamfit_k1_zero_change", n=30, m=40, k=1, density=0.2, seed=720, n_iter=25,
+                  n_iter_per_test=5, tol=0.0, block_size=64)
+    gen_streamrefit("streamrefit_k6", n=40, m=60, k=6, density=0.2, seed=300, n_iter=50, n_iter_per_test=5,
+                    tol=0.001, block_size=96)
+    gen_streamrefit("streamrefit_k8_weighted_thresh", n=30, m=50, k=8, density=0.2, seed=310, n_iter=20,
+                    n_iter_per_test=10, tol=0.005, block_size=65536, thresh=2e-3, weighted=True)
+    gen_streamestimator("streamestimator_int_emptyrows", seed=420)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "big":       # only the slow one
         gen_fit_big("fit_k4_big")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg1":      # the slowest one; needs the downloaded corpus
+        gen_fit_cfg1()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "stream":    # only the streamed_plsa.py fixtures
+        gen_stream_all()
         sys.exit(0)
     gen_kernels("kernels_k6", n=40, m=50, k=6, density=0.15, seed=100, thresh=1e-32)
     gen_kernels("kernels_k8_thresh", n=36, m=44, k=8, density=0.2, seed=110, thresh=2.5e-3, zero_doc=3)
@@ -466,6 +646,8 @@ if __name__ == "__main__":
     gen_blockfit("blockfit_k1_zero_change", n=30, m=40, k=1, density=0.2, seed=720, n_iter=25, n_iter_per_test=5, tol=0.0)
 
     gen_combine("combine_t24", seed=800)
+
+    gen_stream_all()
 
     gen_fit_inner_ll_only("fit_inner_ll_only_weights", seed=900)
 

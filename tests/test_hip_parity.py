@@ -1141,6 +1141,66 @@ def test_streamed_transform_takes_sample_weight(amd):
     close_factors(b, g["transformed"])
 
 
+STREAMFIT_CASES = ["streamfit_k6", "streamfit_k4_weighted", "streamfit_k5_earlystop", "streamfit_k8_thresh",
+                   "streamfit_k1_zero_change"]
+
+
+@pytest.mark.parametrize("case", STREAMFIT_CASES)
+def test_streamed_fit_vs_reference(amd, case):
+    """enstop/streamed_plsa.py plsa_fit (:606-699) run by the reference itself, several blocks of non-zeros per
+    EM step: weights as plsa.py, stop test without the `change == 0` arm (:596-597)."""
+    from enstop_amd.streamed_plsa import plsa_fit as streamed_fit
+    g = load_golden(case)
+    X = golden_csr(g)
+    U, V, info = streamed_fit(X, int(g["k"]), g["sw"], block_size=int(g["block_size"]), n_iter=int(g["n_iter"]),
+                              n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+                              e_step_thresh=float(g["thresh"]), random_state=int(g["fit_seed"]), return_info=True)
+    assert info["n_iter"] == int(g["iters"])
+    tol = 2e-3 if float(g["thresh"]) >= 1e-6 else 1e-4     # in-range threshold: single responsibilities flip (see above)
+    close_factors(U, g["U"], tol); close_factors(V, g["V"], tol)
+    close_ll(info["log_likelihood_trace"][:len(g["ll_trace"])], g["ll_trace"], rtol=2e-5)
+    if case == "streamfit_k1_zero_change":
+        assert int(g["plsa_py_iters"]) < info["n_iter"]         # plsa.py's loop stopped on `change == 0`
+
+
+@pytest.mark.parametrize("case", ["streamrefit_k6", "streamrefit_k8_weighted_thresh"])
+def test_streamed_refit_vs_reference(amd, case):
+    """enstop/streamed_plsa.py plsa_refit (:959-1039): never stops early (:949), and the caller's e_step_thresh
+    is not used (:932-943) -- `U` was generated with thresh 2e-3 in the second case and equals the default-1e-32 run."""
+    from enstop_amd.streamed_plsa import plsa_refit as streamed_refit
+    g = load_golden(case)
+    X = golden_csr(g)
+    U, info = streamed_refit(X, g["topics"], g["sw"], block_size=int(g["block_size"]), n_iter=int(g["n_iter"]),
+                             n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+                             e_step_thresh=float(g["thresh"]), random_state=np.random.RandomState(42),
+                             return_info=True)
+    assert info["n_iter"] == int(g["iters"]) == int(g["n_iter"])
+    close_factors(U, g["U"])
+    close_ll(info["log_likelihood_trace"][:len(g["ll_trace"])], g["ll_trace"], rtol=2e-5)
+    if float(g["thresh"]) != 1e-32:
+        # plsa.py's own refit honours the threshold and lands elsewhere; ours must do the same there
+        Up = amd.plsa_refit(X, g["topics"], g["sw"], n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]),
+                            tolerance=float(g["tol"]), e_step_thresh=float(g["thresh"]),
+                            random_state=np.random.RandomState(42))
+        close_factors(Up, g["U_plsa_py"], 2e-3)
+        assert np.abs(g["U_plsa_py"] - g["U"]).max() > 1e-2 * g["U"].max()
+
+
+def test_streamed_estimator_vs_reference(amd):
+    """StreamedPLSA.fit_transform / transform (streamed_plsa.py:1167-1268) on int input with empty documents."""
+    g = load_golden("streamestimator_int_emptyrows")
+    X = sp.csr_matrix((g["data"], g["indices"], g["indptr"]), shape=tuple(g["shape"]))
+    model = amd.StreamedPLSA(n_components=int(g["k"]), block_size=int(g["block_size"]), n_iter=30, n_iter_per_test=10,
+                             tolerance=0.0, random_state=11)
+    emb = model.fit_transform(X)
+    assert str(emb.dtype) == str(g["embedding_dtype"])             # float64 zeros when rows were dropped (:1216)
+    close_factors(emb, g["embedding"]); close_factors(model.components_, g["components"])
+    assert (emb[[0, 17, 47]] == 0).all()
+    Xt = sp.csr_matrix((g["t_data"], g["t_indices"], g["t_indptr"]), shape=tuple(g["t_shape"]))
+    close_factors(model.transform(Xt), g["transformed"])
+    close_factors(model.transform(Xt, sample_weight=g["t_sw"]), g["transformed_weighted"])
+
+
 def test_device_all_pairs_kl_vs_reference(amd):
     """plsa_all_pairs_kl against all_pairs_kl_divergence run by the reference (enstop_.py:234-253)."""
     g = load_golden("combine_t24")

@@ -181,3 +181,102 @@ def test_big_fit_pins_the_float32_stagnation(oracle):
     Uw, Vw, _, _ = wide.plsa_fit(X, int(g["k"]), g["sw"], **kw)
     assert peak_rel(g["V"], Vw) > 1e-4, peak_rel(g["V"], Vw)
     assert peak_rel(g["V"], Vw) < 1e-3 and peak_rel(g["U"], Uw) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# enstop/streamed_plsa.py (fixtures generated by running that module)
+# ------------------------------------------------------------------------------------------------
+STREAMFIT_CASES = ["streamfit_k6", "streamfit_k4_weighted", "streamfit_k5_earlystop", "streamfit_k8_thresh",
+                   "streamfit_k1_zero_change"]
+
+
+@pytest.mark.parametrize("case", STREAMFIT_CASES)
+def test_streamed_fit_matches_reference(oracle, case):
+    """oracle_streamed_fit_inner (streamed_plsa.py:469-603, blocks of `block_size` non-zeros) reproduces the
+    reference's streamed fit bit for bit, iteration count included; where plsa.py's loop ran the same number of
+    iterations its restatement gives the SAME bits (one summation order) -- they part on the `change == 0` arm."""
+    g = load_golden(case)
+    X = golden_csr(g)
+    kw = dict(n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+              e_step_thresh=float(g["thresh"]), random_state=int(g["fit_seed"]), return_trace=True)
+    U, V, trace, iters = oracle.streamed_plsa_fit(X, int(g["k"]), g["sw"], block_size=int(g["block_size"]), **kw)
+    assert iters == int(g["iters"])
+    np.testing.assert_array_equal(U, g["U"])
+    np.testing.assert_array_equal(V, g["V"])
+    assert trace.shape == g["ll_trace"].shape
+    np.testing.assert_allclose(trace, g["ll_trace"], rtol=2e-6)
+    assert bool(g["plsa_py_same_factors"])
+    U2, V2, _, iters2 = oracle.plsa_fit(X, int(g["k"]), g["sw"], **kw)
+    assert iters2 == int(g["plsa_py_iters"])
+    if case == "streamfit_k1_zero_change":
+        assert iters2 < iters                        # plsa.py:635 stops on `change == 0`, :596-597 does not
+    else:
+        assert iters2 == iters
+    np.testing.assert_array_equal(U2, g["U"]); np.testing.assert_array_equal(V2, g["V"])
+
+
+@pytest.mark.parametrize("case", ["streamrefit_k6", "streamrefit_k8_weighted_thresh"])
+def test_streamed_refit_matches_reference(oracle, case):
+    g = load_golden(case)
+    X = golden_csr(g)
+    U, trace, iters = oracle.streamed_plsa_refit(X, g["topics"], g["sw"], block_size=int(g["block_size"]),
+                                                n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]),
+                                                tolerance=float(g["tol"]), e_step_thresh=float(g["thresh"]),
+                                                random_state=np.random.RandomState(42), return_trace=True)
+    assert iters == int(g["iters"]) == int(g["n_iter"])          # never stops early (streamed_plsa.py:949)
+    np.testing.assert_array_equal(U, g["U"])
+    np.testing.assert_allclose(trace, g["ll_trace"], rtol=2e-6)
+    # the caller's e_step_thresh never reaches the E-step (streamed_plsa.py:932-943) ...
+    np.testing.assert_array_equal(g["U"], g["U_default_thresh"])
+    # ... while plsa.py's refit uses it: same bits at the default, different vectors at 2e-3
+    Up = oracle.plsa_refit(X, g["topics"], g["sw"], n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]),
+                           tolerance=float(g["tol"]), e_step_thresh=float(g["thresh"]),
+                           random_state=np.random.RandomState(42))
+    np.testing.assert_array_equal(Up, g["U_plsa_py"])
+    assert np.array_equal(g["U_plsa_py"], g["U"]) == (float(g["thresh"]) == 1e-32)
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference itself at BASELINE config 1's exact shape (fit_cfg1_shape.npz, round 4)
+# ------------------------------------------------------------------------------------------------
+def cfg1_reference_views(g, U, V):
+    """what the fixture keeps of a fit: P(z|d) in full, 4000 columns of P(w|z), its row sums and maxima"""
+    return dict(U=U, V_sample=np.ascontiguousarray(V[:, g["V_cols"]]),
+                V_rowsum64=V.astype(np.float64).sum(axis=1), V_max=V.max(axis=1),
+                V_abs_checksum64=np.float64(np.abs(V.astype(np.float64)).sum()))
+
+
+def test_cfg1_shape_reference_run_is_reproduced_bit_for_bit(oracle):
+    """fit_cfg1_shape: enstop/plsa.py plsa_fit run by the reference on the 18 846 x 173 762 / 2 948 108-nnz corpus of
+    BASELINE config 1 (k = 20, two iterations, 226 s of pure-Python time).  (i) the strict oracle reproduces every
+    stored output bit for bit -- the inference "oracle == reference at BASELINE sizes" now rests on the reference's
+    own output at a BASELINE size; (ii) the float64 build of the same algorithm is 1e-4 ... 1e-2 of the largest
+    P(w|z) entry away: the reference's float32 running sums (plsa.py:193, 322) are the inexact side here."""
+    import hashlib
+    from oracle.plsa_oracle import Oracle
+    g = load_golden("fit_cfg1_shape")
+    X = golden_csr(g)
+    assert X.shape == (18846, 173762) and X.nnz == 2948108
+    h = hashlib.sha256()
+    for a in (X.indptr.astype(np.int32), X.indices.astype(np.int32), X.data.astype(np.float32)):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert h.hexdigest() == str(g["corpus_sha256"])
+    kw = dict(n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+              e_step_thresh=float(g["thresh"]), random_state=int(g["fit_seed"]), return_trace=True)
+    sw = np.ones(X.shape[0], np.float32)
+    U, V, trace, iters = oracle.plsa_fit(X, int(g["k"]), sw, **kw)
+    assert iters == int(g["iters"]) == 2
+    got = cfg1_reference_views(g, U, V)
+    for key in ("U", "V_sample", "V_rowsum64", "V_max", "V_abs_checksum64"):
+        np.testing.assert_array_equal(got[key], g[key], err_msg=key)
+    # one float32 running sum over 2.9 M terms; NumPy's float32 log vs logf differ in the last ulp per term
+    np.testing.assert_allclose(trace, g["ll_trace"], rtol=2e-5)
+    wide = Oracle(variant="wide")
+    wide.set_threads(1)
+    Uw, Vw, tw, _ = wide.plsa_fit(X, int(g["k"]), sw, **kw)
+    gap_v = peak_rel(g["V_sample"], Vw[:, g["V_cols"]])
+    gap_u = peak_rel(g["U"], Uw)
+    gap_ll = float(np.max(np.abs(tw.astype(np.float64) - g["ll_trace"]) / np.abs(g["ll_trace"])))
+    assert 1e-4 < gap_v < 2e-2, gap_v
+    assert gap_u < 1e-3, gap_u               # measured 1.6e-3 (P(w|z)), 1.1e-4 (P(z|d))
+    assert 1e-4 < gap_ll < 1e-2, gap_ll      # measured 3.4e-3: the float32 running sum of 2.9 M log terms
