@@ -37,6 +37,9 @@
 #ifndef PLSA_UNR_COL
 #define PLSA_UNR_COL 8  // same for the column pass (its U gathers miss L2 more often: measured best)
 #endif
+#ifndef PLSA_WAVES_COL
+#define PLSA_WAVES_COL PLSA_WAVES   // min waves per SIMD for the column pass alone (A/B knob, tools/kernel_resources.py)
+#endif
 
 namespace plsa {
 
@@ -557,7 +560,7 @@ __device__ __forceinline__ void col_batch(int s0, int d_l, float x_l, int p_l, i
 // Per chunk the workgroup also writes the float64 sum of its GPB accumulators (`chunk_sums`, the rows norm_pwz is
 // added up from, in chunk order): every result is independent of the boundaries and of the grid.
 template <class S, bool FROM_P, bool TIMED>
-__global__ __launch_bounds__(256, PLSA_WAVES) void k_col_pass(const int4 *__restrict__ item_rec, i64 n_items,
+__global__ __launch_bounds__(256, PLSA_WAVES_COL) void k_col_pass(const int4 *__restrict__ item_rec, i64 n_items,
                                                   const int *__restrict__ xcd_lo,
                                                   const int *__restrict__ csc_row,
                                                   const float *__restrict__ csc_val,

@@ -9,14 +9,16 @@ Parity status.  Pinned by reference-generated goldens (tests/golden/combine_t24.
 reference's own statements, tests/golden/make_golden.py::gen_combine): `all_pairs_kl_divergence`
 (enstop_.py:234-253), the mutual-reachability matrix of `generate_combined_topics_kl` (:283-296), and
 the cluster representatives of all three combiners given labels / membership strengths (:299-308,
-:340-345, :385-393).  **Unpinned**: what the third-party packages compute -- `hdbscan` (MST, single
-linkage, condensed-tree labels) and `umap` (the Hellinger metric and the embedding); neither is
-installable in the build image.  For those steps scikit-learn's HDBSCAN is used: its public estimator
-on a precomputed matrix for "hellinger", its `_linkage` / `_tree` routines (the same three steps the
-reference calls in hdbscan) on the reference's mutual-reachability matrix for "kl_divergence";
-"hellinger_umap" needs `umap-learn` and raises ImportError when it is absent.  The all-pairs Hellinger
-matrix follows umap.distances.hellinger's published definition (umap-learn >= 0.3.8) and is checked
-against that definition, not against a reference run.
+:340-345, :385-393).  **Unpinned by a run of the package itself**: what `hdbscan` computes (MST, single
+linkage, condensed-tree leaf clusters) and what `umap` computes (the Hellinger metric, the embedding);
+neither is installable in the build image.  The HDBSCAN* tree step is the product's own
+(`hdbscan_tree.py`: Prim order, interval dendrogram, leaf clusters, hdbscan's conventions for core
+distances and cluster numbering) for "kl_divergence" and "hellinger", checked against a restatement of
+hdbscan's published routines and against scikit-learn's public estimator (tests/test_hdbscan_tree.py);
+no private scikit-learn module is imported.  "hellinger_umap" needs
+`umap-learn` and raises ImportError when it is absent.  The all-pairs Hellinger matrix follows
+umap.distances.hellinger's published definition (umap-learn >= 0.3.8) and is checked against that
+definition, not against a reference run.
 """
 import numpy as np
 from scipy.sparse import csr_matrix, issparse
@@ -90,34 +92,11 @@ def _cluster_representatives(all_topics, labels, weights=None, engine=None):
     return result
 
 
-def _hdbscan_precomputed(D, min_samples, min_cluster_size):
-    from sklearn.cluster import HDBSCAN
-    return HDBSCAN(min_samples=min_samples, min_cluster_size=min_cluster_size, metric="precomputed",
-                   cluster_selection_method="leaf").fit(D)
-
-
 def labels_from_mutual_reachability(mutual_reachability, min_cluster_size):
-    """enstop_.py:291-298: minimum spanning tree of the mutual-reachability graph (Prim), edges sorted
-    by weight, single-linkage tree, condensed tree with leaf selection.  The reference calls
-    hdbscan's `mst_linkage_core`, `label` and `_tree_to_labels`; scikit-learn's HDBSCAN carries the same
-    three routines (`mst_from_mutual_reachability`, `make_single_linkage`, `tree_to_labels`).  This tree
-    step is the one part of the topic combination whose parity is unpinned (hdbscan is not installable
-    in the build image)."""
-    try:      # private scikit-learn modules (present in 1.3 ... 1.7): say so instead of an AttributeError deep inside
-        from sklearn.cluster._hdbscan._linkage import make_single_linkage, mst_from_mutual_reachability
-        from sklearn.cluster._hdbscan._tree import tree_to_labels
-    except ImportError as e:
-        import sklearn
-        raise ImportError("topic_combination='kl_divergence' uses the HDBSCAN internals of scikit-learn 1.3-1.7 "
-                          "(sklearn.cluster._hdbscan._linkage / ._tree); scikit-learn %s does not provide them: %s"
-                          % (sklearn.__version__, e))
-    mr = np.ascontiguousarray(mutual_reachability, dtype=np.float64).copy()
-    mst = mst_from_mutual_reachability(mr)
-    mst = mst[np.argsort(mst["distance"])]
-    tree = make_single_linkage(mst)
-    labels, probabilities = tree_to_labels(tree, min_cluster_size=min_cluster_size,
-                                           cluster_selection_method="leaf")
-    return np.asarray(labels), np.asarray(probabilities)
+    """enstop_.py:291-298 (hdbscan's `mst_linkage_core`, `label`, `_tree_to_labels(..., "leaf")`):
+    (labels, membership strengths) from the product's own tree step, `hdbscan_tree.py`."""
+    from .hdbscan_tree import labels_from_mutual_reachability as tree_step
+    return tree_step(mutual_reachability, min_cluster_size)
 
 
 def generate_combined_topics_kl(all_topics, min_samples=5, min_cluster_size=5, engine=None):
@@ -136,7 +115,10 @@ def generate_combined_topics_hellinger(all_topics, min_samples=5, min_cluster_si
     if distance_fn is None:
         distance_fn = engine.all_pairs_hellinger if engine is not None else all_pairs_hellinger_distance
     D = distance_fn(all_topics)
-    labels = _hdbscan_precomputed(D, min_samples, min_cluster_size).labels_
+    # hdbscan.HDBSCAN(metric="precomputed", cluster_selection_method="leaf").fit_predict (enstop_.py:340-345);
+    # hdbscan's min_samples convention (core distance = min_samples-th smallest entry of a row, self included)
+    from .hdbscan_tree import hdbscan_precomputed_leaf
+    labels, _ = hdbscan_precomputed_leaf(D, min_samples, min_cluster_size)
     return _cluster_representatives(all_topics, labels, engine=engine)
 
 
@@ -150,7 +132,9 @@ def generate_combined_topics_hellinger_umap(all_topics, min_samples=5, min_clust
     from sklearn.cluster import HDBSCAN
     embedding = umap.UMAP(n_neighbors=n_neighbors, n_components=reduced_dim,
                           metric="hellinger").fit_transform(all_topics)
-    clusterer = HDBSCAN(min_samples=min_samples, min_cluster_size=min_cluster_size,
+    # scikit-learn's public estimator on the embedding; its min_samples counts the point itself, hdbscan's
+    # (enstop_.py:388-392) does not: + 1 gives the same core distances
+    clusterer = HDBSCAN(min_samples=min_samples + 1, min_cluster_size=min_cluster_size,
                         cluster_selection_method="leaf", allow_single_cluster=True).fit(embedding)
     return _cluster_representatives(all_topics, clusterer.labels_, clusterer.probabilities_, engine=engine)
 

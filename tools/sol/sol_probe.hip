@@ -465,8 +465,9 @@ __global__ __launch_bounds__(256) void k_col_dyn(const int4 *__restrict__ items,
 //    not depend on the boundaries.  TIMED: thread 0 records the block's end time (100 MHz wall clock).
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 ld4_sel(const float *p, bool nt) { return nt ? plsa::ld4_nt(p) : plsa::ld4(p); }
-template <int MODE, int UNR, bool TIMED>
-__global__ __launch_bounds__(256) void k_col_chunks(const int4 *__restrict__ items, i64 n_items, const int *__restrict__ lo,
+// TAG only makes the kernel NAME distinct (rocprofv3 --pmc rows of the hit / miss experiment); W = min waves per SIMD
+template <int MODE, int UNR, bool TIMED, int TAG = 0, int W = 1>
+__global__ __launch_bounds__(256, W) void k_col_chunks(const int4 *__restrict__ items, i64 n_items, const int *__restrict__ lo,
                                                     const int *__restrict__ csc_row, const float *__restrict__ csc_val,
                                                     const float *__restrict__ U, const float *__restrict__ Vt,
                                                     float *__restrict__ partial, double *__restrict__ chunk_sums, float thresh,
@@ -673,7 +674,7 @@ int main(int argc, char **argv) {
         valu_case<V_BPERM>("ds_bpermute_b32", 16, cus);
     }
     if (want("gather")) gather_cases(cus);
-    if (!want("row") && !want("col") && !want("timeline") && !want("dyn") && !want("balance") && !want("rowx") && !want("ntcol") && !want("order") && !want("rowsplit") && !want("rowlean")) return 0;
+    if (!want("row") && !want("col") && !want("timeline") && !want("dyn") && !want("balance") && !want("rowx") && !want("ntcol") && !want("order") && !want("rowsplit") && !want("rowlean") && !want("hitmiss")) return 0;
 
     // ---- corpus ------------------------------------------------------------------------------------------
     i64 n = 1000000, m = 100000, nnz_t = 100000000;
@@ -1008,6 +1009,83 @@ int main(int argc, char **argv) {
             }
             HC(hipFree(d_items)); HC(hipFree(d_p2)); HC(hipFree(d_cs)); HC(hipFree(d_lo)); HC(hipFree(d_te));
         }
+    }
+    if (want("hitmiss")) {
+        // Round 4, VERDICT r03 item 2b: the SHIPPED column schedule (64-entry items, band-major order of 2048 documents,
+        // head words first, one chunk per workgroup, measured XCD boundaries) run against three P(z|d) row maps:
+        //   real      the corpus' own document ids                         (61 % of the gathers hit the 4 MB L2s)
+        //   all-hit   document id & 8191: a 2 MB table, L2-resident on every XCD
+        //   all-miss  a pseudo-random row of the same 256 MB table per ENTRY (no reuse distance shorter than the table)
+        // full arithmetic (MODE 0) and gather-only (MODE 2), at several (rows in flight, waves per SIMD) points.  If a CU
+        // overlapped hits with misses perfectly the real pass would take max(0.61 t_hit, 0.39 t_miss); if its request
+        // slots are one shared pool (Little's law) it takes 0.61 t_hit + 0.39 t_miss.
+        const int seg = 64, band = 2048;
+        std::vector<int4> recs;
+        for (i64 c = 0; c < m; ++c)
+            for (int st = colptr[c]; st < colptr[c + 1]; st += seg) recs.push_back(make_int4((int)c, st, std::min(st + seg, colptr[c + 1]), 0));
+        const i64 ni = (i64)recs.size();
+        std::stable_sort(recs.begin(), recs.end(), [&](const int4 &a, const int4 &b) {
+            const int ba = csc_row[a.y] / band, bb = csc_row[b.y] / band;
+            if (ba != bb) return ba < bb;
+            return colptr[a.x + 1] - colptr[a.x] > colptr[b.x + 1] - colptr[b.x]; });
+        const int n_chunks = (int)((ni + 15) / 16);
+        int4 *d_items = dev(recs);
+        float *d_p2 = dev_alloc<float>((size_t)ni * 64);
+        double *d_cs = dev_alloc<double>((size_t)n_chunks * 64);
+        std::vector<int> lo(9);
+        for (int x = 0; x <= 8; ++x) lo[x] = (int)((i64)n_chunks * x / 8);
+        int *d_lo = dev(lo);
+        int grid = (n_chunks / 8 + 8) * 8;
+        unsigned long long *d_te = dev_alloc<unsigned long long>((size_t)n_chunks * 8 + 16);
+        std::vector<unsigned long long> te((size_t)n_chunks * 8 + 16);
+        for (int iter = 0; iter < 5; ++iter) {       // measured boundaries, as plsa_hip.hip::ensure_balance
+            { int longest = 1; for (int x = 0; x < 8; ++x) longest = std::max(longest, lo[x + 1] - lo[x]); grid = 8 * longest; }
+            HC(hipMemcpyAsync(d_lo, lo.data(), sizeof(int) * 9, hipMemcpyHostToDevice, g_stream));
+            HC(hipMemsetAsync(d_te, 0, sizeof(unsigned long long) * grid, g_stream));
+            hipLaunchKernelGGL((k_col_chunks<0, 8, true>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te);
+            HC(hipStreamSynchronize(g_stream));
+            HC(hipMemcpy(te.data(), d_te, sizeof(unsigned long long) * grid, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, last[8] = {0};
+            for (int b = 0; b < grid; ++b) if (te[b]) { t0 = std::min(t0, te[b]); last[b & 7] = std::max(last[b & 7], te[b]); }
+            double T[8], mean = 0, size[8], tot = 0, accs = 0, lo_t = 1e300, hi_t = 0;
+            for (int x = 0; x < 8; ++x) { T[x] = std::max(1.0, (double)(last[x] - t0) / 100.0 + 100.0); mean += T[x] / 8; lo_t = std::min(lo_t, T[x]); hi_t = std::max(hi_t, T[x]); }
+            if (iter == 4 || (hi_t - lo_t) / mean < 0.02) break;
+            for (int x = 0; x < 8; ++x) { size[x] = (lo[x + 1] - lo[x]) * (1.0 + 0.8 * (mean / T[x] - 1.0)); tot += size[x]; }
+            for (int x = 0; x < 8; ++x) { accs += size[x]; lo[x + 1] = (int)(accs / tot * n_chunks + 0.5); }
+            lo[8] = n_chunks;
+        }
+        { int longest = 1; for (int x = 0; x < 8; ++x) longest = std::max(longest, lo[x + 1] - lo[x]); grid = 8 * longest; }
+        HC(hipMemcpy(d_lo, lo.data(), sizeof(int) * 9, hipMemcpyHostToDevice));
+        std::vector<int> row_hit(nnz), row_miss(nnz);
+        for (i64 j = 0; j < nnz; ++j) {
+            row_hit[j] = csc_row[j] & 8191;
+            row_miss[j] = (int)(((uint64_t)csc_row[j] * 2654435761ull + (uint64_t)j * 0x9E3779B97F4A7C15ull) % (uint64_t)n);
+        }
+        int *d_rhit = dev(row_hit), *d_rmiss = dev(row_miss);
+        const int *maps[3] = {d_cscrow, d_rhit, d_rmiss};
+        const char *map_name[3] = {"real", "all-hit (2 MB table)", "all-miss (random row of the 256 MB table per entry)"};
+#define HM_CASE(UNRV, WV, TAGBASE)                                                                                          \
+        for (int mp = 0; mp < 3; ++mp) {                                                                                    \
+            const int *rows_ = maps[mp];                                                                                    \
+            double full_ = 0, gath_ = 0;                                                                                    \
+            if (mp == 0) { full_ = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<0, UNRV, false, TAGBASE + 0, WV>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, rows_, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); }); \
+                           gath_ = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<2, UNRV, false, TAGBASE + 0, WV>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, rows_, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); }); } \
+            if (mp == 1) { full_ = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<0, UNRV, false, TAGBASE + 1, WV>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, rows_, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); }); \
+                           gath_ = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<2, UNRV, false, TAGBASE + 1, WV>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, rows_, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); }); } \
+            if (mp == 2) { full_ = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<0, UNRV, false, TAGBASE + 2, WV>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, rows_, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); }); \
+                           gath_ = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<2, UNRV, false, TAGBASE + 2, WV>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, rows_, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); }); } \
+            printf("{\"test\": \"col_hitmiss\", \"rows_in_flight\": %d, \"min_waves_per_simd\": %d, \"tag\": %d, \"row_map\": \"%s\", \"ms_full\": %.4f, \"ms_gather_only\": %.4f, \"rows_per_ns_gather_only\": %.1f}\n", \
+                   UNRV, WV, TAGBASE + mp, map_name[mp], full_, gath_, nnz / gath_ / 1e6);                                  \
+            fflush(stdout);                                                                                                 \
+        }
+        HM_CASE(8, 1, 10)
+        HM_CASE(8, 6, 20)
+        HM_CASE(8, 8, 30)
+        HM_CASE(4, 8, 40)
+        HM_CASE(6, 6, 50)
+        HM_CASE(16, 1, 60)
+#undef HM_CASE
+        HC(hipFree(d_items)); HC(hipFree(d_p2)); HC(hipFree(d_cs)); HC(hipFree(d_lo)); HC(hipFree(d_te)); HC(hipFree(d_rhit)); HC(hipFree(d_rmiss));
     }
     if (want("rowx")) {
         // does the order of a document's entries matter?  as stored (by word id = random w.r.t. frequency) vs sorted by
