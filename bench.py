@@ -27,6 +27,10 @@ mode for single-GPU boxes (ranks share the GPU, host-file exchange) and says so 
 Inputs are generated in HBM before the timed region (plsa_generate_synthetic); factors are
 initialised on the host exactly as plsa_init does and uploaded before the timed region.
 
+`value` is the MEDIAN of three back-to-back timed regions of exactly K iterations each (every region bracketed by
+barrier + synchronize, max over ranks); all three are listed in `timed_regions` (round 3: one of eight fresh
+processes ended 6 % low after an unlucky boundary tuning -- one region must not become the driver's number).
+
 Extra objects in the JSON line:
   roofline      the per-nnz materialising E-step kernel (plsa.py:39-107; the kernel the north_star
                 roofline target names): algorithmic bytes (SURVEY.md section 8d / DESIGN.md) / average
@@ -36,6 +40,8 @@ Extra objects in the JSON line:
   cpu_baseline  the CPU port (oracle/plsa_oracle.c, -O3 -ffast-math, OpenMP, reference thread
                 structure) timed on a bounded row-sample of the same corpus ("sampled": true), rank 0 /
                 N = 1 only; next to it `whole_config2`: the same port on the WHOLE of BASELINE configs[1]
+  hot_kernels   per hot kernel: VGPRs / waves per SIMD / LDS (hipcc's own remarks, captured when the library was
+                built: enstop_amd/kernel_resources.json) and traffic_ratio = counter bytes / algorithmic bytes
   roofline.traffic   HBM-side bytes per launch from rocprofv3 PMC passes run by this script itself
                 (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md)
                 when rocprofv3 is available; otherwise the committed profile's figure, labelled as such
@@ -319,6 +325,43 @@ def measure_traffic(args):
     return table or None
 
 
+def hot_kernel_table(k, kernels, traffic, source):
+    """Per hot kernel of this run: registers / occupancy / LDS as hipcc reported them when the library was built
+    (enstop_amd/kernel_resources.json, written by enstop_amd/build.py), launch time, compulsory bytes, counter
+    traffic and traffic_ratio = counter bytes / compulsory bytes (well above 1 = gathered rows re-fetched)."""
+    res = {}
+    try:
+        res = json.load(open(os.path.join(ROOT, "enstop_amd", "kernel_resources.json")))
+    except Exception:
+        pass
+    shape = {20: "k=20", 32: "k=32", 64: "k=64", 128: "k=128"}.get(k)
+    suffix = {"k_e_step": None, "k_row_pass<fused>": ", false, false>", "k_row_pass<fused,LL>": ", false, true>",
+              "k_col_pass<fused>": ", false, false>", "k_row_pass<P>": ", true, false>", "k_col_pass<P>": ", true, false>"}
+    out = {}
+    for name, e in kernels.items():
+        if name not in suffix or "algorithmic_GB" not in e:
+            continue
+        row = {"avg_ms": e["avg_ms"], "algorithmic_GB": e["algorithmic_GB"], "frac_of_hbm_peak_on_algorithmic_bytes":
+               round(e["GBps"] / HBM_PEAK_GBS, 4)}
+        t = traffic.get(name)
+        if t:
+            row["traffic_GB"] = round(t["hbm_bytes_per_launch"] / 1e9, 3)
+            row["traffic_ratio"] = round(t["hbm_bytes_per_launch"] / 1e9 / e["algorithmic_GB"], 2)
+            row["frac_of_hbm_peak_on_traffic"] = round(t["hbm_bytes_per_launch"] / 1e9 / (e["avg_ms"] / 1e3) / HBM_PEAK_GBS, 4)
+            row["traffic_source"] = "this run" if source != "from_committed_profile" else "committed profile"
+        base = name.split("<")[0]
+        for r in res.get("kernels", []):
+            if r["shape"] != shape or not r["kernel"].startswith(base):
+                continue
+            if suffix[name] is not None and not (r["kernel"].startswith(base + "<") and r["kernel"].endswith(suffix[name])):
+                continue
+            row.setdefault("instantiations", []).append(
+                {"kernel": r["kernel"], "vgprs": r["vgprs"], "waves_per_simd": r["waves_per_simd"],
+                 "lds_bytes": r["lds_bytes"], "scratch_bytes_per_lane": r["scratch"]})
+        out[name] = row
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,6 +371,9 @@ def main():
     ap.add_argument("--schedule", default=os.environ.get("PLSA_BENCH_SCHEDULE", "fused"),
                     choices=["fused", "materialised"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="additionally time the CPU port on the WHOLE corpus for 2 iterations (config 3: ~1.5 min of "
+                         "host time, 26 GB of host memory) -> cpu_baseline.whole_corpus")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
     ap.add_argument("--no-ensemble", action="store_true", help="skip the measured ensemble leg")
     ap.add_argument("--members-per-rank", type=int, default=2)
@@ -422,25 +468,34 @@ def main():
         assert it == args.warmup
     gather_components()
 
-    # ---- timed region: exactly K EM iterations ---------------------------------------------------
-    eng.timing(True)
-    eng.timing_reset()
-    barrier()
-    t0 = time.perf_counter()
-    it, _ = eng.fit(None, n_iter=args.steps, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=flags)
-    stack = gather_components()
-    barrier()
-    dt = time.perf_counter() - t0
-    assert it == args.steps, "early stop inside the timed region (%d of %d)" % (it, args.steps)
-    report = eng.timing_report()
-    eng.timing(False)
+    # ---- timed regions: three times exactly K EM iterations, each bracketed by barrier + synchronize; the
+    # MEDIAN region is reported (its per-kernel events, its wall time), all three are listed
+    plsa_comm.set_stage("timed")
+    regions = []
+    stack = None
+    for _region in range(3):
+        eng.set_factors(U0, V0)
+        eng.timing(True)
+        eng.timing_reset()
+        barrier()
+        t0 = time.perf_counter()
+        it, _ = eng.fit(None, n_iter=args.steps, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=flags)
+        stack = gather_components()
+        barrier()
+        dt_r = time.perf_counter() - t0
+        assert it == args.steps, "early stop inside the timed region (%d of %d)" % (it, args.steps)
+        rep_r = eng.timing_report()
+        eng.timing(False)
+        dt_r = float(comm.allreduce_f64([dt_r], "max")[0])
+        regions.append((dt_r, rep_r))
+    order = sorted(range(3), key=lambda i: regions[i][0])
+    dt, report = regions[order[1]]
     schedule = eng.balance_info()            # measured XCD boundaries of the column pass (results do not depend on them)
     if stack is not None and rank == 0:
         assert stack.shape == (world, k, m) and np.all(np.isfinite(stack))
         _, V_mine = eng.get_factors(want_u=False)
         assert np.array_equal(stack[0], V_mine), "all-gather slot 0 is not rank 0's topic matrix"
 
-    dt = float(comm.allreduce_f64([dt], "max")[0])
     nnz_total = float(comm.allreduce_f64([float(nnz_act)], "sum")[0])
 
     # ---- per-kernel roofline figures from the HIP events of the timed region ----------------------
@@ -499,6 +554,10 @@ def main():
         "metric": "EM iterations/sec", "value": round(n_gpus * args.steps / dt, 4), "unit": "iter/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "value_is": "median of 3 back-to-back timed regions of exactly %d iterations (barrier + synchronize around each, "
+                    "max over ranks)" % args.steps,
+        "timed_regions": [{"value": round(n_gpus * args.steps / r[0], 4), "ms_per_step": round(r[0] / args.steps * 1e3, 4)}
+                          for r in regions],
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "n_docs": n, "n_vocab": m, "nnz": nnz, "k": k,
                    "schedule": args.schedule,
@@ -512,11 +571,9 @@ def main():
         # figure is ensemble.fits_per_min below
         "ensemble_fits_per_min_from_iteration_rate": round(n_gpus * args.steps / dt / FITS_ITERS * 60.0, 3),
         # north_star's roofline kernel: the per-nnz materialising E-step (HBM-bound)
-        "roofline_note": "`roofline` is north_star's roofline kernel, the per-nnz materialising E-step (timed in the second "
-                         "leg: the headline `value` runs the fused schedule, which never launches it); "
-                         "`roofline_dominant_fused` is the dominant kernel of the timed region against its COMPULSORY bytes -- "
-                         "that kernel is bound by gathered factor rows missing the L2s, not by compulsory HBM bytes: "
-                         "profiles/r03_speed_of_light.md puts both fused passes at 95-100 % of the measured row-gather bound",
+        "roofline_note": "`roofline`: k_e_step, MATERIALISED schedule (second leg, `materialised_leg`; `value` never launches "
+                         "it). `roofline_dominant_fused`: dominant kernel of the FUSED schedule that produces `value`, against "
+                         "its compulsory bytes; its counter traffic / ratio: `hot_kernels`.",
         "roofline": roof("k_e_step", e_entry),
         # dominant kernel of the (fused) timed region against its own compulsory bytes; it is
         # gather/VALU-bound, not an HBM-roofline claim
@@ -533,13 +590,20 @@ def main():
             except Exception as e:       # the baseline must never cost the GPU measurement
                 out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+            if args.cpu_baseline_full and isinstance(out.get("cpu_baseline"), dict):
+                try:
+                    out["cpu_baseline"]["whole_corpus"] = cpu_baseline(eng, cfg, k, iters=2, whole=True)
+                except Exception as e:
+                    out["cpu_baseline"]["whole_corpus"] = "failed: %r" % (e,)
     # ---- measured ensemble: the product's own call, two members per rank (see the module docstring) -------------
     if not args.no_ensemble:
+        plsa_comm.set_stage("ensemble")
         try:
             out["ensemble"] = ensemble_leg(eng, comm, k, world, rank, args, rccl_init_s)
             out["ensemble_fits_per_min"] = out["ensemble"]["fits_per_min"]
         except Exception as e:
             if world > 1:
+                plsa_comm.report_failure(e, rank, world, eng)
                 raise                                     # a rank that fails here would leave the others in a collective
             out["ensemble"] = "failed: %r" % (e,)
     if rank == 0 and n_gpus == 1 and args.config == 3 and not args.no_cpu_baseline:
@@ -580,6 +644,7 @@ def main():
                     "from_committed_profile: " + rec.get("source", "profiles/pmc_traffic.json")
         if table and source != "from_committed_profile":
             out["pmc_traffic"] = table
+        out["hot_kernels"] = hot_kernel_table(k, dict(kernels, **((mat or {}).get("kernels", {}))), table or {}, source)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

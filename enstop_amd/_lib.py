@@ -56,6 +56,8 @@ SIGNATURES = {
                              C.POINTER(_i32)]),
     "plsa_em_accumulate": (C.c_int, [_ctx, _vp, C.c_float, _vp]),
     "plsa_em_finish": (C.c_int, [_ctx]),
+    "plsa_set_sample_weight": (C.c_int, [_ctx, _vp]),
+    "plsa_comm_last_error": (C.c_int, [_ctx, C.c_char_p, _i64]),
     "plsa_accumulator_device": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(_i64)]),
     "plsa_accumulator_get": (C.c_int, [_ctx, _f32p]),
     "plsa_accumulator_set": (C.c_int, [_ctx, _f32p]),

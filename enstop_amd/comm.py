@@ -23,6 +23,41 @@ import time
 import numpy as np
 
 ID_BYTES = 128
+ID_MAGIC = b"PLSAID2\n"
+TOKEN_BYTES = 120
+
+# Where this rank is in the multi-GPU start-up / exchange sequence; `report_failure` prints it.  Stages, in order:
+# "id read" (rendezvous file) -> "comm init" (ncclCommInitRank) -> "warm-up gather" (first collective) ->
+# "timed" / "ensemble" (set by the callers around their own collectives).
+_STATE = {"stage": "start", "id_file": None, "device": None}
+
+
+def set_stage(stage):
+    _STATE["stage"] = stage
+
+
+def report_failure(exc, rank=None, world=None, eng=None):
+    """ONE line on stderr per rank that says where a multi-GPU run died: rank, device, stage reached, the id file,
+    the exception and RCCL's own last error text (ncclGetLastError through the C ABI).  Callers keep the rule
+    "non-zero exit status, no JSON line" -- this only makes the first 8-GPU failure cheap to read."""
+    rank = os.environ.get("RANK", "0") if rank is None else rank
+    world = os.environ.get("WORLD_SIZE", "1") if world is None else world
+    rccl = ""
+    try:
+        from . import _lib
+        import ctypes as C
+        buf = C.create_string_buffer(1024)
+        _lib.load().plsa_comm_last_error(eng._h if eng is not None else None, buf, 1024)
+        rccl = buf.value.decode(errors="replace")
+    except Exception as e:          # never let the reporter mask the real error
+        rccl = "unavailable (%s)" % type(e).__name__
+    dev = _STATE["device"] if eng is None else getattr(eng, "device", _STATE["device"])
+    line = "[enstop_amd rank %s/%s device %s] FAILED at stage '%s'; id file %s; %s: %s; rccl: %s" % (
+        rank, world, dev, _STATE["stage"], _STATE["id_file"], type(exc).__name__, str(exc).replace("\n", " | "),
+        rccl.replace("\n", " | ") or "-")
+    sys.stderr.write(line + "\n")
+    sys.stderr.flush()
+    return line
 
 
 def _run_order(g):
@@ -88,11 +123,18 @@ class RcclComm(SingleComm):
         return self.eng.comm_broadcast_host(np.ascontiguousarray(a), root)
 
     def gather_stack(self, eng, slots, k, m):
-        assert eng is self.eng            # one grouped ncclAllGather on the engine's stream + one copy to the host
-        return eng.comm_allgather_stack(slots, k, m)
+        if eng is not self.eng:
+            # the members were fitted on another engine than the communicator's (ensemble_of_topics(device=d),
+            # init_from_env(eng=custom)): bring that engine's stack to the host and exchange it through RCCL's
+            # host path -- slower than the grouped device gather, never wrong
+            return self.gather_host_stack(eng.comm_allgather_stack(slots, k, m, copy=False))
+        return eng.comm_allgather_stack(slots, k, m)   # one grouped ncclAllGather on the engine's stream + one copy
 
     def allreduce_accumulator(self, eng):
-        assert eng is self.eng
+        if eng is not self.eng:
+            raise RuntimeError("RcclComm is bound to the engine on device %s; the doc-sharded fit ran on device %s. "
+                               "Create the communicator on the engine that fits (init_from_env(eng=...))"
+                               % (self.eng.device, eng.device))
         eng.allreduce_accumulator()
 
     def close(self):
@@ -161,10 +203,14 @@ class FileComm(SingleComm):
     """Test double: exchanges through .npy files in a directory shared by the ranks of one node."""
     name = "files"
 
+    _instances = 0      # communicators this process has created: every rank creates them in the same order
+
     def __init__(self, directory, rank, world, timeout=300.0):
-        # one sub-directory per launch (launch_token: the launcher's nonce / pid), so that a re-used base
-        # directory can never hand a rank the payload of an earlier run
-        self.dir = os.path.join(directory, "run_" + launch_token())
+        # one sub-directory per launch (launch_token: the launcher's nonce / pid) AND per communicator of that launch
+        # (a process that shuts one down and creates another -- a test session, a notebook -- gets a fresh one), so
+        # that a re-used base directory can never hand a rank the payload of an earlier exchange
+        FileComm._instances += 1
+        self.dir = os.path.join(directory, "run_%s_c%d" % (launch_token(), FileComm._instances))
         self.rank, self.world, self.timeout = int(rank), int(world), timeout
         self.seq = 0
         os.makedirs(self.dir, exist_ok=True)
@@ -172,6 +218,19 @@ class FileComm(SingleComm):
         if stale:
             raise RuntimeError("FileComm: %s already holds exchange files of rank %d (%s ...): a previous run with the "
                                "same launch token; remove the directory" % (self.dir, self.rank, stale[0]))
+
+    def close(self):
+        """Final barrier (every rank has read everything), then this rank's last file goes; the directory is removed
+        by whoever finds it empty."""
+        if self.seq == 0:
+            return
+        try:
+            self.barrier()
+            time.sleep(0.01)                       # the others may still be loading the barrier payload
+            os.unlink(self._path(self.seq, self.rank))
+            os.rmdir(self.dir)
+        except (OSError, TimeoutError):
+            pass
 
     def _path(self, seq, r):
         return os.path.join(self.dir, "x%06d_r%d.npy" % (seq, r))
@@ -256,17 +315,6 @@ def _parent_start_ticks():
         return 0
 
 
-def _parent_start_epoch():
-    """Wall-clock start of the parent process (the launcher): nothing published before it belongs to this launch."""
-    try:
-        ticks = _parent_start_ticks()
-        with open("/proc/stat") as f:
-            btime = next(int(line.split()[1]) for line in f if line.startswith("btime"))
-        return btime + ticks / float(os.sysconf("SC_CLK_TCK"))
-    except Exception:
-        return 0.0
-
-
 def default_id_file():
     """Where the ranks of one launch meet.  PLSA_COMM_ID_FILE wins; otherwise a name that is unique per
     launch (`launch_token`: every worker of one launcher -- torchrun, bench.py's own spawner -- has the same parent)."""
@@ -278,12 +326,30 @@ def default_id_file():
                                                         os.environ.get("MASTER_PORT", "0"), launch_token()))
 
 
+def _rendezvous_token(path):
+    """What the id file must carry for a waiting rank to accept it.  A path chosen by `default_id_file` belongs to
+    one launcher: the full launch token (nonce + parent pid + parent start).  An explicit PLSA_COMM_ID_FILE may be
+    shared by ranks of DIFFERENT launchers (a second torchrun, ssh sessions): only the nonce the launchers export
+    (PLSA_LAUNCH_NONCE / TORCHELASTIC_RUN_ID) can be compared -- without one any well-formed file is accepted, so
+    an explicit path must be fresh for each launch (rank 0 removes what it finds there before publishing)."""
+    if os.environ.get("PLSA_COMM_ID_FILE") and path == os.environ["PLSA_COMM_ID_FILE"]:
+        nonce = os.environ.get("PLSA_LAUNCH_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+        tok = "".join(ch if ch.isalnum() else "_" for ch in nonce)[:40]
+    else:
+        tok = launch_token()
+    return tok.encode()[:TOKEN_BYTES].ljust(TOKEN_BYTES, b"\0")
+
+
 def rendezvous_id(rank, path=None, timeout=600.0):
     """Rank 0 creates the RCCL unique id and publishes it atomically (after removing whatever an earlier, crashed
-    launch left at that path; the file is private to the user); the others wait for a file that is YOUNGER than
-    their launcher -- a stale id would otherwise be read before rank 0 replaces it and ncclCommInitRank would hang."""
+    launch left at that path; the file is private to the user) as  magic | launch token | 128 id bytes;  the
+    others wait for a file that carries THEIR launch's token -- a stale id would otherwise be read before rank 0
+    replaces it and ncclCommInitRank would hang.  No clock is compared."""
     from . import _lib
     path = path or default_id_file()
+    _STATE["id_file"] = path
+    set_stage("id read")
+    token = _rendezvous_token(path)
     if rank == 0:
         import ctypes as C
         for old in (path, path + ".tmp"):
@@ -297,22 +363,27 @@ def rendezvous_id(rank, path=None, timeout=600.0):
             raise RuntimeError(L.plsa_last_error(None).decode())
         fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
         with os.fdopen(fd, "wb") as f:
-            f.write(buf.raw)
+            f.write(ID_MAGIC + token + buf.raw)
         os.replace(path + ".tmp", path)
         return buf.raw
-    not_before = _parent_start_epoch() - 1.0
     t0 = time.time()
+    want = len(ID_MAGIC) + TOKEN_BYTES + ID_BYTES
+    seen = "no file"
     while True:
         try:
-            if os.stat(path).st_mtime >= not_before:
-                with open(path, "rb") as f:
-                    data = f.read()
-                if len(data) == ID_BYTES:
-                    return data
+            with open(path, "rb") as f:
+                data = f.read()
+            if len(data) == want and data.startswith(ID_MAGIC):
+                if data[len(ID_MAGIC):len(ID_MAGIC) + TOKEN_BYTES] == token:
+                    return data[-ID_BYTES:]
+                seen = "a file of another launch (token mismatch)"
+            else:
+                seen = "a malformed / half-written file (%d bytes)" % len(data)
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout:
-            raise TimeoutError("rank %d: no RCCL id at %s after %.0f s" % (rank, path, timeout))
+            raise TimeoutError("rank %d: no RCCL id for this launch at %s after %.0f s (last seen: %s)"
+                               % (rank, path, timeout, seen))
         time.sleep(0.005)
 
 
@@ -327,8 +398,18 @@ def init_from_env(eng=None, id_file=None):
         return install(SingleComm())
     eng = eng if eng is not None else get_engine()
     path = id_file or default_id_file()
-    comm = RcclComm(eng, rank, world, rendezvous_id(rank, path))
-    comm.barrier()
+    _STATE["device"] = eng.device
+    timeout = float(os.environ.get("PLSA_RENDEZVOUS_TIMEOUT", "600"))
+    try:
+        id_bytes = rendezvous_id(rank, path, timeout=timeout)
+        set_stage("comm init")
+        comm = RcclComm(eng, rank, world, id_bytes)
+        set_stage("warm-up gather")
+        comm.barrier()
+    except Exception as e:
+        report_failure(e, rank, world, eng)
+        raise
+    set_stage("ready")
     if rank == 0:                       # every rank has read the id by now
         try:
             os.unlink(path)

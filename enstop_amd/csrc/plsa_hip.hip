@@ -136,6 +136,8 @@ struct plsa_ctx {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     bool sharded = false;            // PLSA_SHARDED fit in progress: accumulators / likelihoods are all-reduced
+    bool sw_resident = false;   // plsa_set_sample_weight: c->sw holds weights that apply whenever a call passes sw = NULL
+    i64 sw_n = 0;
     DevBuf comm_send, comm_recv, comm_small, comm_stack;   // comm_stack: the member stack (plsa_stack_reserve)
     float *comm_host = nullptr;      // pinned landing buffer of plsa_comm_allgather_stack
     size_t comm_host_cap = 0;
@@ -567,7 +569,16 @@ int ensure_csc(plsa_ctx *c) {
 
 int upload_sw(plsa_ctx *c, const float *sw, const float **d_sw) {
     *d_sw = nullptr;
-    if (!sw) return 0;
+    if (!sw) {
+        // weights made resident by plsa_set_sample_weight: no copy, no host wait (the per-iteration calls of the
+        // split doc-sharded loop stay enqueue-only)
+        if (c->sw_resident) {
+            if (c->sw_n != c->n) return fail(c, "resident sample weights were set for %lld documents, the active matrix has %lld",
+                                              (long long)c->sw_n, (long long)c->n);
+            *d_sw = c->sw.as<float>();
+        }
+        return 0;
+    }
     CHK(ensure(c, c->sw, sizeof(float) * (size_t)c->n));
     HIPCHK(c, hipMemcpyAsync(c->sw.p, sw, sizeof(float) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
     // `sw` is borrowed for the call only (it may be a temporary of the caller): the copy must have left the host
@@ -753,7 +764,10 @@ int ensure_balance(plsa_ctx *c, int n_chunks, bool split, Launch &&launch) {
     c->bal_launches = 0;
     // auto: corpora from ~1e8 cells per iteration (config 2: 4279 -> 4540 iterations/s; the tuning launches of a
     // 20NG-sized corpus would cost a bootstrap member more than they return)
-    const bool tune = split && n_chunks >= 64 &&
+    // PLSA_SMALL_GRID caps the launch below col_grid(): workgroup b would no longer be chunk-stretch b's only visitor
+    // and the start stamp would land in a slot read as an end time -- that experiment knob runs on equal stretches
+    const bool small_grid_active = c->small_grid > 0 && (double)c->nnz * c->kp < c->overlap_full_limit;
+    const bool tune = split && n_chunks >= 64 && !small_grid_active &&
                       (c->balance > 0 || (c->balance < 0 && (double)c->nnz * c->kp >= 1e8));
     if (tune) {
         const size_t cap = (size_t)8 * (size_t)n_chunks + 16;      // any boundaries: at most 8 x n_chunks workgroups
@@ -1748,6 +1762,18 @@ int plsa_em_accumulate(plsa_ctx *c, const float *sw, float thresh, double *ll_pa
     return 0;
 }
 
+int plsa_set_sample_weight(plsa_ctx *c, const float *sw) {
+    HIPCHK(c, hipSetDevice(c->device));
+    c->sw_resident = false;
+    if (!sw) return 0;
+    if (c->n <= 0) return fail(c, "plsa_set_sample_weight: no matrix uploaded");
+    const float *unused = nullptr;
+    CHK(upload_sw(c, sw, &unused));          // copies and waits: `sw` may be freed on return
+    c->sw_resident = true;
+    c->sw_n = c->n;
+    return 0;
+}
+
 int plsa_em_finish(plsa_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
@@ -1799,6 +1825,13 @@ int plsa_comm_init(plsa_ctx *c, const void *id128, int32_t rank, int32_t world) 
     NCCLCHK(c, ncclCommInitRank(&c->comm, world, id, rank));
     c->comm_rank = rank; c->comm_world = world;
     CHK(ensure(c, c->comm_small, 4096));
+    return 0;
+}
+
+int plsa_comm_last_error(plsa_ctx *c, char *buf, int64_t cap) {
+    if (!buf || cap <= 0) return 1;
+    const char *msg = ncclGetLastError(c ? c->comm : nullptr);     // RCCL keeps one text per process; comm may be NULL
+    snprintf(buf, (size_t)cap, "%s", msg ? msg : "");
     return 0;
 }
 
@@ -1946,6 +1979,10 @@ int plsa_release_scratch(plsa_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     release(c->P); release(c->partial); release(c->tmp0); release(c->tmp1); release(c->tmp2); release(c->cubtmp);
+    // member stack + gather buffers of the ensemble exchange (16 runs x 64 topics x 100 k words = 0.4 GB): re-created
+    // by the next plsa_stack_reserve / plsa_comm_allgather_stack
+    release(c->comm_stack); release(c->comm_recv); release(c->comm_send);
+    if (c->comm_host) { (void)hipHostFree(c->comm_host); c->comm_host = nullptr; c->comm_host_cap = 0; }
     c->p_valid = false;
     c->p_shift = 0;
     return 0;

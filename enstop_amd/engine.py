@@ -246,6 +246,12 @@ class Engine:
     def em_finish(self):
         self._ok(self._L.plsa_em_finish(self._h))
 
+    def set_sample_weight(self, sample_weight=None):
+        """Make the document weights resident on the device (None: clear): later calls that pass no weights use
+        them without a host copy -- the per-iteration calls of the doc-sharded loop stay enqueue-only."""
+        sw = None if sample_weight is None else _f32(sample_weight)
+        self._ok(self._L.plsa_set_sample_weight(self._h, ptr(sw)))
+
     def accumulator_device(self):
         p, n = C.c_void_p(), C.c_int64(0)
         self._ok(self._L.plsa_accumulator_device(self._h, C.byref(p), C.byref(n)))

@@ -39,7 +39,7 @@ last_ensemble_timing = {}      # seconds spent by the last multi-member call of 
 def _fit_members(A, k, runs, seeds, member_kw, device, n_jobs, world=1, n_runs=None):
     """Fits the given runs of an ensemble on this process' GPU and leaves their topic matrices in the device
     stack of the process-wide engine (run r -> slot r // world); run r draws from RandomState(seeds[r]) whichever
-    engine or thread fits it, so the result does not depend on `n_jobs`.  Returns (engine, slots)."""
+    engine or thread fits it, so the result does not depend on `n_jobs`.  Returns the engine that holds the stack."""
     jobs = min(concurrent_members(A.nnz, k, n_jobs), max(len(runs), 1))
     engines = get_member_engines(device, jobs)
     for e in engines[1:]:

@@ -84,6 +84,17 @@ def sharded_em(engines, comm, sample_weights=None, n_iter=100, n_iter_per_test=1
     each with its rows uploaded and factors set (same P(w|z) everywhere).  Returns (iterations,
     float32 log-likelihood trace)."""
     sws = sample_weights or [None] * len(engines)
+    for e, sw in zip(engines, sws):          # one upload per fit, not one copy + host wait per iteration
+        e.set_sample_weight(sw)
+    try:
+        return _sharded_em_loop(engines, comm, n_iter, n_iter_per_test, tolerance, e_step_thresh, trace_last, zero_arm)
+    finally:
+        for e in engines:
+            e.set_sample_weight(None)
+
+
+def _sharded_em_loop(engines, comm, n_iter, n_iter_per_test, tolerance, e_step_thresh, trace_last, zero_arm):
+    sws = [None] * len(engines)              # the resident weights apply
     trace = []
     prev = np.float32(comm.allreduce_scalar([e.log_likelihood(sw) for e, sw in zip(engines, sws)]))
     trace.append(prev)                                             # plsa.py:591

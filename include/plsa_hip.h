@@ -148,6 +148,11 @@ int plsa_refit(plsa_ctx *ctx, const float *sw, int32_t n_iter, int32_t n_iter_pe
  * buffer from a stream of its own calls plsa_synchronize first (ll_partial != NULL implies that synchronisation). */
 int plsa_em_accumulate(plsa_ctx *ctx, const float *sw, float thresh, double *ll_partial);
 int plsa_em_finish(plsa_ctx *ctx);
+/* Makes the per-document weights (`sample_weight`, enstop/plsa.py:208, :314) resident in HBM: one copy + one host
+ * wait here, after which every call that passes sw = NULL (plsa_em_accumulate in a per-iteration loop, plsa_fit,
+ * plsa_log_likelihood ...) uses them without touching the host.  sw = NULL clears them; uploading another matrix
+ * with a different number of documents makes the next use an error.                                          */
+int plsa_set_sample_weight(plsa_ctx *ctx, const float *sw /* [n] or NULL */);
 int plsa_accumulator_device(plsa_ctx *ctx, void **ptr, int64_t *n_floats);
 int plsa_accumulator_get(plsa_ctx *ctx, float *host);
 int plsa_accumulator_set(plsa_ctx *ctx, const float *host);
@@ -178,6 +183,10 @@ int plsa_accumulator_set(plsa_ctx *ctx, const float *host);
 int plsa_comm_unique_id(void *id128);
 int plsa_comm_init(plsa_ctx *ctx, const void *id128, int32_t rank, int32_t world);
 int plsa_comm_destroy(plsa_ctx *ctx);
+/* RCCL's own text for the last failure in this process (ncclGetLastError); ctx may be NULL.  No reference
+ * counterpart (dask / joblib raise Python exceptions, enstop_.py:209-217); read by enstop_amd/comm.py::report_failure
+ * so that a failed multi-GPU start says which stage and why. */
+int plsa_comm_last_error(plsa_ctx *ctx, char *buf, int64_t cap);
 int plsa_comm_info(plsa_ctx *ctx, int32_t *rank, int32_t *world);
 int plsa_comm_barrier(plsa_ctx *ctx);
 int plsa_stack_reserve(plsa_ctx *ctx, int64_t slots, int64_t m, int32_t k, void **base_device);
@@ -202,7 +211,8 @@ int plsa_placement_info(plsa_ctx *ctx, int32_t *candidates, double *best_gbps, d
 int plsa_schedule_info(plsa_ctx *ctx, int32_t *xcd_lo /*[9]*/, double *xcd_end_us /*[8]*/, int32_t *timed_launches,
                        int32_t *item_len, int64_t *n_items);
 
-/* frees the large scratch buffers (materialised P, column-pass partials); they are re-created on demand */
+/* frees the large scratch buffers (materialised P, column-pass partials, the ensemble member stack and its gather
+ * buffers); they are re-created on demand */
 int plsa_release_scratch(plsa_ctx *ctx);
 
 /* ---- measurement --------------------------------------------------------------------------------

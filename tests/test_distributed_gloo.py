@@ -117,28 +117,38 @@ def test_file_comm_world2(tmp_path):
         assert p.returncode == 0 and "ok" in out, "rank %d failed:\n%s" % (rank, out)
 
 
+def _publish(comm, path, payload, token=None, delay=0.2):
+    """what rank 0 does in comm.rendezvous_id, without needing a GPU for ncclGetUniqueId"""
+    import time
+    time.sleep(delay)
+    for old in (path, path + ".tmp"):
+        try:
+            os.unlink(old)
+        except OSError:
+            pass
+    token = comm._rendezvous_token(path) if token is None else token
+    fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    with os.fdopen(fd, "wb") as f:
+        f.write(comm.ID_MAGIC + token + payload)
+    os.replace(path + ".tmp", path)
+
+
 def test_rendezvous_file_for_waiting_ranks(tmp_path, monkeypatch):
     """Ranks > 0 wait for the file rank 0 publishes atomically; the default name is unique per launcher."""
     import threading
-    import time
     from enstop_amd import comm
+    monkeypatch.delenv("PLSA_COMM_ID_FILE", raising=False)
     path = str(tmp_path / "rccl.id")
     payload = bytes(range(128))
-
-    def publish():
-        time.sleep(0.2)
-        with open(path + ".tmp", "wb") as f:
-            f.write(payload)
-        os.replace(path + ".tmp", path)
-    t = threading.Thread(target=publish)
+    t = threading.Thread(target=_publish, args=(comm, path, payload))
     t.start()
     assert comm.rendezvous_id(1, path, timeout=30) == payload
     t.join()
+    assert (os.stat(path).st_mode & 0o777) == 0o600
     with pytest.raises(TimeoutError):
         comm.rendezvous_id(1, str(tmp_path / "never.id"), timeout=0.2)
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29999")
-    monkeypatch.delenv("PLSA_COMM_ID_FILE", raising=False)
     monkeypatch.delenv("PLSA_LAUNCH_NONCE", raising=False)
     monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
     name = comm.default_id_file()
@@ -150,47 +160,90 @@ def test_rendezvous_file_for_waiting_ranks(tmp_path, monkeypatch):
     assert isinstance(comm.current(), comm.SingleComm) and comm.current().world == 1
 
 
-def test_stale_rendezvous_file_is_ignored(tmp_path):
-    """A crashed earlier launch may leave a 128-byte id at the very path this launch uses (same parent pid in a
-    container).  Waiting ranks must not take it: they only accept a file younger than their launcher, and rank 0
-    removes what it finds before it publishes."""
+def test_stale_rendezvous_file_is_ignored(tmp_path, monkeypatch):
+    """A crashed earlier launch may leave an id at the very path this launch uses.  Waiting ranks must not take it:
+    the file carries the launch token of whoever wrote it and only THIS launch's token is accepted (no clock is
+    compared: ADVICE r03 -- a launcher that starts after rank 0 published, or a file system whose clock lags, made
+    the mtime rule reject valid ids); rank 0 removes what it finds before it publishes."""
     import threading
-    import time
     from enstop_amd import comm
+    monkeypatch.delenv("PLSA_COMM_ID_FILE", raising=False)
     path = str(tmp_path / "rccl.id")
-    stale = bytes([7]) * 128
-    with open(path, "wb") as f:
-        f.write(stale)
-    old = comm._parent_start_epoch() - 3600.0                          # published an hour before the launcher started
-    os.utime(path, (old, old))
-    with pytest.raises(TimeoutError):
-        comm.rendezvous_id(1, path, timeout=0.3)                        # the stale file is not accepted
+    other_launch = b"x_1_1".ljust(comm.TOKEN_BYTES, b"\0")
+    _publish(comm, path, bytes([7]) * 128, token=other_launch, delay=0)
+    with pytest.raises(TimeoutError, match="token mismatch"):
+        comm.rendezvous_id(1, path, timeout=0.3)
+    with open(path, "wb") as f:                                         # the pre-round-4 format: 128 raw bytes
+        f.write(bytes([7]) * 128)
+    with pytest.raises(TimeoutError, match="malformed"):
+        comm.rendezvous_id(1, path, timeout=0.3)
     fresh = bytes(range(128))
-
-    def publish():                                                      # what rank 0 does (without needing a GPU)
-        time.sleep(0.2)
-        os.unlink(path)
-        fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
-        with os.fdopen(fd, "wb") as f:
-            f.write(fresh)
-        os.replace(path + ".tmp", path)
-    t = threading.Thread(target=publish)
+    t = threading.Thread(target=_publish, args=(comm, path, fresh))
     t.start()
     assert comm.rendezvous_id(1, path, timeout=30) == fresh
     t.join()
-    assert (os.stat(path).st_mode & 0o777) == 0o600
+    # the file may be much OLDER than the waiting rank's launcher and is still accepted (same token)
+    os.utime(path, (1.0, 1.0))
+    assert comm.rendezvous_id(1, path, timeout=1) == fresh
 
 
-def test_file_comm_refuses_left_over_files(tmp_path, monkeypatch):
+def test_explicit_id_file_shared_by_two_launchers(tmp_path, monkeypatch):
+    """PLSA_COMM_ID_FILE shared by ranks whose parents differ (a second torchrun, ssh sessions): the parent pid is
+    not part of the token there -- only the nonce the launchers export is compared (none: any well-formed file)."""
+    from enstop_amd import comm
+    path = str(tmp_path / "shared.id")
+    monkeypatch.setenv("PLSA_COMM_ID_FILE", path)
+    monkeypatch.delenv("PLSA_LAUNCH_NONCE", raising=False)
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    assert comm._rendezvous_token(path) == b"".ljust(comm.TOKEN_BYTES, b"\0")
+    _publish(comm, path, bytes(range(128)), delay=0)
+    assert comm.rendezvous_id(1, path, timeout=1) == bytes(range(128))
+    monkeypatch.setenv("PLSA_LAUNCH_NONCE", "job7")
+    with pytest.raises(TimeoutError, match="token mismatch"):          # written without the nonce: another launch
+        comm.rendezvous_id(1, path, timeout=0.3)
+    _publish(comm, path, bytes(range(128)), delay=0)
+    assert comm.rendezvous_id(1, path, timeout=1) == bytes(range(128))
+
+
+def test_file_comm_instances_and_cleanup(tmp_path, monkeypatch):
     from enstop_amd import comm
     monkeypatch.setenv("PLSA_LAUNCH_NONCE", "abc")
     c = comm.FileComm(str(tmp_path / "x"), 0, 1)
     c.barrier(); c.barrier()
     assert len([f for f in os.listdir(c.dir) if f.endswith(".npy")]) == 1   # older exchanges are deleted
+    d1 = c.dir
+    c.close()                                                               # final barrier, last file and directory go
+    assert not os.path.exists(d1)
+    c2 = comm.FileComm(str(tmp_path / "x"), 0, 1)                           # same launch, same process: a fresh directory
+    assert c2.dir != d1
+    c2.barrier()
+    # a directory that already holds this rank's files (a crashed run with the same token and instance number) is refused
+    comm.FileComm._instances -= 1
     with pytest.raises(RuntimeError):
-        comm.FileComm(str(tmp_path / "x"), 0, 1)                             # same launch token, files present
+        comm.FileComm(str(tmp_path / "x"), 0, 1)
     monkeypatch.setenv("PLSA_LAUNCH_NONCE", "def")
     comm.FileComm(str(tmp_path / "x"), 0, 1).barrier()                      # a new launch gets a fresh directory
+
+
+def test_failure_line_names_rank_stage_and_id_file(tmp_path, monkeypatch, capsys):
+    """a rank that dies in the multi-GPU start-up says where.  Here: the rendezvous times out
+    (rank 0 never publishes, e.g. it was killed); the line carries rank, world, device, stage and the id file."""
+    from enstop_amd import comm
+
+    class FakeEngine:
+        device = 3
+        _h = None
+    monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("PLSA_RENDEZVOUS_TIMEOUT", "0.3")
+    monkeypatch.delenv("PLSA_COMM_ID_FILE", raising=False)
+    path = str(tmp_path / "never.id")
+    with pytest.raises(TimeoutError):
+        comm.init_from_env(eng=FakeEngine(), id_file=path)
+    err = capsys.readouterr().err
+    line = [ln for ln in err.splitlines() if ln.startswith("[enstop_amd rank 1/2 device 3]")]
+    assert len(line) == 1, err
+    assert "stage 'id read'" in line[0] and path in line[0] and "TimeoutError" in line[0] and "rccl:" in line[0]
+    comm.install(None)
 
 
 def test_bench_refuses_gpus_world_mismatch(tmp_path):

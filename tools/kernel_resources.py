@@ -8,7 +8,6 @@ and prints one line per instantiation of the hot kernels for the BASELINE shapes
 k = 20 -> Shape<8,1,false>, k = 32 -> Shape<8,1,true>, k = 64 -> Shape<16,1,true>, k = 128 -> Shape<16,2,true>."""
 import argparse
 import os
-import re
 import subprocess
 import sys
 
@@ -16,37 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from enstop_amd import build as hb  # noqa: E402
 
-HOT = ("k_col_pass", "k_row_pass", "k_e_step", "k_loglik", "k_col_reduce_norm", "k_col_tail")
-SHAPES = {"Shape<8, 1, false>": "k=20", "Shape<8, 1, true>": "k=32", "Shape<16, 1, true>": "k=64",
-          "Shape<16, 2, true>": "k=128"}
-
-
 def collect(defines):
     cmd = [hb.HIPCC] + hb.FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + ["-D" + d for d in defines] + \
           [hb.SRC, "-o", "/tmp/plsa_resource_probe.so", "-L" + os.path.join(hb.ROCM, "lib"), "-lrccl"]
     txt = subprocess.run(cmd, capture_output=True, text=True).stderr
-    blocks = re.split(r"remark: Function Name: ", txt)[1:]
-    rows = []
-    for b in blocks:
-        name = b.split(" ")[0].strip()
-
-        def g(key):
-            mm = re.search(re.escape(key) + r": (\d+)", b)
-            return int(mm.group(1)) if mm else -1
-        rows.append([name, g("VGPRs"), g("AGPRs"), g("TotalSGPRs"), g("ScratchSize [bytes/lane]"),
-                     g("Occupancy [waves/SIMD]"), g("LDS Size [bytes/block]")])
-    dem = subprocess.run(["c++filt"] + [r[0] for r in rows], capture_output=True, text=True).stdout.split("\n")
-    out = []
-    for r, d in zip(rows, dem):
-        d = d.replace("plsa::", "").replace("(anonymous namespace)::", "")
-        if not any(d.startswith("void " + h) or d.startswith(h) for h in HOT):
-            continue
-        shape = next((v for s, v in SHAPES.items() if s in d), None)
-        if shape is None:
-            continue
-        short = re.sub(r"\(.*", "", d.replace("void ", ""))
-        out.append((shape, short, r[1], r[2], r[3], r[4], r[5], r[6]))
-    return sorted(set(out))
+    return [(r["shape"], r["kernel"], r["vgprs"], r["agprs"], r["sgprs"], r["scratch"], r["waves_per_simd"], r["lds_bytes"])
+            for r in hb.parse_resource_remarks(txt)]
 
 
 if __name__ == "__main__":
