@@ -20,12 +20,13 @@ ap.add_argument("--flags", default="fused")
 ap.add_argument("--events", action="store_true")
 ap.add_argument("--estep", action="store_true", help="time the materialising E-step kernel instead of fits")
 ap.add_argument("--tag", default="")
+ap.add_argument("--no-zero-arm", action="store_true", help="stop test without the `change == 0` arm (timing experiments)")
 a = ap.parse_args()
 cfg = bench.CONFIGS[a.config]
 eng = Engine(0)
 nnz = eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], seed=0)
 U0, V0 = bench.init_factors(cfg["n"], cfg["m"], cfg["k"], 42)
-flags = (PLSA_FUSED if a.flags == "fused" else 0)
+flags = (PLSA_FUSED if a.flags == "fused" else 0) | (16 if a.no_zero_arm else 0)
 eng.set_factors(U0, V0)
 if a.estep:
     eng.timing(True)

@@ -459,6 +459,58 @@ __global__ __launch_bounds__(256) void k_col_dyn(const int4 *__restrict__ items,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// 3b. document pass with the R most frequent words' P(w|z) rows staged in LDS (round 4).  `colidx` is TAGGED: a hot word
+//     is stored as ~slot (negative), every other word as its id.  Persistent grid (BPC workgroups per CU, grid-stride over
+//     the documents): the hot rows are staged once per workgroup.  T threads per workgroup share one LDS image.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, int UNR, int T>
+__global__ __launch_bounds__(T) void k_row_hot(const int *__restrict__ indptr, const int *__restrict__ colidx_tag,
+                                               const float *__restrict__ vals, int n, const int *__restrict__ row_order,
+                                               const float *__restrict__ U, const float *__restrict__ Vt,
+                                               const int *__restrict__ hot_words, int n_hot, float *__restrict__ U_new,
+                                               float thresh) {
+    constexpr int LPN = 16, GPB = T / 16;
+    extern __shared__ float4 hot[];          // [n_hot][16] float4 = n_hot rows of 256 B
+    for (int i = threadIdx.x; i < n_hot * 16; i += T)
+        hot[i] = plsa::ld4(Vt + (i64)hot_words[i >> 4] * 64 + (i & 15) * 4);
+    __syncthreads();
+    const int li = threadIdx.x % LPN, gid = threadIdx.x / LPN;
+    for (i64 r = (i64)blockIdx.x * GPB + gid; r < n; r += (i64)gridDim.x * GPB) {
+        const int d = row_order[r];
+        const int j0 = indptr[d], j1 = indptr[d + 1];
+        const float4 u = plsa::ld4(U + (i64)d * 64 + li * 4);
+        float4 acc = plsa::zero4();
+        int w_n = (j0 + li < j1) ? colidx_tag[j0 + li] : 0;
+        float x_n = (j0 + li < j1) ? vals[j0 + li] : 0.f;
+        for (int jb = j0; jb < j1; jb += LPN) {
+            const int w_l = w_n;
+            const float x_l = x_n;
+            const int jn = jb + LPN + li;
+            w_n = jn < j1 ? colidx_tag[jn] : 0;
+            x_n = jn < j1 ? vals[jn] : 0.f;
+            const int cnt = min(LPN, j1 - jb);
+            for (int s0 = 0; s0 < cnt; s0 += UNR) {
+                float4 a[UNR];
+                float x[UNR];
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) {
+                    const int w = __shfl(w_l, s0 + q, LPN);
+                    x[q] = __shfl(x_l, s0 + q, LPN);
+                    if (w < 0) a[q] = hot[(~w) * 16 + li];
+                    else a[q] = plsa::ld4(Vt + (i64)w * 64 + li * 4);
+                }
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) nz_update<MODE>(u, a[q], x[q], thresh, acc);
+            }
+        }
+        const float rown = plsa::group_sum<LPN>(plsa::hsum(acc));
+        float4 o = acc;
+        if (rown > 0.f) { o.x /= rown; o.y /= rown; o.z /= rown; o.w /= rown; }
+        plsa::st4(U_new + (i64)d * 64 + li * 4, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // 5. column pass, static schedule with MEASURED XCD boundaries.  The visiting list is cut into chunks of 16 items
 //    (one per group of a workgroup); XCD x (= blockIdx & 7) walks the chunks [lo[x], lo[x+1]).  Per chunk the
 //    workgroup also writes the float64 sum of its 16 accumulators (what norm_pwz is made of), so the results do
@@ -674,7 +726,7 @@ int main(int argc, char **argv) {
         valu_case<V_BPERM>("ds_bpermute_b32", 16, cus);
     }
     if (want("gather")) gather_cases(cus);
-    if (!want("row") && !want("col") && !want("timeline") && !want("dyn") && !want("balance") && !want("rowx") && !want("ntcol") && !want("order") && !want("rowsplit") && !want("rowlean") && !want("hitmiss")) return 0;
+    if (!want("row") && !want("col") && !want("timeline") && !want("dyn") && !want("balance") && !want("rowx") && !want("ntcol") && !want("order") && !want("rowsplit") && !want("rowlean") && !want("hitmiss") && !want("mix") && !want("headsplit") && !want("rowhot")) return 0;
 
     // ---- corpus ------------------------------------------------------------------------------------------
     i64 n = 1000000, m = 100000, nnz_t = 100000000;
@@ -1086,6 +1138,174 @@ int main(int argc, char **argv) {
         HM_CASE(16, 1, 60)
 #undef HM_CASE
         HC(hipFree(d_items)); HC(hipFree(d_p2)); HC(hipFree(d_cs)); HC(hipFree(d_lo)); HC(hipFree(d_te)); HC(hipFree(d_rhit)); HC(hipFree(d_rmiss));
+    }
+    if (want("mix")) {
+        // Round 4, VERDICT r03 item 2c: does mixing word classes INSIDE a chunk (= inside a workgroup / wave) let L2 hits
+        // overlap L2 misses better than the shipped homogeneous chunks?  All items are 64 entries long (the rare words'
+        // single short items are <3 % of the items), so a mixed chunk wastes no lanes.  Orders inside a band of 2048 documents:
+        //   0  head words first (shipped)
+        //   1  halves: position j of the first half next to position j of the second half, 8 + 8 per chunk
+        //   2  riffle: most frequent, least frequent, 2nd most frequent, 2nd least frequent, ...
+        //   3  quarters: 4 + 4 + 4 + 4 per chunk
+        const int seg = 64, band = 2048;
+        for (int mode = 0; mode < 4; ++mode) {
+            std::vector<int4> recs;
+            for (i64 c = 0; c < m; ++c)
+                for (int st = colptr[c]; st < colptr[c + 1]; st += seg) recs.push_back(make_int4((int)c, st, std::min(st + seg, colptr[c + 1]), 0));
+            const i64 ni = (i64)recs.size();
+            std::stable_sort(recs.begin(), recs.end(), [&](const int4 &a, const int4 &b) {
+                const int ba = csc_row[a.y] / band, bb = csc_row[b.y] / band;
+                if (ba != bb) return ba < bb;
+                return colptr[a.x + 1] - colptr[a.x] > colptr[b.x + 1] - colptr[b.x]; });
+            if (mode > 0) {
+                std::vector<int4> out(recs.size());
+                i64 b0 = 0;
+                while (b0 < ni) {
+                    i64 b1 = b0;
+                    const int bd = csc_row[recs[b0].y] / band;
+                    while (b1 < ni && csc_row[recs[b1].y] / band == bd) ++b1;
+                    const i64 L = b1 - b0;
+                    const int parts = mode == 1 ? 2 : (mode == 3 ? 4 : 0);
+                    if (mode == 2) {
+                        for (i64 j = 0; j < L; ++j) out[b0 + j] = recs[b0 + ((j & 1) ? L - 1 - j / 2 : j / 2)];
+                    } else {
+                        // `parts` strands of the sorted list, taken 16 / parts at a time from each in turn
+                        const int take = 16 / parts;
+                        std::vector<i64> pos(parts), end(parts);
+                        for (int q = 0; q < parts; ++q) { pos[q] = b0 + L * q / parts; end[q] = b0 + L * (q + 1) / parts; }
+                        i64 o = b0;
+                        while (o < b1)
+                            for (int q = 0; q < parts; ++q)
+                                for (int t = 0; t < take && pos[q] < end[q]; ++t) out[o++] = recs[pos[q]++];
+                    }
+                    b0 = b1;
+                }
+                recs.swap(out);
+            }
+            const int n_chunks = (int)((ni + 15) / 16);
+            int4 *d_items = dev(recs);
+            float *d_p2 = dev_alloc<float>((size_t)ni * 64);
+            double *d_cs = dev_alloc<double>((size_t)n_chunks * 64);
+            std::vector<int> lo(9);
+            for (int x = 0; x <= 8; ++x) lo[x] = (int)((i64)n_chunks * x / 8);
+            int *d_lo = dev(lo);
+            int grid = 8;
+            unsigned long long *d_te = dev_alloc<unsigned long long>((size_t)n_chunks * 8 + 16);
+            std::vector<unsigned long long> te((size_t)n_chunks * 8 + 16);
+            double ms = 0, msg = 0;
+            for (int iter = 0; iter < 5; ++iter) {
+                { int longest = 1; for (int x = 0; x < 8; ++x) longest = std::max(longest, lo[x + 1] - lo[x]); grid = 8 * longest; }
+                HC(hipMemcpyAsync(d_lo, lo.data(), sizeof(int) * 9, hipMemcpyHostToDevice, g_stream));
+                ms = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<0, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); });
+                msg = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<2, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); });
+                HC(hipMemsetAsync(d_te, 0, sizeof(unsigned long long) * grid, g_stream));
+                hipLaunchKernelGGL((k_col_chunks<0, 8, true>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te);
+                HC(hipStreamSynchronize(g_stream));
+                HC(hipMemcpy(te.data(), d_te, sizeof(unsigned long long) * grid, hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull, last[8] = {0};
+                for (int b = 0; b < grid; ++b) if (te[b]) { t0 = std::min(t0, te[b]); last[b & 7] = std::max(last[b & 7], te[b]); }
+                double T[8], mean = 0, size[8], tot = 0, accs = 0;
+                for (int x = 0; x < 8; ++x) { T[x] = std::max(1.0, (double)(last[x] - t0) / 100.0 + 100.0); mean += T[x] / 8; }
+                for (int x = 0; x < 8; ++x) { size[x] = (lo[x + 1] - lo[x]) * (1.0 + 0.8 * (mean / T[x] - 1.0)); tot += size[x]; }
+                for (int x = 0; x < 8; ++x) { accs += size[x]; lo[x + 1] = (int)(accs / tot * n_chunks + 0.5); }
+                lo[8] = n_chunks;
+                printf("{\"test\": \"col_mix\", \"order_in_band\": %d, \"round\": %d, \"ms\": %.4f, \"ms_gather_only\": %.4f}\n", mode, iter, ms, msg);
+                fflush(stdout);
+            }
+            HC(hipFree(d_items)); HC(hipFree(d_p2)); HC(hipFree(d_cs)); HC(hipFree(d_lo)); HC(hipFree(d_te));
+        }
+    }
+    if (want("headsplit")) {
+        // Round 4: how much of the column pass is the Zipf-HEAD words (their gathers are the L2 hits)?  Shipped schedule,
+        // items of the R most frequent words removed / kept alone.  If t(all) ~ t(without head) the head's gathers are already
+        // hidden behind the rare words' misses and serving them from LDS tiles instead of the L2 cannot pay.
+        const int seg = 64, band = 2048;
+        std::vector<int> by_len(m);
+        std::iota(by_len.begin(), by_len.end(), 0);
+        std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) { return colptr[a + 1] - colptr[a] > colptr[b + 1] - colptr[b]; });
+        std::vector<int> rank_of(m);
+        for (i64 r = 0; r < m; ++r) rank_of[by_len[r]] = (int)r;
+        for (int R : {0, 128, 1024}) {
+            for (int keep_head = 0; keep_head < (R ? 2 : 1); ++keep_head) {
+                std::vector<int4> recs;
+                i64 entries = 0;
+                for (i64 c = 0; c < m; ++c) {
+                    const bool head = rank_of[c] < R;
+                    if (R && (head != (keep_head == 1))) continue;
+                    for (int st = colptr[c]; st < colptr[c + 1]; st += seg) recs.push_back(make_int4((int)c, st, std::min(st + seg, colptr[c + 1]), 0));
+                    entries += colptr[c + 1] - colptr[c];
+                }
+                const i64 ni = (i64)recs.size();
+                std::stable_sort(recs.begin(), recs.end(), [&](const int4 &a, const int4 &b) {
+                    const int ba = csc_row[a.y] / band, bb = csc_row[b.y] / band;
+                    if (ba != bb) return ba < bb;
+                    return colptr[a.x + 1] - colptr[a.x] > colptr[b.x + 1] - colptr[b.x]; });
+                const int n_chunks = (int)((ni + 15) / 16);
+                int4 *d_items = dev(recs);
+                float *d_p2 = dev_alloc<float>((size_t)ni * 64);
+                double *d_cs = dev_alloc<double>((size_t)n_chunks * 64);
+                std::vector<int> lo(9);
+                for (int x = 0; x <= 8; ++x) lo[x] = (int)((i64)n_chunks * x / 8);
+                int *d_lo = dev(lo);
+                int grid = 8;
+                unsigned long long *d_te = dev_alloc<unsigned long long>((size_t)n_chunks * 8 + 16);
+                std::vector<unsigned long long> te((size_t)n_chunks * 8 + 16);
+                double ms = 0, msg = 0;
+                for (int iter = 0; iter < 5; ++iter) {
+                    { int longest = 1; for (int x = 0; x < 8; ++x) longest = std::max(longest, lo[x + 1] - lo[x]); grid = 8 * longest; }
+                    HC(hipMemcpyAsync(d_lo, lo.data(), sizeof(int) * 9, hipMemcpyHostToDevice, g_stream));
+                    ms = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<0, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); });
+                    msg = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<2, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); });
+                    HC(hipMemsetAsync(d_te, 0, sizeof(unsigned long long) * grid, g_stream));
+                    hipLaunchKernelGGL((k_col_chunks<0, 8, true>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te);
+                    HC(hipStreamSynchronize(g_stream));
+                    HC(hipMemcpy(te.data(), d_te, sizeof(unsigned long long) * grid, hipMemcpyDeviceToHost));
+                    unsigned long long t0 = ~0ull, last[8] = {0};
+                    for (int b = 0; b < grid; ++b) if (te[b]) { t0 = std::min(t0, te[b]); last[b & 7] = std::max(last[b & 7], te[b]); }
+                    double T[8], mean = 0, size[8], tot = 0, accs = 0;
+                    for (int x = 0; x < 8; ++x) { T[x] = std::max(1.0, (double)(last[x] - t0) / 100.0 + 100.0); mean += T[x] / 8; }
+                    for (int x = 0; x < 8; ++x) { size[x] = (lo[x + 1] - lo[x]) * (1.0 + 0.8 * (mean / T[x] - 1.0)); tot += size[x]; }
+                    for (int x = 0; x < 8; ++x) { accs += size[x]; lo[x + 1] = (int)(accs / tot * n_chunks + 0.5); }
+                    lo[8] = n_chunks;
+                }
+                printf("{\"test\": \"col_headsplit\", \"head_words\": %d, \"part\": \"%s\", \"entries\": %lld, \"share_of_nnz\": %.3f, \"items\": %lld, \"ms\": %.4f, \"ms_gather_only\": %.4f}\n",
+                       R, R == 0 ? "all words" : (keep_head ? "head words only" : "all but the head words"), (long long)entries, (double)entries / nnz, (long long)ni, ms, msg);
+                fflush(stdout);
+                HC(hipFree(d_items)); HC(hipFree(d_p2)); HC(hipFree(d_cs)); HC(hipFree(d_lo)); HC(hipFree(d_te));
+            }
+        }
+    }
+    if (want("rowhot")) {
+        // the R most frequent words (by document frequency) -> LDS slots; tagged column ids
+        std::vector<int> by_len(m);
+        std::iota(by_len.begin(), by_len.end(), 0);
+        std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) { return colptr[a + 1] - colptr[a] > colptr[b + 1] - colptr[b]; });
+        const double base = time_ms([&] { hipLaunchKernelGGL((plsa::k_row_pass<S, false, false>), dim3(grid_row), dim3(256), 0, g_stream, d_indptr, d_col, d_val, (int)n, d_order, d_U, d_Vt, (const float *)nullptr, d_Un, (const float *)nullptr, (float *)nullptr, 64, thresh, d_ll, (const int *)nullptr, (const int *)nullptr, 0, (i64)0, (float *)nullptr); });
+        printf("{\"test\": \"row_hot\", \"variant\": \"shipped k_row_pass<fused>\", \"ms\": %.4f}\n", base);
+        fflush(stdout);
+        for (int R : {0, 64, 128, 256, 512}) {
+            std::vector<int> slot(m, -1), hot_words(std::max(R, 1), 0);
+            i64 hot_entries = 0;
+            for (int r = 0; r < R; ++r) { slot[by_len[r]] = r; hot_words[r] = by_len[r]; hot_entries += colptr[by_len[r] + 1] - colptr[by_len[r]]; }
+            std::vector<int> tag(nnz);
+            for (i64 j = 0; j < nnz; ++j) tag[j] = slot[col[j]] >= 0 ? ~slot[col[j]] : col[j];
+            int *d_tag = dev(tag), *d_hot = dev(hot_words);
+            const size_t smem = (size_t)R * 256;
+#define RH_CASE(TT, BPC)                                                                                                     \
+            if (smem * (BPC) <= 160 * 1024 && (TT) * (BPC) <= 2048) {                                                        \
+                const int grid = cus * (BPC);                                                                                \
+                HC(hipFuncSetAttribute((const void *)k_row_hot<0, 4, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                HC(hipFuncSetAttribute((const void *)k_row_hot<2, 4, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                const double f_ = time_ms([&] { hipLaunchKernelGGL((k_row_hot<0, 4, TT>), dim3(grid), dim3(TT), smem, g_stream, d_indptr, d_tag, d_val, (int)n, d_order, d_U, d_Vt, d_hot, R, d_Un, thresh); }); \
+                const double g_ = time_ms([&] { hipLaunchKernelGGL((k_row_hot<2, 4, TT>), dim3(grid), dim3(TT), smem, g_stream, d_indptr, d_tag, d_val, (int)n, d_order, d_U, d_Vt, d_hot, R, d_Un, thresh); }); \
+                printf("{\"test\": \"row_hot\", \"hot_words\": %d, \"hot_share_of_nnz\": %.3f, \"threads\": %d, \"workgroups_per_cu\": %d, \"lds_kb\": %.0f, \"ms\": %.4f, \"ms_gather_only\": %.4f}\n", \
+                       R, (double)hot_entries / nnz, TT, BPC, smem / 1024.0, f_, g_);                                        \
+                fflush(stdout);                                                                                              \
+            }
+            RH_CASE(256, 8) RH_CASE(256, 4) RH_CASE(512, 4) RH_CASE(512, 2) RH_CASE(1024, 2) RH_CASE(1024, 1)
+#undef RH_CASE
+            HC(hipFree(d_tag)); HC(hipFree(d_hot));
+        }
     }
     if (want("rowx")) {
         // does the order of a document's entries matter?  as stored (by word id = random w.r.t. frequency) vs sorted by
