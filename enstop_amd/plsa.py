@@ -139,6 +139,30 @@ def log_likelihood(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, sample_weig
 # ------------------------------------------------------------------------------------------------
 # initialisation (host side, as in the reference)
 # ------------------------------------------------------------------------------------------------
+def _nndsvd(X, k):
+    """Non-negative double SVD start (Boutsidis & Gallopoulos 2008) as plsa.py:458-491 spells it out: a rank-k
+    randomized SVD of X (scikit-learn's PUBLIC `randomized_svd`, drawn from NumPy's global stream exactly like the
+    reference's call -- it passes no random_state), the leading triplet taken as is, every further pair (u_j, v_j)
+    replaced by the heavier of its positive / negative parts scaled by sqrt(s_j * |part_u| * |part_v|).
+    Vectorised over j; no private scikit-learn module."""
+    from sklearn.utils.extmath import randomized_svd
+    U, S, Vh = randomized_svd(X, k)
+    up, un = np.maximum(U, 0.0), np.maximum(-U, 0.0)             # [n, k]
+    vp, vn = np.maximum(Vh, 0.0), np.maximum(-Vh, 0.0)           # [k, m]
+    up_n, un_n = np.linalg.norm(up, axis=0), np.linalg.norm(un, axis=0)
+    vp_n, vn_n = np.linalg.norm(vp, axis=1), np.linalg.norm(vn, axis=1)
+    pos = up_n * vp_n > un_n * vn_n                              # plsa.py:478: strictly heavier positive part
+    with np.errstate(divide="ignore", invalid="ignore"):         # an all-zero part gives nan exactly like the reference
+        u = np.where(pos, up / up_n, un / un_n)
+        v = np.where(pos[:, None], vp / vp_n[:, None], vn / vn_n[:, None])
+        lbd = np.sqrt(S * np.where(pos, up_n * vp_n, un_n * vn_n))
+    W = np.ascontiguousarray(u * lbd)
+    H = np.ascontiguousarray(v * lbd[:, None])
+    W[:, 0] = np.sqrt(S[0]) * np.abs(U[:, 0])                    # the leading triplet is non-negative (plsa.py:463-466)
+    H[0, :] = np.sqrt(S[0]) * np.abs(Vh[0, :])
+    return W, H
+
+
 def plsa_init(X, k, init="random", rng=np.random):
     """Initial (P(z|d), P(w|z)) as float64, rows L1-normalised (plsa.py:412-513).
 
@@ -149,9 +173,7 @@ def plsa_init(X, k, init="random", rng=np.random):
         p_w_given_z = rng.rand(k, m)
         p_z_given_d = rng.rand(n, k)
     elif isinstance(init, str) and init == "nndsvd":
-        from sklearn.decomposition._nmf import _initialize_nmf
-        W, H = _initialize_nmf(X, k, init="nndsvd")
-        p_z_given_d, p_w_given_z = np.array(W, np.float64, order="C"), np.array(H, np.float64, order="C")
+        p_z_given_d, p_w_given_z = _nndsvd(X, k)
     elif isinstance(init, str) and init == "nmf":
         from sklearn.decomposition import non_negative_factorization
         W, H, _ = non_negative_factorization(X, n_components=k, init="nndsvd", solver="cd",

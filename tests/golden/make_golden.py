@@ -521,6 +521,16 @@ def gen_streamestimator(name, seed, empty_rows=(0, 17, 47)):
          transformed=tr, transformed_weighted=tr_w)
 
 
+def gen_nndsvd(name, seed):
+    """plsa_init(init="nndsvd") (plsa.py:458-491, 510-511).  The reference calls randomized_svd(X, k) without a
+    random_state: NumPy's global stream is seeded here (and in the test) so that both sides draw the same SVD."""
+    n, m, k = 60, 80, 6
+    X = make_counts(n, m, 0.15, seed)
+    np.random.seed(4242)
+    U, V = ref.plsa_init(X, k, init="nndsvd")
+    save(name, **csr_parts(X), k=np.int64(k), numpy_seed=np.int64(4242), U=U, V=V)
+
+
 def gen_combine(name, seed, t=24, m=150, min_samples=3):
     """Topic combination, enstop/enstop_.py:234-253 (KL), :283-296 (mutual reachability), :299-308 /
     :340-345 / :385-393 (cluster representatives).  Third-party calls are placeholders that record their
@@ -612,6 +622,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cfg1":      # the slowest one; needs the downloaded corpus
         gen_fit_cfg1()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "nndsvd":
+        gen_nndsvd("init_nndsvd_k6", seed=1000)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stream":    # only the streamed_plsa.py fixtures
         gen_stream_all()
         sys.exit(0)
@@ -648,6 +661,8 @@ if __name__ == "__main__":
     gen_combine("combine_t24", seed=800)
 
     gen_stream_all()
+
+    gen_nndsvd("init_nndsvd_k6", seed=1000)
 
     gen_fit_inner_ll_only("fit_inner_ll_only_weights", seed=900)
 

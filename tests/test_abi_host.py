@@ -83,6 +83,30 @@ def test_plsa_init_matches_reference(case):
     np.testing.assert_array_equal(V.astype(np.float32), g["V0"])
 
 
+def test_plsa_init_nndsvd_matches_reference():
+    """plsa_init(init="nndsvd") against the reference's own loop (plsa.py:458-491) on the same randomized SVD: both
+    sides call scikit-learn's public randomized_svd on NumPy's global stream, seeded alike."""
+    from enstop_amd import plsa_init
+    g = load_golden("init_nndsvd_k6")
+    X = golden_csr(g).astype(np.float64)             # the generator handed the reference a float64 matrix
+    np.random.seed(int(g["numpy_seed"]))
+    U, V = plsa_init(X, int(g["k"]), init="nndsvd")
+    np.testing.assert_allclose(U, g["U"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(V, g["V"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(U.sum(axis=1), 1.0, atol=1e-12)
+
+
+def test_no_private_sklearn_modules_in_the_product():
+    """scikit-learn's underscore modules are not an interface (`_hdbscan._linkage`, `_nmf._initialize_nmf`)."""
+    import re
+    pkg = os.path.join(ROOT, "enstop_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            bad = re.findall(r"(?:from|import)\s+sklearn(?:\.\w+)*\._\w+", src)
+            assert not bad, (f, bad)
+
+
 def test_plsa_init_errors():
     from enstop_amd import plsa_init
     X = sp.random(5, 7, density=0.5, format="csr", random_state=0)
