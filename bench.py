@@ -236,8 +236,8 @@ def spawn_ranks(args):
                     pending.remove(p_)
                     if code != 0 and rc == 0:
                         rc = code
-                        for q in pending:           # one rank died: the others would wait in a collective forever
-                            q.terminate()
+                        for q in pending:           # one rank died: the others would wait in a collective forever --
+                            q.terminate()           # SIGTERM: each prints the stage it was at (comm.install_termination_reporter)
             if time.time() > deadline:
                 rc = rc or 124
                 for q in pending:
@@ -403,6 +403,8 @@ def main():
     from enstop_amd import _lib, comm as plsa_comm
     from enstop_amd.engine import Engine, PLSA_FUSED
     import ctypes
+    if world > 1:
+        plsa_comm.install_termination_reporter(rank, world)
     cnt = ctypes.c_int(0)
     if _lib.load().plsa_device_count(ctypes.byref(cnt)) or cnt.value < 1:
         print("bench.py: no HIP device visible", file=sys.stderr)
@@ -417,6 +419,14 @@ def main():
               % (world, world), file=sys.stderr)
         sys.exit(3)
     device = local_rank if local_rank < n_dev else local_rank % n_dev
+    plsa_comm._STATE["device"] = device
+    fail_at = os.environ.get("PLSA_BENCH_FAIL_AT", "")          # test hook "rank:stage": that rank dies there (exit 9)
+
+    def stage(name):
+        plsa_comm.set_stage(name)
+        if fail_at == "%d:%s" % (rank, name):
+            print("bench.py: rank %d exits at stage '%s' (PLSA_BENCH_FAIL_AT)" % (rank, name), file=sys.stderr)
+            os._exit(9)
 
     cfg = CONFIGS[args.config]
     n, m, k = cfg["n"], cfg["m"], cfg["k"]
@@ -463,6 +473,7 @@ def main():
         return plsa_dist.gather_stack(eng, world, k, m).reshape(world, k, m)
 
     # ---- warmup (untimed): W EM iterations + the collective --------------------------------------
+    stage("warm-up gather")
     if args.warmup > 0:
         it, _ = eng.fit(None, n_iter=args.warmup, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=flags)
         assert it == args.warmup
@@ -470,7 +481,7 @@ def main():
 
     # ---- timed regions: three times exactly K EM iterations, each bracketed by barrier + synchronize; the
     # MEDIAN region is reported (its per-kernel events, its wall time), all three are listed
-    plsa_comm.set_stage("timed")
+    stage("timed")
     regions = []
     stack = None
     for _region in range(3):
@@ -597,7 +608,7 @@ def main():
                     out["cpu_baseline"]["whole_corpus"] = "failed: %r" % (e,)
     # ---- measured ensemble: the product's own call, two members per rank (see the module docstring) -------------
     if not args.no_ensemble:
-        plsa_comm.set_stage("ensemble")
+        stage("ensemble")
         try:
             out["ensemble"] = ensemble_leg(eng, comm, k, world, rank, args, rccl_init_s)
             out["ensemble_fits_per_min"] = out["ensemble"]["fits_per_min"]
@@ -651,4 +662,15 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as exc:        # one line per rank that says where a multi-GPU run died; then the traceback
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            try:
+                from enstop_amd import comm as _c
+                _c.report_failure(exc)
+            except Exception:
+                pass
+        raise

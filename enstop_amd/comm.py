@@ -60,6 +60,31 @@ def report_failure(exc, rank=None, world=None, eng=None):
     return line
 
 
+def install_termination_reporter(rank=None, world=None, eng=None):
+    """When a launcher (torchrun, bench.py's spawner) tears a job down after ONE rank failed, the surviving ranks
+    are usually blocked inside a collective -- in C, where a Python-level signal handler never runs.  This installs
+    a wake-up descriptor for SIGTERM (written by CPython's C-level handler the moment the signal arrives) and a
+    daemon thread that prints this rank's `report_failure` line and exits with status 143.  Main thread only."""
+    import signal
+    import threading
+    r, w = os.pipe()
+    os.set_blocking(w, False)
+    signal.signal(signal.SIGTERM, lambda *a: None)          # keep the default action (silent death) from running
+    signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+
+    def watch():
+        try:
+            os.read(r, 1)
+        except OSError:
+            return
+        report_failure(RuntimeError("terminated by the launcher (SIGTERM): another rank failed or a deadline passed"),
+                       rank, world, eng)
+        os._exit(143)
+    t = threading.Thread(target=watch, name="plsa-termination-reporter", daemon=True)
+    t.start()
+    return t
+
+
 def _run_order(g):
     """[world, slots, k, m] as gathered rank by rank -> [slots * world, k, m] in run order (r = slot * world + rank)."""
     world, slots = g.shape[:2]

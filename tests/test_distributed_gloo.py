@@ -246,6 +246,33 @@ def test_failure_line_names_rank_stage_and_id_file(tmp_path, monkeypatch, capsys
     comm.install(None)
 
 
+def test_terminated_rank_reports_its_stage(tmp_path):
+    """A launcher tears the job down with SIGTERM while this rank sits inside a C call (a collective): the
+    termination reporter still prints the stage line and the rank exits with 143."""
+    import signal
+    import time
+    code = (
+        "import ctypes, os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "from enstop_amd import comm\n"
+        "comm.install_termination_reporter(rank=3, world=8)\n"
+        "comm._STATE.update(device=3, id_file='/tmp/x.id')\n"
+        "comm.set_stage('timed')\n"
+        "print('ready', flush=True)\n"
+        "libc = ctypes.CDLL(None)\n"
+        "t0 = time.time()\n"
+        "while time.time() - t0 < 60: libc.usleep(200000)   # blocked in C, like a rank inside ncclAllGather\n"
+    ) % ROOT
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.stdout.readline().strip() == "ready"
+    time.sleep(0.3)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=30)
+    assert p.returncode == 143, (p.returncode, err)
+    line = [ln for ln in err.splitlines() if ln.startswith("[enstop_amd rank 3/8 device 3]")]
+    assert len(line) == 1 and "stage 'timed'" in line[0] and "SIGTERM" in line[0], err
+
+
 def test_bench_refuses_gpus_world_mismatch(tmp_path):
     """`bench.py --gpus N` under a launcher whose WORLD_SIZE differs must fail, not report n_gpus wrongly."""
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")

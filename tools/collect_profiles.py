@@ -55,6 +55,12 @@ for src, dst in (("bench_cfg2_world2_files.json", "%s_bench_cfg2_world2_on_one_g
 f = os.path.join(G, "bench_cfg2_world2_rccl_on_one_gpu.txt")
 if os.path.exists(f):
     shutil.copy(f, os.path.join(P, "%s_bench_world2_rccl_refused_on_one_gpu.txt" % tag))
+f = os.path.join(G, "bench_world2_one_rank_killed.err")
+if os.path.exists(f):
+    keep = [ln for ln in open(f) if ("enstop_amd rank" in ln or "exits at stage" in ln or ln.startswith("rc "))]
+    with open(os.path.join(P, "%s_bench_world2_one_rank_killed_stage_lines.txt" % tag), "w") as o:
+        o.write("PLSA_BENCH_FAIL_AT=1:timed python bench.py --gpus 2 --config 2 --steps 20 --exchange files   (one GPU box, host-file test mode)\n")
+        o.writelines(keep)
 f = os.path.join(G, "prof", "bench_under_rocprof.json")
 if os.path.exists(f):
     json.dump(last_json(f), open(os.path.join(P, "%s_bench_cfg3_under_rocprofv3.json" % tag), "w"), indent=1)

@@ -5,12 +5,15 @@ R=$PWD
 mkdir -p $R/gpurun_out/prof
 export TMPDIR=/tmp
 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -3
-timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 300 gpurun_out/bench_default.err
+timeout 1500 python bench.py --cpu-baseline-full > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 300 gpurun_out/bench_default.err
 for c in 2 1 5; do timeout 900 python bench.py --config $c --no-cpu-baseline --no-pmc > gpurun_out/bench_cfg$c.json 2> gpurun_out/bench_cfg$c.err; done
 # the N = 2 launch path on this single-GPU box: bench.py spawns its own ranks; RCCL refuses two ranks on one
 # device, so this is the host-file TEST MODE (labelled as such in the JSON) -- and the RCCL attempt must fail
 timeout 600 python bench.py --gpus 2 --config 2 --steps 20 --no-cpu-baseline --exchange files > gpurun_out/bench_cfg2_world2_files.json 2> gpurun_out/bench_cfg2_world2_files.err
 timeout 600 python bench.py --gpus 2 --config 2 --steps 20 --no-cpu-baseline > gpurun_out/bench_cfg2_world2_rccl_on_one_gpu.out 2> gpurun_out/bench_cfg2_world2_rccl_on_one_gpu.err; echo "rccl world-2 on one GPU: rc $? (expected non-zero), stdout bytes $(wc -c < gpurun_out/bench_cfg2_world2_rccl_on_one_gpu.out)" | tee gpurun_out/bench_cfg2_world2_rccl_on_one_gpu.txt
+# multi-GPU first contact made cheap to read: rank 1 dies at the start of the timed region; rank 1's own line
+# and rank 0's "terminated by the launcher" line name rank, device, stage, id file
+PLSA_BENCH_FAIL_AT=1:timed timeout 600 python bench.py --gpus 2 --config 2 --steps 20 --no-cpu-baseline --no-pmc --exchange files > gpurun_out/bench_world2_one_rank_killed.out 2> gpurun_out/bench_world2_one_rank_killed.err; echo "rc $? (expected non-zero), stdout bytes $(wc -c < gpurun_out/bench_world2_one_rank_killed.out)" >> gpurun_out/bench_world2_one_rank_killed.err; grep -E "enstop_amd rank|exits at stage|^rc " gpurun_out/bench_world2_one_rank_killed.err
 python - <<'PY' > gpurun_out/stream_probe.txt
 from enstop_amd.engine import Engine
 e = Engine(0)
