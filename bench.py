@@ -251,14 +251,15 @@ def spawn_ranks(args):
 
 def pmc_child(args):
     """Short run for the counter passes (`rocprofv3 --pmc ... -- python bench.py --pmc-child`): the same
-    corpus and factors, two launches of the materialising E-step and two fused EM iterations."""
+    corpus and factors, two launches of the materialising E-step and four fused EM iterations."""
     from enstop_amd.engine import Engine, PLSA_FUSED
     cfg = CONFIGS[args.config]
     eng = Engine(0)
     eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], zipf_s=1.07, seed=args.seed)
     U0, V0 = init_factors(cfg["n"], cfg["m"], cfg["k"], 42)
     eng.set_factors(U0, V0)
-    eng.fit(None, n_iter=2, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=PLSA_FUSED)
+    # four iterations: the first two document passes carry a log-likelihood (k_row_pass<fused,LL>), the others do not
+    eng.fit(None, n_iter=4, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=PLSA_FUSED)
     for _ in range(2):
         eng.e_step(1e-32, want_host_copy=False)
     eng.synchronize()

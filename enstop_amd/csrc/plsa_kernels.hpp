@@ -10,8 +10,11 @@
 // and 512, 1024) makes kp a compile-time constant and removes every lane predicate.
 //
 // Latency hiding: each wave keeps UNR non-zeros' factor rows in flight (all gathers of a batch are
-// issued before the first use) and prefetches the next batch of (index, count) pairs; with 8 waves
-// per SIMD this is what lets the gathers run at L2 rate instead of one L2 round trip per non-zero.
+// issued before the first use) and prefetches the next batch of (index, count) pairs.  Occupancy as
+// hipcc reports it (enstop_amd/kernel_resources.json, written at build time; k = 64): document pass
+// 60 VGPR = 8 waves per SIMD, column pass 90 VGPR = 5 waves, materialising E-step (document-owned) 124
+// VGPR = 4 waves.  Round 4 measured that neither more waves (5 -> 8) nor more rows in flight (4 -> 16)
+// moves the column pass (profiles/r04_column_pass_bound.md): it sits at its L2-miss service bound.
 //
 // Reference statements implemented here (paths relative to the reference root):
 //   E-step            enstop/plsa.py:91-105      M-step scatter    enstop/plsa.py:182-194, 287-300
