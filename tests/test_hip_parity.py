@@ -649,6 +649,60 @@ def test_sharded_fit_matches_single_gpu_fit_midsize(amd):
     close_factors(U4, U1, tol=2e-5); close_factors(V4, V1, tol=2e-5)
 
 
+def test_resident_sample_weights_and_comm_diagnostics(amd):
+    """Round 4 ABI additions.  plsa_set_sample_weight: weights uploaded once apply to every later call that passes
+    none (the per-iteration calls of the split doc-sharded loop no longer copy + wait) -- same bits as passing them;
+    cleared with None; a matrix with another document count makes the next use an error.  plsa_comm_last_error returns
+    RCCL's text (empty without a failure).  An RcclComm asked to gather from ANOTHER engine falls back to the host path."""
+    import ctypes as C
+    from enstop_amd import comm
+    from enstop_amd.engine import Engine, DeviceError
+    rs = np.random.RandomState(5)
+    X = sp.random(800, 600, density=0.03, format="csr", random_state=rs, dtype=np.float32)
+    X.data = np.ceil(X.data * 4).astype(np.float32)
+    sw = (0.25 + 1.5 * rs.rand(800)).astype(np.float32)
+    U0, V0 = amd.plsa_init(X, 12, rng=np.random.RandomState(1))
+    with Engine() as eng:
+        eng.upload_csr(X)
+        eng.set_factors(U0.astype(np.float32), V0.astype(np.float32))
+        it_a, tr_a = eng.fit(sw, 9, 4, 0.0, 1e-32, amd.PLSA_FUSED, trace=True)
+        Ua, Va = eng.get_factors()
+        eng.set_factors(U0.astype(np.float32), V0.astype(np.float32))
+        eng.set_sample_weight(sw)
+        it_b, tr_b = eng.fit(None, 9, 4, 0.0, 1e-32, amd.PLSA_FUSED, trace=True)      # resident weights apply
+        Ub, Vb = eng.get_factors()
+        np.testing.assert_array_equal(Ub, Ua); np.testing.assert_array_equal(Vb, Va)
+        np.testing.assert_array_equal(tr_b, tr_a)
+        ll_w = eng.log_likelihood(None)
+        eng.set_sample_weight(None)
+        ll_1 = eng.log_likelihood(None)
+        assert ll_w != ll_1 and abs(ll_w - eng.log_likelihood(sw)) <= 1e-9 * abs(ll_w)
+        eng.set_sample_weight(sw)
+        eng.upload_csr(X[:500])
+        eng.set_factors(U0[:500].astype(np.float32), V0.astype(np.float32))
+        with pytest.raises(DeviceError, match="resident sample weights"):
+            eng.log_likelihood(None)
+        eng.set_sample_weight(None)
+        buf = C.create_string_buffer(256)
+        assert eng._L.plsa_comm_last_error(eng._h, buf, 256) == 0 and isinstance(buf.value, bytes)
+        assert eng._L.plsa_comm_last_error(None, buf, 256) == 0
+    # communicator bound to the process-wide engine, members fitted on another engine of the same GPU
+    eng0 = amd.engine.get_engine()
+    c = comm.RcclComm(eng0, 0, 1, comm.rendezvous_id(0, "/tmp/plsa_test_rccl2_%d.id" % os.getpid()))
+    try:
+        with Engine() as other:
+            other.upload_csr(X)
+            other.set_factors(U0.astype(np.float32), V0.astype(np.float32))
+            base = other.stack_reserve(1, 12, X.shape[1])
+            other.copy_components_to_device(base)
+            got = c.gather_stack(other, 1, 12, X.shape[1])
+            np.testing.assert_array_equal(got, V0.astype(np.float32)[None])
+            with pytest.raises(RuntimeError, match="bound to the engine"):
+                c.allreduce_accumulator(other)
+    finally:
+        c.close()
+
+
 def test_native_rccl_communicator_single_rank(amd):
     """The product exchange path -- RCCL called from the C ABI on the engine's own streams, no PyTorch in
     the process -- with a one-rank communicator (all a single-GPU box can host: RCCL refuses two ranks

@@ -726,7 +726,7 @@ int main(int argc, char **argv) {
         valu_case<V_BPERM>("ds_bpermute_b32", 16, cus);
     }
     if (want("gather")) gather_cases(cus);
-    if (!want("row") && !want("col") && !want("timeline") && !want("dyn") && !want("balance") && !want("rowx") && !want("ntcol") && !want("order") && !want("rowsplit") && !want("rowlean") && !want("hitmiss") && !want("mix") && !want("headsplit") && !want("rowhot")) return 0;
+    if (!want("row") && !want("col") && !want("timeline") && !want("dyn") && !want("balance") && !want("rowx") && !want("ntcol") && !want("order") && !want("rowsplit") && !want("rowlean") && !want("hitmiss") && !want("mix") && !want("headsplit") && !want("rowhot") && !want("rowcold")) return 0;
 
     // ---- corpus ------------------------------------------------------------------------------------------
     i64 n = 1000000, m = 100000, nnz_t = 100000000;
@@ -1305,6 +1305,39 @@ int main(int argc, char **argv) {
             RH_CASE(256, 8) RH_CASE(256, 4) RH_CASE(512, 4) RH_CASE(512, 2) RH_CASE(1024, 2) RH_CASE(1024, 1)
 #undef RH_CASE
             HC(hipFree(d_tag)); HC(hipFree(d_hot));
+        }
+    }
+    if (want("rowcold")) {
+        // document pass over the entries of all but the R most frequent words / of those words alone (the counterpart of
+        // "headsplit" for the column pass): what would remain of the pass if the head region were computed elsewhere
+        std::vector<int> by_len(m);
+        std::iota(by_len.begin(), by_len.end(), 0);
+        std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) { return colptr[a + 1] - colptr[a] > colptr[b + 1] - colptr[b]; });
+        for (int R : {0, 128, 1024}) {
+            std::vector<char> head(m, 0);
+            for (int r = 0; r < R; ++r) head[by_len[r]] = 1;
+            for (int keep_head = 0; keep_head < (R ? 2 : 1); ++keep_head) {
+                std::vector<int> ip(n + 1, 0), cc;
+                std::vector<float> vv;
+                cc.reserve(nnz); vv.reserve(nnz);
+                for (i64 d = 0; d < n; ++d) {
+                    for (int j = indptr[d]; j < indptr[d + 1]; ++j)
+                        if (!R || (head[col[j]] != 0) == (keep_head == 1)) { cc.push_back(col[j]); vv.push_back(val[j]); }
+                    ip[d + 1] = (int)cc.size();
+                }
+                std::vector<int> ord(n);
+                std::iota(ord.begin(), ord.end(), 0);
+                std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return ip[a + 1] - ip[a] > ip[b + 1] - ip[b]; });
+                int *d_ip = dev(ip), *d_cc = dev(cc), *d_ord = dev(ord);
+                float *d_vv = dev(vv);
+                const double shipped = time_ms([&] { hipLaunchKernelGGL((plsa::k_row_pass<S, false, false>), dim3(grid_row), dim3(256), 0, g_stream, d_ip, d_cc, d_vv, (int)n, d_ord, d_U, d_Vt, (const float *)nullptr, d_Un, (const float *)nullptr, (float *)nullptr, 64, thresh, d_ll, (const int *)nullptr, (const int *)nullptr, 0, (i64)0, (float *)nullptr); });
+                const double full = time_ms([&] { hipLaunchKernelGGL((k_row_variant<0, 4>), dim3(grid_row), dim3(256), 0, g_stream, d_ip, d_cc, d_vv, (int)n, d_ord, d_U, d_Vt, d_Un, thresh); });
+                const double gath = time_ms([&] { hipLaunchKernelGGL((k_row_variant<2, 4>), dim3(grid_row), dim3(256), 0, g_stream, d_ip, d_cc, d_vv, (int)n, d_ord, d_U, d_Vt, d_Un, thresh); });
+                printf("{\"test\": \"row_cold\", \"head_words\": %d, \"part\": \"%s\", \"entries\": %lld, \"share_of_nnz\": %.3f, \"ms_shipped_kernel\": %.4f, \"ms_variant\": %.4f, \"ms_gather_only\": %.4f}\n",
+                       R, R == 0 ? "all words" : (keep_head ? "head words only" : "all but the head words"), (long long)cc.size(), (double)cc.size() / nnz, shipped, full, gath);
+                fflush(stdout);
+                HC(hipFree(d_ip)); HC(hipFree(d_cc)); HC(hipFree(d_ord)); HC(hipFree(d_vv));
+            }
         }
     }
     if (want("rowx")) {
