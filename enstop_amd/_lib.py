@@ -68,6 +68,7 @@ SIGNATURES = {
     "plsa_comm_barrier": (C.c_int, [_ctx]),
     "plsa_stack_reserve": (C.c_int, [_ctx, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "plsa_comm_allgather_stack": (C.c_int, [_ctx, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.POINTER(C.c_float))]),
+    "plsa_comm_allgather_stack_to": (C.c_int, [_ctx, _i64, _i64, _i32, _f32p]),
     "plsa_comm_allgather_host": (C.c_int, [_ctx, _vp, _i64, _vp]),
     "plsa_comm_allreduce_f64": (C.c_int, [_ctx, _f64p, _i64, _i32]),
     "plsa_comm_broadcast_host": (C.c_int, [_ctx, _vp, _i64, _i32]),

@@ -290,15 +290,23 @@ class Engine:
         self._ok(self._L.plsa_stack_reserve(self._h, int(slots), int(m), int(k), C.byref(base)))
         return int(base.value)
 
-    def comm_allgather_stack(self, slots, k, m, copy=True):
+    def comm_allgather_stack(self, slots, k, m, copy=True, out=None):
         """[slots * world, k, m] float32 in run order (run r = slot r // world of rank r % world): one grouped
-        ncclAllGather + one copy to page-locked host memory.  copy=False: a VIEW of that buffer, overwritten by
-        the next call on this engine."""
+        ncclAllGather, then ONE device-to-host copy -- straight into `out` (a C-contiguous float32 array of that size the
+        caller re-uses), into a fresh array (copy=True), or into the engine's page-locked buffer of which a VIEW is
+        returned (copy=False: overwritten by the next call on this engine)."""
         _, world = self.comm_info()
+        shape = (int(slots) * world, int(k), int(m))
+        if out is None and copy:
+            out = np.empty(shape, np.float32)
+        if out is not None:
+            if out.dtype != np.float32 or not out.flags.c_contiguous or out.size != shape[0] * shape[1] * shape[2]:
+                raise ValueError("out must be a C-contiguous float32 array of %d elements" % (shape[0] * shape[1] * shape[2]))
+            self._ok(self._L.plsa_comm_allgather_stack_to(self._h, int(slots), int(m), int(k), out.reshape(-1)))
+            return out.reshape(shape)
         p = C.POINTER(C.c_float)()
         self._ok(self._L.plsa_comm_allgather_stack(self._h, int(slots), int(m), int(k), C.byref(p)))
-        a = np.ctypeslib.as_array(p, shape=(int(slots) * world, int(k), int(m)))
-        return a.copy() if copy else a
+        return np.ctypeslib.as_array(p, shape=shape)
 
     def comm_allgather_host(self, a):
         a = np.ascontiguousarray(a)

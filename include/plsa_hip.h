@@ -191,6 +191,9 @@ int plsa_comm_info(plsa_ctx *ctx, int32_t *rank, int32_t *world);
 int plsa_comm_barrier(plsa_ctx *ctx);
 int plsa_stack_reserve(plsa_ctx *ctx, int64_t slots, int64_t m, int32_t k, void **base_device);
 int plsa_comm_allgather_stack(plsa_ctx *ctx, int64_t slots, int64_t m, int32_t k, float **host);
+/* the same gather with the caller's own host array as the destination ([slots * world][k][m] floats, e.g. the NumPy array
+ * that np.vstack would have returned, enstop_.py:231): one pass instead of page-locked buffer + copy */
+int plsa_comm_allgather_stack_to(plsa_ctx *ctx, int64_t slots, int64_t m, int32_t k, float *dst);
 int plsa_comm_allgather_host(plsa_ctx *ctx, const void *send, int64_t bytes, void *recv /* world * bytes */);
 int plsa_comm_allreduce_f64(plsa_ctx *ctx, double *inout, int64_t count, int32_t op);
 int plsa_comm_broadcast_host(plsa_ctx *ctx, void *buf, int64_t bytes, int32_t root);
