@@ -40,6 +40,9 @@ def report_failure(exc, rank=None, world=None, eng=None):
     """ONE line on stderr per rank that says where a multi-GPU run died: rank, device, stage reached, the id file,
     the exception and RCCL's own last error text (ncclGetLastError through the C ABI).  Callers keep the rule
     "non-zero exit status, no JSON line" -- this only makes the first 8-GPU failure cheap to read."""
+    if _STATE.get("reported") is exc:          # the same failure travelling up through several handlers: one line
+        return None
+    _STATE["reported"] = exc
     rank = os.environ.get("RANK", "0") if rank is None else rank
     world = os.environ.get("WORLD_SIZE", "1") if world is None else world
     rccl = ""
