@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised pin of the CPU oracle against THE REFERENCE ITSELF (build container only: imports /root/reference
-under the numba shim of make_golden.py).  The 35 committed fixtures pin the oracle on hand-picked cases; this
+under the numba shim of make_golden.py).  The 34 committed fixtures pin the oracle on hand-picked cases; this
 script draws hundreds of small random problems -- shapes, k, thresholds, sample weights, tolerances, test
 intervals, empty words -- runs enstop/plsa.py (fit, refit), enstop/streamed_plsa.py (fit, refit) and
 enstop/block_parallel_plsa.py (fit) on each and demands from oracle/plsa_oracle.c
