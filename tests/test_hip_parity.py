@@ -421,6 +421,25 @@ def test_duplicate_coo_entries_are_separate_nonzeros(amd, oracle):
     np.testing.assert_allclose(Uh, Uo, rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("k", [384, 500, 512, 1000, 1024])
+def test_largest_topic_counts_vs_oracle(amd, oracle, k):
+    """The widest lane shapes (64 lanes x 2 / 4 chunks; k = 512 and 1024 are FULL shapes, 500 and 1000 are not): both
+    schedules against the oracle, weighted, with a log-likelihood test every other iteration."""
+    rs = np.random.RandomState(k)
+    X = sp.random(90, 70, density=0.12, format="csr", random_state=rs, dtype=np.float32)
+    X.data = np.ceil(X.data * 5).astype(np.float32)
+    X = X[np.diff(X.indptr) > 0]
+    n = X.shape[0]
+    sw = (0.5 + rs.rand(n)).astype(np.float32)
+    kw = dict(n_iter=5, n_iter_per_test=2, tolerance=0.0, e_step_thresh=1e-32, random_state=4)
+    Uo, Vo, trace, iters = oracle.plsa_fit(X, k, sw, return_trace=True, **kw)
+    for mode in MODES.values():
+        U, V, info = amd.plsa_fit(X, k, sw, flags=mode, return_info=True, **kw)
+        assert info["n_iter"] == iters == 5
+        close_ll(info["log_likelihood_trace"][:len(trace)], trace, rtol=2e-5)
+        close_factors(U, Uo); close_factors(V, Vo)
+
+
 def test_limits_and_errors(amd):
     X = sp.random(50, 40, density=0.2, format="csr", random_state=0, dtype=np.float32)
     ones = np.ones(50, np.float32)
