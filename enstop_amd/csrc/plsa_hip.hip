@@ -658,10 +658,13 @@ int run_e_step(plsa_ctx *c, float thresh) {
         if (!items) CHK(ensure_roworder(c, &order));
         CHK(dispatch_shape(c, [&](auto S) {
             Scope s(c, "k_e_step");
-            hipLaunchKernelGGL((plsa::k_e_step_rows<decltype(S)>), dim3(grid), dim3(256), 0, c->stream,
-                               c->indptr, c->col, (int)c->n, order, c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
-                               p_base(c), c->kp, thresh, items ? c->eitem_row.as<int>() : nullptr,
-                               items ? c->eitem_start.as<int>() : nullptr, eseg, c->n_eitems);
+            auto go = [&](auto TN) {      // TN: the denormal-norm rescue is compiled in only for thresholds below TINY_THRESH
+                hipLaunchKernelGGL((plsa::k_e_step_rows<decltype(S), decltype(TN)::value>), dim3(grid), dim3(256), 0, c->stream,
+                                   c->indptr, c->col, (int)c->n, order, c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
+                                   p_base(c), c->kp, thresh, items ? c->eitem_row.as<int>() : nullptr,
+                                   items ? c->eitem_start.as<int>() : nullptr, eseg, c->n_eitems);
+            };
+            if (thresh < plsa::TINY_THRESH) go(std::true_type{}); else go(std::false_type{});
         }));
     } else {
         CHK(ensure_rowidx(c));
@@ -669,9 +672,12 @@ int run_e_step(plsa_ctx *c, float thresh) {
         const int grid = grid_for(c, tiles, 4);
         CHK(dispatch_shape(c, [&](auto S) {
             Scope s(c, "k_e_step");
-            hipLaunchKernelGGL((plsa::k_e_step<decltype(S)>), dim3(grid), dim3(256), 0, c->stream,
-                               c->rowidx.as<int>(), c->col, c->nnz, c->U[c->cu].as<float>(),
-                               c->Vt[c->cv].as<float>(), p_base(c), c->kp, thresh);
+            auto go = [&](auto TN) {
+                hipLaunchKernelGGL((plsa::k_e_step<decltype(S), decltype(TN)::value>), dim3(grid), dim3(256), 0, c->stream,
+                                   c->rowidx.as<int>(), c->col, c->nnz, c->U[c->cu].as<float>(),
+                                   c->Vt[c->cv].as<float>(), p_base(c), c->kp, thresh);
+            };
+            if (thresh < plsa::TINY_THRESH) go(std::true_type{}); else go(std::false_type{});
         }));
     }
     CHK(launch_check(c, "k_e_step"));
@@ -702,17 +708,18 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, floa
         float *Un = c->U[1 - c->cu].as<float>();
         double *llp = c->ll_partials.as<double>();
         const int n = (int)c->n, kp = c->kp;
-        auto go = [&](auto FP, auto LL, const char *name) {
+        auto go = [&](auto FP, auto LL, auto TN, const char *name) {
             Scope s(c, name);
-            hipLaunchKernelGGL((plsa::k_row_pass<Sh, decltype(FP)::value, decltype(LL)::value>),
+            hipLaunchKernelGGL((plsa::k_row_pass<Sh, decltype(FP)::value, decltype(LL)::value, decltype(TN)::value>),
                                dim3(grid), dim3(256), 0, c->ls, ip, cl, vl, n, order, U, Vt, P, Un,
                                d_sw, d_norm_pdz, kp, thresh, llp, ri_row, ri_start, rseg, n_ritems, rpart);
         };
         using T = std::true_type;
         using F = std::false_type;
-        if (from_p) go(T{}, F{}, "k_row_pass<P>");
-        else if (want_ll) go(F{}, T{}, "k_row_pass<fused,LL>");
-        else go(F{}, F{}, "k_row_pass<fused>");
+        const bool tiny = thresh < plsa::TINY_THRESH;   // denormal-norm rescue: compiled in for these thresholds only
+        if (from_p) go(T{}, F{}, F{}, "k_row_pass<P>");
+        else if (want_ll) { if (tiny) go(F{}, T{}, T{}, "k_row_pass<fused,LL>"); else go(F{}, T{}, F{}, "k_row_pass<fused,LL>"); }
+        else { if (tiny) go(F{}, F{}, T{}, "k_row_pass<fused>"); else go(F{}, F{}, F{}, "k_row_pass<fused>"); }
         if (items) {
             Scope s(c, "k_row_reduce");
             hipLaunchKernelGGL((plsa::k_row_reduce<Sh>), dim3(grid_for(c, c->n, 256 / Sh::LPN)), dim3(256), 0, c->ls,
@@ -861,15 +868,17 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int 
                 double *sums = c->colsum_rows.as<double>();
                 unsigned long long *te = c->t_end.as<unsigned long long>();
                 const int kp = c->kp;
-                auto go = [&](auto FP, auto TM) {
-                    hipLaunchKernelGGL((plsa::k_col_pass<Sh, decltype(FP)::value, decltype(TM)::value>), dim3(grid), dim3(256),
-                                       smem, c->ls, rec, n_visit, lo, cr, cvl, cp, U, Vt, p_base(c), d_sw, part, kp, thresh,
-                                       xcd_split, sums, te);
+                auto go = [&](auto FP, auto TM, auto TN) {
+                    hipLaunchKernelGGL((plsa::k_col_pass<Sh, decltype(FP)::value, decltype(TM)::value, decltype(TN)::value>),
+                                       dim3(grid), dim3(256), smem, c->ls, rec, n_visit, lo, cr, cvl, cp, U, Vt, p_base(c), d_sw,
+                                       part, kp, thresh, xcd_split, sums, te);
                 };
                 using T = std::true_type;
                 using F = std::false_type;
-                if (from_p) { if (timed) go(T{}, T{}); else go(T{}, F{}); }
-                else { if (timed) go(F{}, T{}); else go(F{}, F{}); }
+                const bool tiny = !from_p && thresh < plsa::TINY_THRESH;
+                if (from_p) { if (timed) go(T{}, T{}, F{}); else go(T{}, F{}, F{}); }
+                else if (tiny) { if (timed) go(F{}, T{}, T{}); else go(F{}, F{}, T{}); }
+                else { if (timed) go(F{}, T{}, F{}); else go(F{}, F{}, F{}); }
                 return launch_check(c, "k_col_pass");
             };
             rc = ensure_balance(c, n_chunks, xcd_split != 0, launch);

@@ -162,9 +162,11 @@ __device__ __forceinline__ void scale(float4 (&a)[CH], float s) {
 
 // Thresholds below the smallest normal float (e_step_thresh = 0 is legal) let a responsibility norm be
 // denormal; 1/norm then overflows although every quotient v/norm the reference forms (plsa.py:104) is
-// <= 1.  `tiny` (kernel-uniform: thresh < TINY_THRESH) enables a rescue that multiplies such a norm
+// <= 1.  TINY (a TEMPLATE parameter of the hot kernels, chosen by the host from thresh < TINY_THRESH) compiles in a rescue that multiplies such a norm
 // and its products by 2^100 first -- exact, powers of two -- so the reciprocal stays finite.  With the
-// default threshold (1e-32) every non-zero norm exceeds 1e-32 and the branch is never compiled in.
+// default threshold (1e-32) every non-zero norm exceeds 1e-32 and the rescue is not in the code at all: rounds 1-3 passed
+// `tiny` as a run-time flag, which left one exec-masked region of 5 multiplies + 4 scalar instructions per non-zero in every
+// launch (9 of ~45 instructions per entry) and kept the scheduler from interleaving the entries of a batch.
 constexpr float TINY_THRESH = 5e-38f;
 template <int CH>
 __device__ __forceinline__ void rescue_tiny(bool tiny, float &norm, float4 (&keep)[CH]) {
@@ -183,7 +185,7 @@ __device__ __forceinline__ void rescue_tiny(bool tiny, float &norm, float4 (&kee
 // the buffer carries one tile of slack so the last tile needs no store predicate.
 // Algorithmic bytes: 4(n+1) + 4 nnz + 4k nnz + 4k(n+m)   (SURVEY.md section 8d).
 // ------------------------------------------------------------------------------------------------
-template <class S>
+template <class S, bool TINY = false>
 __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step(const int *__restrict__ rowidx,
                                                 const int *__restrict__ colidx, i64 nnz,
                                                 const float *__restrict__ U,
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step(const int *__restric
     const int wave = threadIdx.x >> 6;
     const int g = lane / LPN, li = lane % LPN;
     const i64 tiles = (nnz + 63) >> 6;
-    const bool tiny = thresh < TINY_THRESH;
+    constexpr bool tiny = TINY;
     for (i64 t = (i64)blockIdx.x * 4 + wave; t < tiles; t += (i64)gridDim.x * 4) {
         const i64 base = t << 6;
         const i64 mine = base + lane;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step(const int *__restric
 // for corpora with few long documents), so the only gathers are the P(w|z) rows and the (doc) index
 // stream is not read at all.  Measured against the flat kernel above on config 3: the P(z|d) row
 // loads are L1/L2 hits there but still cost a tenth of the kernel (tools/experiments/README.md).
-template <class S>
+template <class S, bool TINY = false>
 __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step_rows(const int *__restrict__ indptr,
                                                      const int *__restrict__ colidx, int n,
                                                      const int *__restrict__ row_order,
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step_rows(const int *__re
     const int gid = threadIdx.x / LPN;
     const bool items = ritem_row != nullptr;
     const i64 n_work = items ? n_ritems : (i64)n;
-    const bool tiny = thresh < TINY_THRESH;
+    constexpr bool tiny = TINY;
     for (i64 r = (i64)blockIdx.x * GPB + gid; r < n_work; r += (i64)gridDim.x * GPB) {
         const int d = items ? ritem_row[r] : (row_order ? row_order[r] : (int)r);
         const int j0 = items ? ritem_start[r] : indptr[d];
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step_rows(const int *__re
 // once.  Rows are visited through `row_order` (descending length) so the groups of a wave finish
 // together; entries beyond the row end are padded with (word 0, count 0) and add exact zeros.
 // ------------------------------------------------------------------------------------------------
-template <class S, bool FROM_P, bool WANT_LL>
+template <class S, bool FROM_P, bool WANT_LL, bool TINY = false>
 __global__ __launch_bounds__(256, PLSA_WAVES) void k_row_pass(const int *__restrict__ indptr,
                                                   const int *__restrict__ colidx,
                                                   const float *__restrict__ vals, int n,
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_row_pass(const int *__restr
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
     double ll = 0.0;
-    const bool tiny = !FROM_P && thresh < TINY_THRESH;
+    constexpr bool tiny = !FROM_P && TINY;
     // item mode (ritem_row != nullptr): rows are cut into items of <= rseg entries, a group owns
     // one item and writes an un-normalised partial row that k_row_reduce adds up in item order.
     // Used when there are too few / too uneven rows to fill the chip (few long documents).
@@ -513,7 +515,7 @@ __device__ __forceinline__ void block_colsum(const float4 (&csum)[S::CH], int li
 }
 
 // one batch of UN entries of a column item: all UN gathers are issued before the first use
-template <class S, bool FROM_P, int UN>
+template <class S, bool FROM_P, int UN, bool TINY>
 __device__ __forceinline__ void col_batch(int s0, int d_l, float x_l, int p_l, int li, int kp, float thresh,
                                           const float *__restrict__ U, const float *__restrict__ P,
                                           const float4 (&vt)[S::CH], float4 (&acc)[S::CH]) {
@@ -540,7 +542,7 @@ __device__ __forceinline__ void col_batch(int s0, int d_l, float x_l, int p_l, i
         } else {
             float unth;
             float norm = group_sum<LPN>(products<CH, false>(a[q], vt, thresh, pz, unth));
-            rescue_tiny(thresh < TINY_THRESH, norm, pz);
+            rescue_tiny(TINY, norm, pz);
             x[q] *= inv_norm(norm);
         }
 #pragma unroll
@@ -562,7 +564,7 @@ __device__ __forceinline__ void col_batch(int s0, int d_l, float x_l, int p_l, i
 // (round 3: 2.35 -> 2.06 ms at config 3 with 256-entry items, 1.93 ms with 128).
 // Per chunk the workgroup also writes the float64 sum of its GPB accumulators (`chunk_sums`, the rows norm_pwz is
 // added up from, in chunk order): every result is independent of the boundaries and of the grid.
-template <class S, bool FROM_P, bool TIMED>
+template <class S, bool FROM_P, bool TIMED, bool TINY = false>
 __global__ __launch_bounds__(256, PLSA_WAVES_COL) void k_col_pass(const int4 *__restrict__ item_rec, i64 n_items,
                                                   const int *__restrict__ xcd_lo,
                                                   const int *__restrict__ csc_row,
@@ -613,10 +615,10 @@ __global__ __launch_bounds__(256, PLSA_WAVES_COL) void k_col_pass(const int4 *__
                 // are short (Zipf tail) and must not pay for UNR padded gathers
                 int s0 = 0;
                 for (; s0 + UNR <= cnt; s0 += UNR)
-                    col_batch<S, FROM_P, UNR>(s0, d_l, x_l, p_l, li, kp, thresh, U, P, vt, acc);
+                    col_batch<S, FROM_P, UNR, TINY>(s0, d_l, x_l, p_l, li, kp, thresh, U, P, vt, acc);
                 constexpr int TAIL = (UNR >= 2 && LPN >= 2) ? 2 : 1;
                 for (; s0 < cnt; s0 += TAIL)
-                    col_batch<S, FROM_P, TAIL>(s0, d_l, x_l, p_l, li, kp, thresh, U, P, vt, acc);
+                    col_batch<S, FROM_P, TAIL, TINY>(s0, d_l, x_l, p_l, li, kp, thresh, U, P, vt, acc);
             }
 #pragma unroll
             for (int j = 0; j < CH; ++j)
