@@ -77,6 +77,8 @@ struct plsa_ctx {
     DevBuf colptr, csc_row, csc_val, csc_pos, item_first, item_col, item_start, item_order, partial, heavy_cols;
     bool use_item_order = true, xcd_split = true;
     int chunks_per_lane = 2;
+    int row_lpn = 1, row_ch = 1;     // lane shape of the DOCUMENT pass (may differ from lpn / ch: see set_shape)
+    bool row_shape_8x2 = true;       // PLSA_ROW_SHAPE=0: document pass in the common shape
     int e_rows = -1;               // E-step traversal: 1 document-owned, 0 one group per non-zero, -1 by size (PLSA_E_ROWS)
     int mt_streams = 256;          // pieces the MT19937 init stream is cut into (PLSA_MT_STREAMS; 1 = sequential)
     i64 mt_min_blocks = 4096;      // ... once it is at least this many 624-word blocks long (PLSA_MT_MIN_BLOCKS)
@@ -326,6 +328,13 @@ int dispatch_shape(plsa_ctx *c, Fn &&fn) {
     return fail(c, "unsupported topic count k=%d (max 1024)", c->k);
 }
 
+// lane shape of the document pass (k_row_pass, k_row_reduce)
+template <class Fn>
+int dispatch_shape_row(plsa_ctx *c, Fn &&fn) {
+    if (c->row_lpn == 8 && c->row_ch == 2 && c->kp == 64) { fn(plsa::Shape<8, 2, true>{}); return 0; }
+    return dispatch_shape(c, fn);
+}
+
 int launch_check(plsa_ctx *c, const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, "launch of %s failed: %s", what, hipGetErrorString(e));
@@ -401,7 +410,7 @@ int exclusive_sum_int(plsa_ctx *c, const int *in, int *out, i64 count);
 int ensure_ritems(plsa_ctx *c) {
     if (c->ritems_valid) return 0;
     const i64 n = c->n;
-    const i64 group_slots = (i64)c->prop.multiProcessorCount * 32 * (64 / std::max(1, c->lpn));
+    const i64 group_slots = (i64)c->prop.multiProcessorCount * 32 * (64 / std::max(1, c->row_lpn));
     const double avg = (double)c->nnz / (double)std::max<i64>(n, 1);
     c->use_ritems = c->ritems_mode == 1 || (c->ritems_mode < 0 && n < 2 * group_slots && avg > 2.0 * c->rseg);
     c->n_ritems = 0;
@@ -603,6 +612,11 @@ void set_shape(plsa_ctx *c, int k) {
     c->lpn = lpn;
     c->ch = (kp / 4 + lpn - 1) / lpn;
     if (c->ch == 3) c->ch = 4;
+    // k = 64: the document pass runs as 8 lanes x 2 chunks (a wave covers 8 documents, one DPP step less per group sum,
+    // half the log-likelihood reductions per entry): its LL variant 1.94 -> 1.59 ms, the plain one 1.547 -> 1.530 ms at
+    // config 3, while the column pass is 3.5 % SLOWER in that shape (32 items per chunk) and keeps 16 x 1
+    c->row_lpn = c->lpn; c->row_ch = c->ch;
+    if (c->row_shape_8x2 && c->lpn == 16 && c->ch == 1 && kp == 64) { c->row_lpn = 8; c->row_ch = 2; }
     if (lpn != prev_lpn) {        // item lengths / the row-item decision depend on the lane shape
         c->ritems_valid = false;
         c->eitems_valid = false;
@@ -690,7 +704,7 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, floa
                  float *d_norm_pdz, int *ll_blocks) {
     CHK(ensure_ritems(c));
     const bool items = c->use_ritems && c->n_ritems > 0;
-    const int grid = grid_for(c, items ? c->n_ritems : c->n, 256 / c->lpn);
+    const int grid = grid_for(c, items ? c->n_ritems : c->n, 256 / c->row_lpn);
     const int *order = nullptr;
     if (!items) CHK(ensure_roworder(c, &order));
     if (items) CHK(ensure(c, c->rpartial, sizeof(float) * (size_t)c->n_ritems * c->kp));
@@ -700,7 +714,7 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, floa
     const int rseg = c->rseg;
     const i64 n_ritems = c->n_ritems;
     if (want_ll) CHK(ensure(c, c->ll_partials, sizeof(double) * (size_t)grid));
-    CHK(dispatch_shape(c, [&](auto S) {
+    CHK(dispatch_shape_row(c, [&](auto S) {
         using Sh = decltype(S);
         const int *ip = c->indptr, *cl = c->col;
         const float *vl = c->val, *U = c->U[c->cu].as<float>(), *Vt = c->Vt[c->cv].as<float>();
@@ -1104,6 +1118,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_MT_STREAMS")) c->mt_streams = std::max(1, std::min(4096, atoi(s)));
     if (const char *s = getenv("PLSA_MT_MIN_BLOCKS")) c->mt_min_blocks = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_SMALL_GRID")) c->small_grid = std::max(0, atoi(s));
+    if (const char *s = getenv("PLSA_ROW_SHAPE")) c->row_shape_8x2 = atoi(s) != 0;
     *out = c;
     return 0;
 }

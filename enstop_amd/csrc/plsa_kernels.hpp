@@ -97,7 +97,7 @@ struct Shape {
     // take the whole index batch in ONE round of gathers -- the pass is bound by the serial chain of its documents there
     // (config 2: 4730 -> 5470 iterations/s, config 1: 9490 -> 10060); 16-lane groups stay at PLSA_UNR (8 rows cost
     // registers and 1 % at config 3)
-    static constexpr int UNR = (LPN_ <= 8) ? LPN_ : ((LPN_ < PLSA_UNR) ? LPN_ : PLSA_UNR);
+    static constexpr int UNR = (LPN_ <= 8 && CH_ == 1) ? LPN_ : ((LPN_ < PLSA_UNR) ? LPN_ : PLSA_UNR);
     static constexpr int UNR_COL = (LPN_ < PLSA_UNR_COL) ? LPN_ : PLSA_UNR_COL;
     // E-step: gathers per burst, ideally the whole index batch (LPN entries) so that a wave alternates
     // between one long run of loads and one long run of stores (measured: 4 -> 5.81 ms, 16 -> 5.43 ms at k = 64)
