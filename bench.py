@@ -274,7 +274,8 @@ def short_kernel_name(k):
     head = k.replace("void ", "").split("(")[0]
     if "k_e_step" in head:
         return "k_e_step"
-    mm = re.search(r"(k_row_pass|k_col_pass)<.*>\s*,\s*(true|false)(?:\s*,\s*(true|false))?\s*>\s*$", head)
+    # flags BEHIND the Shape: k_row_pass<S, FROM_P, WANT_LL[, TINY]>, k_col_pass<S, FROM_P, TIMED[, TINY]>
+    mm = re.search(r"(k_row_pass|k_col_pass)<.*>\s*,\s*(true|false)(?:\s*,\s*(true|false))?(?:\s*,\s*(?:true|false))?\s*>\s*$", head)
     if not mm:
         return None
     if mm.group(1) == "k_col_pass":
@@ -336,8 +337,9 @@ def hot_kernel_table(k, kernels, traffic, source):
     except Exception:
         pass
     shape = {20: "k=20", 32: "k=32", 64: "k=64", 128: "k=128"}.get(k)
-    suffix = {"k_e_step": None, "k_row_pass<fused>": ", false, false>", "k_row_pass<fused,LL>": ", false, true>",
-              "k_col_pass<fused>": ", false, false>", "k_row_pass<P>": ", true, false>", "k_col_pass<P>": ", true, false>"}
+    suffix = {"k_e_step": ", false>", "k_row_pass<fused>": ", false, false, false>", "k_row_pass<fused,LL>": ", false, true, false>",
+              "k_col_pass<fused>": ", false, false, false>", "k_row_pass<P>": ", true, false, false>",
+              "k_col_pass<P>": ", true, false, false>"}
     out = {}
     for name, e in kernels.items():
         if name not in suffix or "algorithmic_GB" not in e:
@@ -354,11 +356,14 @@ def hot_kernel_table(k, kernels, traffic, source):
         for r in res.get("kernels", []):
             if r["shape"] != shape or not r["kernel"].startswith(base):
                 continue
-            if suffix[name] is not None and not (r["kernel"].startswith(base + "<") and r["kernel"].endswith(suffix[name])):
+            if not r["kernel"].endswith(suffix[name]):
                 continue
             row.setdefault("instantiations", []).append(
                 {"kernel": r["kernel"], "vgprs": r["vgprs"], "waves_per_simd": r["waves_per_simd"],
                  "lds_bytes": r["lds_bytes"], "scratch_bytes_per_lane": r["scratch"]})
+        if base == "k_row_pass" and any("Shape<8, 2" in i["kernel"] for i in row.get("instantiations", [])):
+            # k = 64: the document pass is launched in the 8 x 2 lane shape (plsa_hip.hip::set_shape)
+            row["instantiations"] = [i for i in row["instantiations"] if "Shape<8, 2" in i["kernel"]]
         out[name] = row
     return out
 

@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-f
 
 HOT = ("k_col_pass", "k_row_pass", "k_e_step", "k_loglik", "k_col_reduce_norm")
 SHAPES = {"Shape<8, 1, false>": "k=20", "Shape<8, 1, true>": "k=32", "Shape<16, 1, true>": "k=64",
-          "Shape<16, 2, true>": "k=128"}
+          "Shape<8, 2, true>": "k=64", "Shape<16, 2, true>": "k=128"}     # k = 64: the document pass runs as 8 x 2
 RESOURCES = os.path.join(HERE, "kernel_resources.json")
 
 

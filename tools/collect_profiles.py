@@ -31,7 +31,7 @@ def short(name):
 def label(name):
     """bench.py's label of a hot kernel from its C++ name"""
     s = short(name).replace(" ", "")
-    m = re.match(r"plsa::(k_\w+)<plsa::Shape<[\d,a-z]+>(?:,(\w+))?(?:,(\w+))?>", s)
+    m = re.match(r"plsa::(k_\w+)<plsa::Shape<[\d,a-z]+>(?:,(\w+))?(?:,(\w+))?(?:,\w+)?>", s)
     if not m:
         return None
     k, a, b = m.groups()
