@@ -197,6 +197,10 @@ bool g_contig = false;   // PLSA_CONTIG=1: ask for physically contiguous HBM for
 int ensure(plsa_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return 0;
+    // a buffer that GROWS is one whose size follows the data of the moment (the non-zeros of a bootstrap resample vary by
+    // a fraction of a percent from member to member): 6 % head-room ends the hipFree + hipMalloc pairs (device-wide
+    // synchronisations) after the first few members.  First allocations and buffers of 1 GB or more stay exact.
+    if (b.p && bytes < ((size_t)1 << 30)) bytes += bytes / 16;
     if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     if (g_contig && bytes >= ((size_t)64 << 20)) {
         if (hipExtMallocWithFlags(&b.p, bytes, hipDeviceMallocContiguous) == hipSuccess) { b.cap = bytes; return 0; }
