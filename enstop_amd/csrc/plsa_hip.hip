@@ -546,19 +546,24 @@ int ensure_csc(plsa_ctx *c) {
     unsigned long long *d_key = c->tmp2.as<unsigned long long>();
     // band of the visiting order: 512 KB of P(z|d) rows (2048 documents at k = 64), PLSA_ORDER_BAND documents
     const int band = c->order_band >= 0 ? c->order_band : std::max(64, (512 << 10) / (c->kp > 0 ? c->kp * 4 : 256));
+    // key = band index << len_bits | inverted column length (a column holds at most n entries); first document when band <= 0
+    int len_bits = 1;
+    while (((i64)1 << len_bits) <= c->n) ++len_bits;
+    int key_bits = len_bits;
+    if (band > 0) { i64 n_bands = c->n / band + 1; int bb = 1; while (((i64)1 << bb) < n_bands) ++bb; key_bits = len_bits + bb; }
     if (n_items > 0)
         hipLaunchKernelGGL(plsa::k_item_fill, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, c->stream,
                            c->colptr.as<int>(), c->item_first.as<int>(), (int)m, c->seg, c->csc_row.as<int>(),
-                           c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(), band, d_key,
+                           c->item_col.as<int>(), c->item_start.as<int>(), c->item_end.as<int>(), band, len_bits, d_key,
                            c->tmp1.as<int>(), n_items);
     CHK(launch_check(c, "k_item_fill"));
     if (n_items > 0) {   // visiting order: band-major, Zipf-head words first inside a band (stable)
         size_t bytes = 0;
         HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, d_key, d_key + ni,
-                                                     c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, 64, c->stream));
+                                                     c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, key_bits, c->stream));
         CHK(ensure(c, c->cubtmp, bytes));
         HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, bytes, d_key, d_key + ni,
-                                                     c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, 64, c->stream));
+                                                     c->tmp1.as<int>(), c->item_order.as<int>(), n_items, 0, key_bits, c->stream));
     }
     // visiting-order records (one 16-byte load per item instead of an index chain)
     CHK(ensure(c, c->item_rec, sizeof(int4) * ni));
