@@ -726,7 +726,7 @@ int main(int argc, char **argv) {
         valu_case<V_BPERM>("ds_bpermute_b32", 16, cus);
     }
     if (want("gather")) gather_cases(cus);
-    if (!want("row") && !want("col") && !want("timeline") && !want("dyn") && !want("balance") && !want("rowx") && !want("ntcol") && !want("order") && !want("rowsplit") && !want("rowlean") && !want("hitmiss") && !want("mix") && !want("headsplit") && !want("rowhot") && !want("rowcold")) return 0;
+    if (!want("row") && !want("col") && !want("timeline") && !want("dyn") && !want("balance") && !want("rowx") && !want("ntcol") && !want("order") && !want("rowsplit") && !want("rowlean") && !want("hitmiss") && !want("mix") && !want("headsplit") && !want("rowhot") && !want("rowcold") && !want("rowhitmiss")) return 0;
 
     // ---- corpus ------------------------------------------------------------------------------------------
     i64 n = 1000000, m = 100000, nnz_t = 100000000;
@@ -1339,6 +1339,32 @@ int main(int argc, char **argv) {
                 HC(hipFree(d_ip)); HC(hipFree(d_cc)); HC(hipFree(d_ord)); HC(hipFree(d_vv));
             }
         }
+    }
+    if (want("rowhitmiss")) {
+        // Round 4: the document pass (shipped kernel, 8 lanes x 2 chunks at k = 64) against three P(w|z) row maps:
+        // real word ids / word id & 8191 (2 MB table: every gather an L2 hit) / a pseudo-random word per ENTRY (the
+        // 25.6 MB table misses the 4 MB L2s and is served by the Infinity Cache).  rocprofv3 --pmc passes tell the
+        // three launches apart by the TAG template argument of the gather-only variant and by launch order for the
+        // shipped kernel (real, all-hit, all-miss, in that order, after the warm-up of each).
+        std::vector<int> col_hit(nnz), col_miss(nnz);
+        for (i64 j = 0; j < nnz; ++j) {
+            col_hit[j] = col[j] & 8191;
+            col_miss[j] = (int)(((uint64_t)col[j] * 2654435761ull + (uint64_t)j * 0x9E3779B97F4A7C15ull) % (uint64_t)m);
+        }
+        int *d_chit = dev(col_hit), *d_cmiss = dev(col_miss);
+        const int *maps[3] = {d_col, d_chit, d_cmiss};
+        const char *map_name[3] = {"real", "all-hit (2 MB table)", "all-miss in L2 (random row of the 25.6 MB table per entry)"};
+        using S82 = Shape<8, 2, true>;
+        const int grid82 = (int)std::min<i64>((n + 31) / 32, grid_cap);
+        for (int mp = 0; mp < 3; ++mp) {
+            const int *cc = maps[mp];
+            const double full = time_ms([&] { hipLaunchKernelGGL((plsa::k_row_pass<S82, false, false, false>), dim3(grid82), dim3(256), 0, g_stream, d_indptr, cc, d_val, (int)n, d_order, d_U, d_Vt, (const float *)nullptr, d_Un, (const float *)nullptr, (float *)nullptr, 64, thresh, d_ll, (const int *)nullptr, (const int *)nullptr, 0, (i64)0, (float *)nullptr); });
+            const double gath = time_ms([&] { hipLaunchKernelGGL((k_row_variant<2, 4>), dim3(grid_row), dim3(256), 0, g_stream, d_indptr, cc, d_val, (int)n, d_order, d_U, d_Vt, d_Un, thresh); });
+            printf("{\"test\": \"row_hitmiss\", \"row_map\": \"%s\", \"ms_shipped_kernel\": %.4f, \"ms_gather_only_probe_variant\": %.4f, \"rows_per_ns_shipped\": %.1f}\n",
+                   map_name[mp], full, gath, nnz / full / 1e6);
+            fflush(stdout);
+        }
+        HC(hipFree(d_chit)); HC(hipFree(d_cmiss));
     }
     if (want("rowx")) {
         // does the order of a document's entries matter?  as stored (by word id = random w.r.t. frequency) vs sorted by
