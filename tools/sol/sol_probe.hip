@@ -14,6 +14,7 @@
 // VALU issue rates and of random 256-byte row gathers against tables of L2 / Infinity-Cache / HBM size.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -587,6 +588,83 @@ __global__ __launch_bounds__(256, W) void k_col_chunks(const int4 *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// 5b. column pass, software-pipelined: the P(z|d) rows of the NEXT 8 entries are requested before the current 8 are
+//     reduced (round 4: both passes sit at ~80 % of the VALU issue ceiling AND ~80 % of their miss-service bound --
+//     does decoupling the gathers from the arithmetic of the same wave overlap them better?).  Same chunk schedule as
+//     k_col_chunks; padded entries read document 0 with count 0.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, int W>
+__global__ __launch_bounds__(256, W) void k_col_chunks_pipe(const int4 *__restrict__ items, i64 n_items, const int *__restrict__ lo,
+                                                            const int *__restrict__ csc_row, const float *__restrict__ csc_val,
+                                                            const float *__restrict__ U, const float *__restrict__ Vt,
+                                                            float *__restrict__ partial, double *__restrict__ chunk_sums, float thresh) {
+    constexpr int LPN = 16, GPB = 16, UNR = 8;
+    __shared__ double sred[GPB * 64];
+    const int li = threadIdx.x % LPN, gid = threadIdx.x / LPN;
+    const int x = blockIdx.x & 7;
+    const int nq = (gridDim.x + 7 - x) / 8;
+    for (int ch = lo[x] + (int)(blockIdx.x >> 3); ch < lo[x + 1]; ch += nq) {
+        const i64 io = (i64)ch * GPB + gid;
+        float4 acc = plsa::zero4();
+        if (io < n_items) {
+            const int4 rec = items[io];
+            const int w = rec.x, j0 = rec.y, j1 = rec.z;
+            const float4 vt = plsa::ld4(Vt + (i64)w * 64 + li * 4);
+            // index batches of 16 entries, two sub-batches of 8 each; (d_c, x_c): the index batch being consumed
+            int d_c = (j0 + li < j1) ? csc_row[j0 + li] : 0;
+            float x_c = (j0 + li < j1) ? csc_val[j0 + li] : 0.f;
+            float4 a_n[UNR];
+            float xs_n[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {                 // prologue: first sub-batch
+                xs_n[u] = __shfl(x_c, u, LPN);
+                a_n[u] = plsa::ld4(U + (i64)__shfl(d_c, u, LPN) * 64 + li * 4);
+            }
+            for (int jb = j0; jb < j1; jb += LPN) {
+                const int jn = jb + LPN + li;
+                const int d_nx = jn < j1 ? csc_row[jn] : 0;          // next index batch (requested a batch ahead)
+                const float x_nx = jn < j1 ? csc_val[jn] : 0.f;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float4 a_c[UNR];
+                    float xs_c[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) { a_c[u] = a_n[u]; xs_c[u] = xs_n[u]; }
+                    // request the next sub-batch: second half of this index batch, or first half of the next one
+                    const int d_src = half == 0 ? d_c : d_nx;
+                    const float x_src = half == 0 ? x_c : x_nx;
+                    const int base = half == 0 ? UNR : 0;
+                    const bool more = half == 0 ? (jb + UNR < j1) : (jb + LPN < j1);
+                    if (more) {
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u) {
+                            xs_n[u] = __shfl(x_src, base + u, LPN);
+                            a_n[u] = plsa::ld4(U + (i64)__shfl(d_src, base + u, LPN) * 64 + li * 4);
+                        }
+                    }
+                    if (half == 0 || jb + UNR < j1) {
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u) nz_update<MODE>(vt, a_c[u], xs_c[u], thresh, acc);
+                    }
+                }
+                d_c = d_nx; x_c = x_nx;
+            }
+            plsa::st4(partial + io * 64 + li * 4, acc);
+        }
+        double *p = sred + gid * 64 + li * 4;
+        p[0] = (double)acc.x; p[1] = (double)acc.y; p[2] = (double)acc.z; p[3] = (double)acc.w;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            double t = 0.0;
+#pragma unroll
+            for (int g = 0; g < GPB; ++g) t += sred[g * 64 + threadIdx.x];
+            chunk_sums[(i64)ch * 64 + threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // 6. document pass split in TIME by word class: phase 0 walks only a document's entries of frequent words (their
 //    P(w|z) rows fit the L2 and are not evicted by the stream of rare rows), phase 1 the rest.  The un-normalised
 //    accumulator travels through memory between the phases.  (Measured: slower, r03_row_pass_split_by_word_class_rejected.jsonl)
@@ -726,7 +804,7 @@ int main(int argc, char **argv) {
         valu_case<V_BPERM>("ds_bpermute_b32", 16, cus);
     }
     if (want("gather")) gather_cases(cus);
-    if (!want("row") && !want("col") && !want("timeline") && !want("dyn") && !want("balance") && !want("rowx") && !want("ntcol") && !want("order") && !want("rowsplit") && !want("rowlean") && !want("hitmiss") && !want("mix") && !want("headsplit") && !want("rowhot") && !want("rowcold") && !want("rowhitmiss")) return 0;
+    if (!want("row") && !want("col") && !want("timeline") && !want("dyn") && !want("balance") && !want("rowx") && !want("ntcol") && !want("order") && !want("rowsplit") && !want("rowlean") && !want("hitmiss") && !want("mix") && !want("headsplit") && !want("rowhot") && !want("rowcold") && !want("rowhitmiss") && !want("pipe")) return 0;
 
     // ---- corpus ------------------------------------------------------------------------------------------
     i64 n = 1000000, m = 100000, nnz_t = 100000000;
@@ -1365,6 +1443,67 @@ int main(int argc, char **argv) {
             fflush(stdout);
         }
         HC(hipFree(d_chit)); HC(hipFree(d_cmiss));
+    }
+    if (want("pipe")) {
+        // shipped schedule (64-entry items, band-major, head words first, one chunk per workgroup, measured boundaries):
+        // k_col_chunks against the software-pipelined k_col_chunks_pipe; partial sums compared
+        const int seg = 64, band = 2048;
+        std::vector<int4> recs;
+        for (i64 c = 0; c < m; ++c)
+            for (int st = colptr[c]; st < colptr[c + 1]; st += seg) recs.push_back(make_int4((int)c, st, std::min(st + seg, colptr[c + 1]), 0));
+        const i64 ni = (i64)recs.size();
+        std::stable_sort(recs.begin(), recs.end(), [&](const int4 &a, const int4 &b) {
+            const int ba = csc_row[a.y] / band, bb = csc_row[b.y] / band;
+            if (ba != bb) return ba < bb;
+            return colptr[a.x + 1] - colptr[a.x] > colptr[b.x + 1] - colptr[b.x]; });
+        const int n_chunks = (int)((ni + 15) / 16);
+        int4 *d_items = dev(recs);
+        float *d_p2 = dev_alloc<float>((size_t)ni * 64), *d_p3 = dev_alloc<float>((size_t)ni * 64);
+        double *d_cs = dev_alloc<double>((size_t)n_chunks * 64);
+        std::vector<int> lo(9);
+        for (int x = 0; x <= 8; ++x) lo[x] = (int)((i64)n_chunks * x / 8);
+        int *d_lo = dev(lo);
+        int grid = 8;
+        unsigned long long *d_te = dev_alloc<unsigned long long>((size_t)n_chunks * 8 + 16);
+        std::vector<unsigned long long> te((size_t)n_chunks * 8 + 16);
+        for (int iter = 0; iter < 5; ++iter) {
+            { int longest = 1; for (int x = 0; x < 8; ++x) longest = std::max(longest, lo[x + 1] - lo[x]); grid = 8 * longest; }
+            HC(hipMemcpyAsync(d_lo, lo.data(), sizeof(int) * 9, hipMemcpyHostToDevice, g_stream));
+            HC(hipMemsetAsync(d_te, 0, sizeof(unsigned long long) * grid, g_stream));
+            hipLaunchKernelGGL((k_col_chunks<0, 8, true>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te);
+            HC(hipStreamSynchronize(g_stream));
+            HC(hipMemcpy(te.data(), d_te, sizeof(unsigned long long) * grid, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, last[8] = {0};
+            for (int b = 0; b < grid; ++b) if (te[b]) { t0 = std::min(t0, te[b]); last[b & 7] = std::max(last[b & 7], te[b]); }
+            double T[8], mean = 0, size[8], tot = 0, accs = 0;
+            for (int x = 0; x < 8; ++x) { T[x] = std::max(1.0, (double)(last[x] - t0) / 100.0 + 100.0); mean += T[x] / 8; }
+            if (iter == 4) break;
+            for (int x = 0; x < 8; ++x) { size[x] = (lo[x + 1] - lo[x]) * (1.0 + 0.8 * (mean / T[x] - 1.0)); tot += size[x]; }
+            for (int x = 0; x < 8; ++x) { accs += size[x]; lo[x + 1] = (int)(accs / tot * n_chunks + 0.5); }
+            lo[8] = n_chunks;
+        }
+        { int longest = 1; for (int x = 0; x < 8; ++x) longest = std::max(longest, lo[x + 1] - lo[x]); grid = 8 * longest; }
+        HC(hipMemcpy(d_lo, lo.data(), sizeof(int) * 9, hipMemcpyHostToDevice));
+        for (int rep = 0; rep < 2; ++rep) {
+            const double base_f = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<0, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); });
+            const double base_g = time_ms([&] { hipLaunchKernelGGL((k_col_chunks<2, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te); });
+            hipLaunchKernelGGL((k_col_chunks<0, 8, false>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p2, d_cs, thresh, d_te);
+            printf("{\"test\": \"col_pipe\", \"variant\": \"k_col_chunks (8 rows per batch, no pipelining)\", \"ms\": %.4f, \"ms_gather_only\": %.4f}\n", base_f, base_g);
+#define PIPE_CASE(WV)                                                                                                        \
+            { const double f_ = time_ms([&] { hipLaunchKernelGGL((k_col_chunks_pipe<0, WV>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p3, d_cs, thresh); }); \
+              const double g_ = time_ms([&] { hipLaunchKernelGGL((k_col_chunks_pipe<2, WV>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p3, d_cs, thresh); }); \
+              hipLaunchKernelGGL((k_col_chunks_pipe<0, WV>), dim3(grid), dim3(256), 0, g_stream, d_items, ni, d_lo, d_cscrow, d_cscval, d_U, d_Vt, d_p3, d_cs, thresh); \
+              HC(hipStreamSynchronize(g_stream));                                                                           \
+              std::vector<float> h2(1 << 20), h3(1 << 20);                                                                   \
+              HC(hipMemcpy(h2.data(), d_p2, sizeof(float) * h2.size(), hipMemcpyDeviceToHost));                             \
+              HC(hipMemcpy(h3.data(), d_p3, sizeof(float) * h3.size(), hipMemcpyDeviceToHost));                             \
+              double md = 0; for (size_t i = 0; i < h2.size(); ++i) md = std::max(md, (double)std::fabs(h2[i] - h3[i]));     \
+              printf("{\"test\": \"col_pipe\", \"variant\": \"software-pipelined (next 8 rows requested before the current 8 are reduced)\", \"min_waves_per_simd\": %d, \"ms\": %.4f, \"ms_gather_only\": %.4f, \"max_abs_diff_of_partials\": %.3g}\n", WV, f_, g_, md); \
+              fflush(stdout); }
+            PIPE_CASE(1) PIPE_CASE(4) PIPE_CASE(5)
+#undef PIPE_CASE
+        }
+        HC(hipFree(d_items)); HC(hipFree(d_p2)); HC(hipFree(d_p3)); HC(hipFree(d_cs)); HC(hipFree(d_lo)); HC(hipFree(d_te));
     }
     if (want("rowx")) {
         // does the order of a document's entries matter?  as stored (by word id = random w.r.t. frequency) vs sorted by
