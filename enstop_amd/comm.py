@@ -70,6 +70,8 @@ def install_termination_reporter(rank=None, world=None, eng=None):
     daemon thread that prints this rank's `report_failure` line and exits with status 143.  Main thread only."""
     import signal
     import threading
+    if threading.current_thread() is not threading.main_thread():
+        return None                                          # signal handlers can only be installed from the main thread
     r, w = os.pipe()
     os.set_blocking(w, False)
     signal.signal(signal.SIGTERM, lambda *a: None)          # keep the default action (silent death) from running
