@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -33,6 +34,15 @@ using plsa::i64;
 namespace {
 
 thread_local std::string g_err;  // errors before a context exists
+
+// Ensemble members of a small corpus are fitted concurrently on several contexts of ONE device (two streams each).  The
+// HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES = 4 hardware queues by default, and streams that
+// share a queue run in submission order: a member's 1.9 ms single-workgroup initialisation chain then stalls another
+// member's EM kernels (20NG shape, four contexts: 7.0 -> 6.5 ms per member at engine level, 7 060 -> 7 770 ... 8 500
+// fits/min through ensemble_of_topics; single fits unchanged).  The runtime reads the variable at its first API call, so
+// a default set when this library is loaded is in time unless the host process has used HIP before; a value set by the
+// user is never overwritten.
+__attribute__((constructor)) void plsa_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
 
 struct DevBuf {
     void *p = nullptr;

@@ -12,6 +12,7 @@ import numpy as np
 from scipy.sparse import issparse, csr_matrix
 from sklearn.utils import check_random_state
 
+import os
 import threading
 
 from .engine import get_engine, get_member_engines
@@ -22,8 +23,10 @@ from .plsa import _fit_on_engine, _locked
 # thread pool of nogil fits (enstop_.py:209-217).  Measured on MI355X, 32 members x 50 iterations on the
 # 20NG-shaped corpus: 4960 fits/min with one member at a time, 7050 with two, 7470 with three, flat beyond
 # (profiles/r02_ensemble_concurrent_members_cfg1.jsonl); config 2 (10 M nnz) +22 %; nothing to gain once a
-# single fit saturates the memory system.
-CONCURRENT_MEMBERS_MAX = 4
+# single fit saturates the memory system.  Round 4: the member contexts need their own hardware queues (libplsa_hip.so asks
+# for 8 at load time, see include/plsa_hip.h): 7 370-7 520 -> 8 070-8 290 fits/min with four members in flight; six or eight
+# in flight are slower (profiles/r04_hw_queues_api_jobs_6_8.txt), hence the cap (ENSTOP_AMD_CONCURRENT_MEMBERS_MAX: experiments).
+CONCURRENT_MEMBERS_MAX = int(os.environ.get("ENSTOP_AMD_CONCURRENT_MEMBERS_MAX", "4"))
 CONCURRENT_MEMBERS_CELLS = 2e9          # nnz * k below which members run concurrently
 
 

@@ -48,7 +48,12 @@ enum {
                            arguments and ends with its own P(z|d) rows and the full P(w|z)            */
 };
 
-/* ---- lifetime / errors ----------------------------------------------------------------------- */
+/* ---- lifetime / errors -----------------------------------------------------------------------
+ * Several contexts may live on one device (the reference's thread pool of ensemble members, enstop_.py:209-217: one
+ * context per thread).  Loading the library sets GPU_MAX_HW_QUEUES=8 in the process environment UNLESS the variable is
+ * already set: the HIP runtime otherwise multiplexes every stream of the process onto 4 hardware queues and members that
+ * share a queue run in submission order (20NG shape, four contexts: +10 % ensemble throughput with 8).  It takes effect
+ * when the process has not called HIP before the library is loaded. */
 int plsa_device_count(int *count);
 int plsa_create(int device, plsa_ctx **out);
 void plsa_destroy(plsa_ctx *ctx);

@@ -45,6 +45,20 @@ def test_library_has_gfx950_code_object():
     assert b"gfx950" in data and b"k_e_step" in data and b"k_row_pass" in data
 
 
+def test_library_load_sets_a_default_hardware_queue_count_and_respects_the_users():
+    """libplsa_hip.so asks the HIP runtime for 8 hardware queues when it is loaded (concurrent ensemble members on one
+    device must not serialise on the default 4) -- unless GPU_MAX_HW_QUEUES is already set."""
+    import subprocess
+    import sys
+    code = ("import ctypes, os, sys; sys.path.insert(0, %r); from enstop_amd import _lib; _lib.load(); "
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "2"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "2"
+
+
 def test_no_cpu_fallback_without_device():
     """Without a GPU the product must fail loudly, not compute on the host."""
     from enstop_amd import _lib, plsa_fit

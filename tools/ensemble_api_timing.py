@@ -24,7 +24,12 @@ def main():
             X = eng.download_active_csr()
         enstop_amd.ensemble_of_topics(X, k, n_runs=1, parallelism="none", n_iter=2, tolerance=0.0, random_state=1)   # warm-up
         enstop_amd.ensemble_of_topics(X, k, n_runs=4, n_jobs=4, n_iter=2, tolerance=0.0, random_state=1)             # extra contexts
-        for par, jobs in (("none", 1), ("dask", 1), ("dask", 2), ("dask", 4)):
+        plan = (("none", 1), ("dask", 1), ("dask", 2), ("dask", 4))
+        if os.environ.get("JOBS"):                       # e.g. JOBS=4,6,8: thread counts of the threaded ("dask") mode only
+            plan = tuple(("dask", int(j)) for j in os.environ["JOBS"].split(","))
+        if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+            continue
+        for par, jobs in plan:
             t0 = time.perf_counter()
             T = enstop_amd.ensemble_of_topics(X, k, n_runs=runs, parallelism=par, n_jobs=jobs, n_iter=50,
                                               n_iter_per_test=10, tolerance=0.0, random_state=7)
