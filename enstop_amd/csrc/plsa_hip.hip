@@ -95,6 +95,7 @@ struct plsa_ctx {
     int heavy_items = 32, n_heavy = 0;
 
     // row items (documents cut into pieces) for corpora with few / very uneven rows
+    bool force_wide = false;           // PLSA_FORCE_WIDE: 64-bit gather addresses whatever the table size
     bool ritems_valid = false, use_ritems = false;
     int rseg = 64, ritems_mode = -1;   // -1 auto, 0 never, 1 always (PLSA_ROW_ITEMS)
     i64 n_ritems = 0;
@@ -342,11 +343,32 @@ int dispatch_shape(plsa_ctx *c, Fn &&fn) {
     return fail(c, "unsupported topic count k=%d (max 1024)", c->k);
 }
 
-// lane shape of the document pass (k_row_pass, k_row_reduce)
+// The two fused passes gather rows of a factor table by index with 32-bit byte offsets (plsa_kernels.hpp: gather_row).
+// A table of 4 GB or more (rows * kp * 4 >= 2^32: e.g. 20 M documents at k = 64) takes the WIDE instantiations instead:
+// 64-bit row addresses, run-time kp -- same arithmetic, same results.  PLSA_FORCE_WIDE=1 selects them for any size (tests).
+bool table_is_wide(plsa_ctx *c, i64 rows) { return c->force_wide || (double)rows * c->kp * 4.0 >= 4294967296.0; }
+
+template <class Fn>
+int dispatch_shape_gather(plsa_ctx *c, bool wide, Fn &&fn) {
+    if (!wide) return dispatch_shape(c, fn);
+#define PLSA_SHAPE(L, H)                                                                           \
+    if (c->lpn == L && c->ch == H) { fn(plsa::Shape<L, H, false, true>{}); return 0; }
+    PLSA_SHAPE(1, 1) PLSA_SHAPE(2, 1) PLSA_SHAPE(4, 1) PLSA_SHAPE(8, 1) PLSA_SHAPE(16, 1)
+    PLSA_SHAPE(32, 1) PLSA_SHAPE(64, 1) PLSA_SHAPE(64, 2) PLSA_SHAPE(64, 4)
+    PLSA_SHAPE(16, 2) PLSA_SHAPE(32, 2)
+#undef PLSA_SHAPE
+    return fail(c, "unsupported topic count k=%d (max 1024)", c->k);
+}
+
+// lane shape of the document pass (k_row_pass, k_row_reduce); it gathers P(w|z) rows: m of them
 template <class Fn>
 int dispatch_shape_row(plsa_ctx *c, Fn &&fn) {
-    if (c->row_lpn == 8 && c->row_ch == 2 && c->kp == 64) { fn(plsa::Shape<8, 2, true>{}); return 0; }
-    return dispatch_shape(c, fn);
+    const bool wide = table_is_wide(c, c->m);
+    if (c->row_lpn == 8 && c->row_ch == 2 && c->kp == 64) {
+        if (wide) fn(plsa::Shape<8, 2, false, true>{}); else fn(plsa::Shape<8, 2, true>{});
+        return 0;
+    }
+    return dispatch_shape_gather(c, wide, fn);
 }
 
 int launch_check(plsa_ctx *c, const char *what) {
@@ -874,7 +896,7 @@ int run_col_pass(plsa_ctx *c, bool from_p, const float *d_sw, float thresh, int 
     CHK(ensure_csc(c));
     CHK(ensure(c, c->partial, sizeof(float) * (size_t)std::max<i64>(c->n_items, 1) * c->kp));
     int rc = 0;
-    CHK(dispatch_shape(c, [&](auto S) {
+    CHK(dispatch_shape_gather(c, table_is_wide(c, c->n), [&](auto S) {     // the pass gathers P(z|d) rows: n of them
         using Sh = decltype(S);
         constexpr int LPN = Sh::LPN, GPB = 256 / LPN;
         const i64 n_visit = c->n_items;
@@ -1138,6 +1160,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_MT_MIN_BLOCKS")) c->mt_min_blocks = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_SMALL_GRID")) c->small_grid = std::max(0, atoi(s));
     if (const char *s = getenv("PLSA_ROW_SHAPE")) c->row_shape_8x2 = atoi(s) != 0;
+    if (const char *s = getenv("PLSA_FORCE_WIDE")) c->force_wide = atoi(s) != 0;
     *out = c;
     return 0;
 }

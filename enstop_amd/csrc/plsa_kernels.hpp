@@ -88,11 +88,12 @@ __device__ __forceinline__ float4 ld4_nt(const float *p) {
 __device__ __forceinline__ int ldi(const int *p) { return PLSA_NT_STREAMS ? __builtin_nontemporal_load(p) : *p; }
 __device__ __forceinline__ float ldf(const float *p) { return PLSA_NT_STREAMS ? __builtin_nontemporal_load(p) : *p; }
 
-// Shape of the lane decomposition.  When FULL, kp is the compile-time constant 4*LPN*CH.
-template <int LPN_, int CH_, bool FULL_>
+// Shape of the lane decomposition.  When FULL, kp is the compile-time constant 4*LPN*CH.  WIDE: the gathered factor
+// table may reach 4 GB, its rows are addressed with 64-bit arithmetic (gather_row below; the host picks it per launch).
+template <int LPN_, int CH_, bool FULL_, bool WIDE_ = false>
 struct Shape {
     static constexpr int LPN = LPN_, CH = CH_;
-    static constexpr bool FULL = FULL_;
+    static constexpr bool FULL = FULL_, WIDE = WIDE_;
     // document-owned kernels: rows in flight per group.  Narrow groups (k <= 32: 8 lanes, an index load covers 8 entries)
     // take the whole index batch in ONE round of gathers -- the pass is bound by the serial chain of its documents there
     // (config 2: 4730 -> 5470 iterations/s, config 1: 9490 -> 10060); 16-lane groups stay at PLSA_UNR (8 rows cost
@@ -124,6 +125,25 @@ __device__ __forceinline__ void load_row(const float *row, int li, int kp, float
         const float *p = row + (ok ? S::c4(li, j) : 0);
         const float4 v = STREAM ? ld4_nt(p) : ld4(p);
         out[j] = (ZERO_INVALID && !ok) ? zero4() : v;
+    }
+}
+
+// Row `row` of a factor table that is gathered by index (P(w|z) rows by word in the document pass, P(z|d) rows by
+// document in the column pass).  Tables below 4 GB -- every BASELINE configuration -- are addressed by a 32-bit BYTE offset
+// from the wave-uniform table base (global_load_dwordx4 v, v_off, s[base:base+1]): one VALU instruction per gather
+// (v_lshl_or_b32) where the 64-bit form needs three (sign extension, 64-bit shift, 64-bit add): 16 of ~250 VALU
+// instructions per batch of 8 entries at k = 32 (config 2: +4 %).  S::WIDE keeps the 64-bit form for larger tables.
+template <class S>
+__device__ __forceinline__ void gather_row(const float *table, int row, int li, int kp, float4 (&out)[S::CH]) {
+    if constexpr (S::WIDE) {
+        load_row<S, false>(table + (i64)row * kp, li, kp, out);
+    } else {
+        const unsigned base = (unsigned)row * (unsigned)(kp * 4);
+#pragma unroll
+        for (int j = 0; j < S::CH; ++j) {
+            const unsigned off = S::ok(li, j, kp) ? base + 4u * (unsigned)S::c4(li, j) : base;
+            out[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(table) + off);
+        }
     }
 }
 
@@ -361,14 +381,43 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_row_pass(const int *__restr
             for (int s0 = 0; s0 < cnt; s0 += UNR) {
                 float4 a[UNR][CH];   // Vt rows (fused) or P rows (FROM_P)
                 float x[UNR];
+                // x / norm is formed ONCE, in the lane that loaded the entry (lane s0 + q holds the count of entry q; s0 == 0 here),
+                // and broadcast -- instead of broadcasting the count and forming the quotient in every lane: 8 x (reciprocal,
+                // compare, select, multiply) per batch become 8 selects + one such sequence; same operations on the same values
+                constexpr bool OWNER = !FROM_P && UNR == LPN;
 #pragma unroll
                 for (int q = 0; q < UNR; ++q) {
                     const int w = __shfl(w_l, s0 + q, LPN);
-                    x[q] = __shfl(x_l, s0 + q, LPN);
+                    if (!OWNER) x[q] = __shfl(x_l, s0 + q, LPN);
                     if (FROM_P) load_row<S, false>(P + (i64)min(jb + s0 + q, j1 - 1) * kp, li, kp, a[q]);
-                    else load_row<S, false>(Vt + (i64)w * kp, li, kp, a[q]);
+                    else gather_row<S>(Vt, w, li, kp, a[q]);
                 }
                 float my_dot = 1.f, my_x = 0.f;   // WANT_LL: lane q of the group takes non-zero q of the batch
+                if (OWNER) {
+                    float nmine = 0.f;
+#pragma unroll
+                    for (int q = 0; q < UNR; ++q) {
+                        float unth;
+                        const float part = products<CH, WANT_LL>(u, a[q], thresh, a[q], unth);
+                        float norm = group_sum<LPN>(part);
+                        rescue_tiny(tiny, norm, a[q]);
+                        if (WANT_LL) {
+                            const float dot = group_sum<LPN>(unth);
+                            if (li == q && s0 + q < cnt) { my_dot = dot; my_x = x_l; }
+                        }
+                        nmine = (li == s0 + q) ? norm : nmine;
+                    }
+                    const float xs_mine = x_l * inv_norm(nmine);   // lane s0 + q: entry q of the batch
+#pragma unroll
+                    for (int q = 0; q < UNR; ++q) {
+                        const float xs = __shfl(xs_mine, s0 + q, LPN);
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) {   // s = x * P(z|w,d); U[d,z] += s   plsa.py:188-191
+                            acc[j].x += xs * a[q][j].x; acc[j].y += xs * a[q][j].y;
+                            acc[j].z += xs * a[q][j].z; acc[j].w += xs * a[q][j].w;
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < UNR; ++q) {
                     float4 pz[CH];
@@ -391,6 +440,7 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_row_pass(const int *__restr
                         acc[j].x += x[q] * pz[j].x; acc[j].y += x[q] * pz[j].y;
                         acc[j].z += x[q] * pz[j].z; acc[j].w += x[q] * pz[j].w;
                     }
+                }
                 }
                 // x * log(sum_z P(w|z) P(z|d)) * sample_weight, plsa.py:380-383: one logf sequence per batch
                 // (lanes 0 .. UNR-1 each hold one non-zero; padded slots keep x = 0, dot = 1 -> exactly 0)
@@ -520,18 +570,40 @@ __device__ __forceinline__ void col_batch(int s0, int d_l, float x_l, int p_l, i
                                           const float *__restrict__ U, const float *__restrict__ P,
                                           const float4 (&vt)[S::CH], float4 (&acc)[S::CH]) {
     constexpr int LPN = S::LPN, CH = S::CH;
+    constexpr bool OWNER = !FROM_P && UN >= 4;   // x / norm formed once, in the lane that loaded the entry (see k_row_pass)
     float4 a[UN][CH];   // U rows (fused) or P rows (FROM_P)
     float x[UN];
 #pragma unroll
     for (int q = 0; q < UN; ++q) {
-        x[q] = __shfl(x_l, s0 + q, LPN);     // lanes beyond the item hold (doc 0, count 0): exact zeros
+        if (!OWNER) x[q] = __shfl(x_l, s0 + q, LPN);     // lanes beyond the item hold (doc 0, count 0): exact zeros
         if (FROM_P) {
             const int pos = __shfl(p_l, s0 + q, LPN);
             load_row<S, false>(P + (i64)pos * kp, li, kp, a[q]);
         } else {
             const int d = __shfl(d_l, s0 + q, LPN);
-            load_row<S, false>(U + (i64)d * kp, li, kp, a[q]);
+            gather_row<S>(U, d, li, kp, a[q]);
         }
+    }
+    if (OWNER) {
+        float nmine = 0.f;
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            float unth;
+            float norm = group_sum<LPN>(products<CH, false>(a[q], vt, thresh, a[q], unth));
+            rescue_tiny(TINY, norm, a[q]);
+            nmine = (li == s0 + q) ? norm : nmine;
+        }
+        const float xs_mine = x_l * inv_norm(nmine);
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const float xs = __shfl(xs_mine, s0 + q, LPN);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                acc[j].x += xs * a[q][j].x; acc[j].y += xs * a[q][j].y;
+                acc[j].z += xs * a[q][j].z; acc[j].w += xs * a[q][j].w;
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int q = 0; q < UN; ++q) {

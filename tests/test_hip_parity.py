@@ -1398,7 +1398,8 @@ def test_fuzz_slice(amd):
 def test_schedule_knobs_do_not_change_results(amd):
     """Round-3 scheduling machinery changes WHEN work runs, never WHAT is computed: measured XCD boundaries of the
     column pass (PLSA_BALANCE), the event-linked pipelines of small corpora (PLSA_PIPELINE), hipGraph replay
-    (PLSA_GRAPH) -- factors, iteration count and likelihood trace are bit-identical with each switched the other way.
+    (PLSA_GRAPH), and the address width of the factor-row gathers (PLSA_FORCE_WIDE) -- factors, iteration count and
+    likelihood trace are bit-identical with each switched the other way.
     Two corpora: one large enough for the boundary tuning (nnz * k >= 1e8), one small enough for the pipelines."""
     from enstop_amd.engine import reset_engines
     rs = np.random.RandomState(4)
@@ -1415,7 +1416,9 @@ def test_schedule_knobs_do_not_change_results(amd):
         for X, k, kw in cases:
             ref.append(amd.plsa_fit(X, k, np.ones(X.shape[0], np.float32), return_info=True, **kw))
         assert amd.engine.get_engine().balance_info()["timed_launches"] >= 0
-        for knob, val in (("PLSA_BALANCE", "0"), ("PLSA_BALANCE", "1"), ("PLSA_PIPELINE", "0"), ("PLSA_GRAPH", "1")):
+        # PLSA_FORCE_WIDE: the 64-bit row addressing that factor tables of 4 GB or more take (32-bit byte offsets below)
+        for knob, val in (("PLSA_BALANCE", "0"), ("PLSA_BALANCE", "1"), ("PLSA_PIPELINE", "0"), ("PLSA_GRAPH", "1"),
+                          ("PLSA_FORCE_WIDE", "1")):
             os.environ[knob] = val
             reset_engines()                       # knobs are read when a context is created
             for (X, k, kw), (U0, V0, i0) in zip(cases, ref):
