@@ -18,8 +18,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-f
 
 
 HOT = ("k_col_pass", "k_row_pass", "k_e_step", "k_loglik", "k_col_reduce_norm")
-SHAPES = {"Shape<8, 1, false>": "k=20", "Shape<8, 1, true>": "k=32", "Shape<16, 1, true>": "k=64",
-          "Shape<8, 2, true>": "k=64", "Shape<16, 2, true>": "k=128"}     # k = 64: the document pass runs as 8 x 2
+# (LPN, CH, FULL, WIDE = false: 32-bit gather offsets, every table below 4 GB); k = 64: the document pass runs as 8 x 2
+SHAPES = {"Shape<8, 1, false, false>": "k=20", "Shape<8, 1, true, false>": "k=32", "Shape<16, 1, true, false>": "k=64",
+          "Shape<8, 2, true, false>": "k=64", "Shape<16, 2, true, false>": "k=128"}
 RESOURCES = os.path.join(HERE, "kernel_resources.json")
 
 

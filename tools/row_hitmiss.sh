@@ -13,7 +13,7 @@ python - <<'PY'
 import csv, glob, collections, json
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("/tmp/rhm_*/**/*counter_collection.csv", recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if "k_row_pass<plsa::Shape<8, 2, true>" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "k_row_pass<plsa::Shape<8, 2, true, false>" in r["Kernel_Name"]]
     by = collections.defaultdict(list)
     for r in rows: by[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     for cn, v in by.items():
@@ -23,7 +23,7 @@ for f in glob.glob("/tmp/rhm_*/**/*counter_collection.csv", recursive=True):
         for i, name in enumerate(("real", "all_hit", "all_miss")):
             if 2 * i + 1 < len(vals): res[name][cn] = vals[2 * i + 1]
 for f in glob.glob("/tmp/rhm_tcc/**/*kernel_trace.csv", recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if "k_row_pass<plsa::Shape<8, 2, true>" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "k_row_pass<plsa::Shape<8, 2, true, false>" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     for i, name in enumerate(("real", "all_hit", "all_miss")):
         if 2 * i + 1 < len(rows):
