@@ -43,6 +43,7 @@ SIGNATURES = {
     "plsa_get_factors": (C.c_int, [_ctx, _vp, _vp]),
     "plsa_init_factors_device": (C.c_int, [_ctx, _i32, C.c_uint64]),
     "plsa_init_factors_mt19937": (C.c_int, [_ctx, _i32, np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]),
+    "plsa_mt_marginals": (C.c_int, [_ctx, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), _i32]),
     "plsa_refit_init_mt19937": (C.c_int, [_ctx, C.c_void_p, _i64, _i32,
                                           np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]),
     "plsa_copy_components_to_device": (C.c_int, [_ctx, _vp]),

@@ -125,6 +125,8 @@ struct plsa_ctx {
 
     // small buffers
     DevBuf sw, ll_partials, ll_out, colsum_partials, norm_pwz, norm_pdz, tmp0, tmp1, tmp2, cubtmp;
+    DevBuf mt_seq;                                // chunk sums / parity pairs / binade guesses of the topic marginals
+    bool mt_chain = false;                        // PLSA_MT_CHAIN
     DevBuf mt_words, mt_state, mt_fin, mt_poly;   // MT19937 initialisation scratch: kept between calls (an ensemble member per call:
                                                   // four hipMalloc + four hipFree per member cost more than the generator kernels)
     double *h_ll = nullptr;  // pinned
@@ -1161,6 +1163,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_SMALL_GRID")) c->small_grid = std::max(0, atoi(s));
     if (const char *s = getenv("PLSA_ROW_SHAPE")) c->row_shape_8x2 = atoi(s) != 0;
     if (const char *s = getenv("PLSA_FORCE_WIDE")) c->force_wide = atoi(s) != 0;
+    if (const char *s = getenv("PLSA_MT_CHAIN")) c->mt_chain = atoi(s) != 0;
     *out = c;
     return 0;
 }
@@ -1174,7 +1177,7 @@ void plsa_destroy(plsa_ctx *c) {
     if (c->comm_host) { (void)hipHostFree(c->comm_host); c->comm_host = nullptr; c->comm_host_cap = 0; }
     release(c->item_end); release(c->colsum_rows); release(c->colsum_rows2);
     release(c->item_rec); release(c->xcd_lo); release(c->t_end);
-    release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly);
+    release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly); release(c->mt_seq);
     DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,
@@ -1406,6 +1409,8 @@ static int mt_init(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/, const f
     CHK(ensure(c, st, sizeof(unsigned) * 624 * (size_t)streams_p2));
     CHK(ensure(c, fin, sizeof(unsigned) * 640 + sizeof(double) * 1024));
     if (levels) CHK(ensure(c, gp, sizeof(unsigned) * polys.size()));
+    if (!V_host && !c->mt_chain)     // chunk sums (u64), parity pairs (2 x u64) and binade guesses (int) of the topic marginals
+        CHK(ensure(c, c->mt_seq, (size_t)k * (size_t)((m + plsa::MT_SEQ_L - 1) / plsa::MT_SEQ_L) * (3 * sizeof(plsa::u64) + sizeof(int))));
     hipError_t e = hipMemsetAsync(st.p, 0, sizeof(unsigned) * 624 * (size_t)streams_p2, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(st.p, state_io, sizeof(unsigned) * 624, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && levels)
@@ -1432,7 +1437,20 @@ static int mt_init(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/, const f
             // V[k, m] in the reference layout (words are consumed in that order), then the layout transpose
             float *Vtmp = reinterpret_cast<float *>(c->Vt[1].p);     // [m*kp] floats >= k*m: free scratch here
             double *marg = reinterpret_cast<double *>(fin.as<unsigned>() + 632) ;   // k <= 1024 doubles behind the state
-            hipLaunchKernelGGL(plsa::k_mt_marginal_v, dim3((unsigned)k), dim3(64), 0, c->stream, words.as<unsigned>(), k, (int)m, marg);
+            if (c->mt_chain) {       // PLSA_MT_CHAIN=1: the plain chain of m dependent adds per topic (A/B, tests)
+                hipLaunchKernelGGL(plsa::k_mt_marginal_v, dim3((unsigned)k), dim3(64), 0, c->stream, words.as<unsigned>(), k, (int)m, marg);
+            } else {                 // the same roundings from per-chunk parity pairs (plsa_kernels.hpp: k_mt_chunk_pairs)
+                const int nch = (int)((m + plsa::MT_SEQ_L - 1) / plsa::MT_SEQ_L);
+                const size_t per = (size_t)k * nch;
+                plsa::u64 *csum = c->mt_seq.as<plsa::u64>(), *pairs = csum + per;
+                int *guess = reinterpret_cast<int *>(pairs + 2 * per);
+                const dim3 tiles((unsigned)((nch + plsa::MT_SEQ_L - 1) / plsa::MT_SEQ_L), (unsigned)k);
+                hipLaunchKernelGGL(plsa::k_mt_chunk_sums, tiles, dim3(64), 0, c->stream, words.as<unsigned>(), (int)m, nch, csum);
+                hipLaunchKernelGGL(plsa::k_mt_chunk_pairs, tiles, dim3(64), 0, c->stream, words.as<unsigned>(), (int)m, nch,
+                                   csum, pairs, guess);
+                hipLaunchKernelGGL(plsa::k_mt_marginal_walk, dim3((unsigned)k), dim3(64), 0, c->stream, words.as<unsigned>(),
+                                   (int)m, nch, pairs, guess, marg);
+            }
             hipLaunchKernelGGL(plsa::k_mt_scale_v, dim3(grid_for(c, (i64)k * m, 256)), dim3(256), 0, c->stream,
                                words.as<unsigned>(), marg, k, (int)m, Vtmp);
             dim3 grid((unsigned)((m + 31) / 32), (unsigned)((kp + 31) / 32));
@@ -1451,6 +1469,14 @@ static int mt_init(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/, const f
 int plsa_init_factors_mt19937(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/) {
     if (!state_io) return fail(c, "plsa_init_factors_mt19937: state_io is NULL");
     return mt_init(c, k, state_io, nullptr);
+}
+
+int plsa_mt_marginals(plsa_ctx *c, double *out, int32_t k) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!out || k <= 0 || k > 1024 || !c->mt_fin.p || k != c->k)
+        return fail(c, "plsa_mt_marginals: no MT19937 initialisation with k=%d on this context", k);
+    HIPCHK(c, hipMemcpy(out, c->mt_fin.as<unsigned>() + 632, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int plsa_refit_init_mt19937(plsa_ctx *c, const float *V, int64_t m, int32_t k, uint32_t *state_io /*[625]*/) {
@@ -2059,7 +2085,7 @@ int plsa_release_scratch(plsa_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     release(c->P); release(c->partial); release(c->tmp0); release(c->tmp1); release(c->tmp2); release(c->cubtmp);
-    release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly);
+    release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly); release(c->mt_seq);
     // member stack + gather buffers of the ensemble exchange (16 runs x 64 topics x 100 k words = 0.4 GB): re-created
     // by the next plsa_stack_reserve / plsa_comm_allgather_stack
     release(c->comm_stack); release(c->comm_recv); release(c->comm_send);

@@ -1396,6 +1396,143 @@ __global__ __launch_bounds__(64) void k_mt_marginal_v(const unsigned *__restrict
     if (lane == 0) marg[z] = s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same marginal WITHOUT the chain of m dependent adds (k_mt_marginal_v above: 1.9 ms for the 173 762 words of the
+// 20NG shape, three quarters of a member's initialisation) -- bit for bit the same sequence of roundings.
+//
+// The draws are X * 2^-53 with integers X < 2^53 (numpy's random_sample), so while the running sum s stays inside one
+// binade [2^e, 2^(e+1)), e >= 0, it is an integer multiple T of u = 2^(e-52) and one rounded addition is
+//     T' = T + q + c,   q = X >> (e+1),  r = X mod 2^(e+1),   c = [r > half] or ([r == half] and (T + q) odd)
+// (round to nearest even): the increment depends on T only through its PARITY.  A chunk of 64 draws therefore maps the
+// parity at its start to a total increment -- a pair (A0, A1) that every chunk computes on its own (k_mt_chunk_pairs),
+// for the binade its approximate prefix sum points at.  One wave per topic then walks the chunks: s += A[parity] is an
+// integer addition on the bit pattern, checked on the spot (exponent of s equals the chunk's binade before AND after: no
+// crossing inside, all 64 roundings were at that granularity); a chunk that fails the check -- the ~18 binade crossings,
+// the first chunk (s < 1: exact additions), a wrong guess -- is added one draw at a time exactly as above.  The checks
+// make the result independent of how good the guess is; the guess only decides how many chunks take the slow way.
+// Validated against the sequential sum draw for draw by the NumPy-identity tests and a tie-heavy host prototype.
+// ------------------------------------------------------------------------------------------------
+constexpr int MT_SEQ_L = 64;      // draws per chunk = chunks per workgroup tile
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 mt_int53(const unsigned *w, i64 idx) {
+    return ((u64)(w[2 * idx] >> 5) << 26) | (u64)(w[2 * idx + 1] >> 6);
+}
+
+// tile[c][j] = draw j of chunk c0 + c of topic z (0 beyond the row): coalesced loads, conflict-free row reads
+__device__ __forceinline__ void mt_load_tile(const unsigned *__restrict__ words, i64 base, int m, i64 c0,
+                                             u64 (*tile)[MT_SEQ_L + 1]) {
+    const int lane = threadIdx.x;
+    for (int c = 0; c < MT_SEQ_L; ++c) {
+        const i64 w = (c0 + c) * MT_SEQ_L + lane;
+        tile[c][lane] = w < m ? mt_int53(words, base + w) : 0ull;
+    }
+    __syncthreads();
+}
+
+// exact integer sum of every chunk (< 2^59): grid (ceil(nch / 64), k), 64 threads
+__global__ __launch_bounds__(64) void k_mt_chunk_sums(const unsigned *__restrict__ words, int m, int nch,
+                                                      u64 *__restrict__ csum) {
+    __shared__ u64 tile[MT_SEQ_L][MT_SEQ_L + 1];
+    const int z = blockIdx.y, lane = threadIdx.x;
+    const i64 c0 = (i64)blockIdx.x * MT_SEQ_L;
+    mt_load_tile(words, (i64)z * m, m, c0, tile);
+    u64 t = 0;
+#pragma unroll 8
+    for (int j = 0; j < MT_SEQ_L; ++j) t += tile[lane][j];
+    if (c0 + lane < nch) csum[(i64)z * nch + c0 + lane] = t;
+}
+
+// per chunk: guessed binade e (from the approximate prefix sum of the chunk sums; -1: s < 1 or no guess) and the
+// parity -> increment pair at that binade's granularity.  Same grid.
+__global__ __launch_bounds__(64) void k_mt_chunk_pairs(const unsigned *__restrict__ words, int m, int nch,
+                                                       const u64 *__restrict__ csum, u64 *__restrict__ pairs /*[2]*/,
+                                                       int *__restrict__ guess) {
+    __shared__ u64 tile[MT_SEQ_L][MT_SEQ_L + 1];
+    __shared__ double pre[MT_SEQ_L];
+    const int z = blockIdx.y, lane = threadIdx.x;
+    const i64 c0 = (i64)blockIdx.x * MT_SEQ_L;
+    const u64 *cs = csum + (i64)z * nch;
+    // approximate real prefix at this tile's first chunk, then at each of its chunks (any summation order will do)
+    double before = 0.0;
+    for (i64 c = lane; c < c0; c += 64) before += (double)cs[c];
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    pre[lane] = (c0 + lane < nch) ? (double)cs[c0 + lane] : 0.0;
+    mt_load_tile(words, (i64)z * m, m, c0, tile);     // (synchronises)
+    double start = before;
+    for (int j = 0; j < lane; ++j) start += pre[j];
+    start *= 0x1p-53;
+    const int e = start >= 1.0 ? (int)((__double_as_longlong(start) >> 52) & 0x7ff) - 1023 : -1;
+    u64 a0 = 0, a1 = 0;
+    if (e >= 0 && e <= 51) {
+        const int sh = e + 1;
+        const u64 mask = (1ull << sh) - 1, half = 1ull << (sh - 1);
+        u64 t0 = 0, t1 = 1;
+#pragma unroll 4
+        for (int j = 0; j < MT_SEQ_L; ++j) {
+            const u64 x = tile[lane][j], q = x >> sh, r = x & mask;
+            const u64 up = r > half, tie = r == half;
+            t0 += q + (up | (tie & ((t0 + q) & 1)));
+            t1 += q + (up | (tie & ((t1 + q) & 1)));
+        }
+        a0 = t0; a1 = t1 - 1;
+    }
+    if (c0 + lane < nch) {
+        const i64 o = (i64)z * nch + c0 + lane;
+        pairs[2 * o] = a0; pairs[2 * o + 1] = a1;
+        guess[o] = (e >= 0 && e <= 51) ? e : -1;
+    }
+}
+
+// one wave per topic walks its chunks; marg[z] = the reference's left-to-right float64 sum.  The walk is wave-uniform:
+// lane l fetches the pair and the guess of chunk c0 + l (the next 64 are requested before the current 64 are walked --
+// they do not depend on the sum), v_readlane moves chunk j's values to scalar registers and the dependent chain per chunk
+// is a handful of SCALAR instructions (parity, select, 64-bit add, two range checks); only the draw-by-draw fallback
+// touches the vector units.
+__device__ __forceinline__ u64 readlane64(u64 v, int l) {
+    return (u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), l) |
+           ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l) << 32);
+}
+__global__ __launch_bounds__(64) void k_mt_marginal_walk(const unsigned *__restrict__ words, int m, int nch,
+                                                         const u64 *__restrict__ pairs, const int *__restrict__ guess,
+                                                         double *__restrict__ marg) {
+    __shared__ double sx[MT_SEQ_L];
+    const int z = blockIdx.x, lane = threadIdx.x;
+    const i64 base = (i64)z * m;
+    const u64 *pz = pairs + 2 * (i64)z * nch;
+    const int *gz = guess + (i64)z * nch;
+    u64 b = 0;      // bit pattern of the running sum (+0.0)
+    u64 n0 = 0, n1 = 0;
+    int ne = -1;
+    if (lane < nch) { n0 = pz[2 * lane]; n1 = pz[2 * lane + 1]; ne = gz[lane]; }
+    for (int c0 = 0; c0 < nch; c0 += 64) {
+        const u64 v0 = n0, v1 = n1;
+        const int ve = ne;
+        const int cn = c0 + 64 + lane;
+        if (cn < nch) { n0 = pz[2 * (i64)cn]; n1 = pz[2 * (i64)cn + 1]; ne = gz[cn]; }
+        const int cnt = min(64, nch - c0);
+#pragma unroll 4
+        for (int j = 0; j < cnt; ++j) {
+            const int e = __builtin_amdgcn_readlane(ve, j);
+            const u64 a0 = readlane64(v0, j), a1 = readlane64(v1, j);      // (independent of the sum: issued ahead)
+            // binade e = bit patterns [lo, lo + 2^52) with lo = (e + 1023) << 52: compared on the high words.  The sum may
+            // take the pair iff it starts and ends inside
+            const unsigned lo_hi = (unsigned)(e + 1023) << 20;
+            const u64 nb = b + ((b & 1) ? a1 : a0);
+            if (e >= 0 && (unsigned)(b >> 32) >= lo_hi && (unsigned)(nb >> 32) < lo_hi + (1u << 20)) { b = nb; continue; }
+            // one draw at a time (uniform branch: every lane walks the same sum)
+            const i64 w = (i64)(c0 + j) * MT_SEQ_L + lane;
+            __syncthreads();
+            sx[lane] = w < m ? mt_double(words, base + w) : 0.0;
+            __syncthreads();
+            double sd = __longlong_as_double((long long)b);
+#pragma unroll 8
+            for (int i = 0; i < MT_SEQ_L; ++i) sd += sx[i];
+            b = readlane64((u64)__double_as_longlong(sd), 0);      // (uniform; back to scalar registers)
+        }
+    }
+    if (lane == 0) marg[z] = __longlong_as_double((long long)b);
+}
+
 // V[z, w] = float32(draw / marginal_z) in the reference layout, for the transpose kernel
 __global__ __launch_bounds__(256) void k_mt_scale_v(const unsigned *__restrict__ words, const double *__restrict__ marg,
                                                     int k, int m, float *__restrict__ V) {

@@ -177,6 +177,12 @@ class Engine:
         self.k = int(k)
         return self
 
+    def mt_marginals(self):
+        """float64 row sums of the topic draws of the last init_factors_numpy_stream call (diagnostics / tests)."""
+        out = np.empty(self.k, np.float64)
+        self._ok(self._L.plsa_mt_marginals(self._h, out, int(self.k)))
+        return out
+
     def get_factors(self, want_u=True, want_v=True):
         n, m, _ = self.shape
         U = np.empty((n, self.k), np.float32) if want_u else None

@@ -96,6 +96,10 @@ int plsa_init_factors_device(plsa_ctx *ctx, int32_t k, uint64_t seed);
  * back (set_state it to leave the host generator where the reference would).  Bit-identical to
  * the host path, ~7x faster at config 3.                                                        */
 int plsa_init_factors_mt19937(plsa_ctx *ctx, int32_t k, uint32_t *state_io);
+/* Diagnostics: the k float64 topic marginals (enstop/utils.py:24-29, `marginal[i] += ndarray[i, j]` left to right) that the
+ * last plsa_init_factors_mt19937 call divided by.  The device evaluates that sequential sum from per-chunk parity pairs
+ * (csrc/plsa_kernels.hpp: k_mt_chunk_pairs); the tests pin it bit for bit to numpy's own sequential accumulation.   */
+int plsa_mt_marginals(plsa_ctx *ctx, double *out, int32_t k);
 /* The initialisation of plsa_refit (enstop/plsa.py:979-981): p_z_given_d = rng.rand(n, k), L1 row
  * normalised in float64, cast to float32 -- drawn on the device from the same stream -- against the
  * given fixed topics V [k, m] (host, float32).                                                      */

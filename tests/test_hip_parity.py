@@ -950,6 +950,30 @@ def test_device_mt19937_init_is_bit_identical_to_numpy(amd, n_m_k):
         np.testing.assert_array_equal(rng_h.rand(5), rng_d.rand(5))      # same continuation
 
 
+@pytest.mark.parametrize("m_k", [(1, 3), (63, 2), (64, 5), (65, 4), (4097, 7), (100_000, 64), (173_762, 20), (1_000_003, 3)])
+def test_device_topic_marginals_are_the_sequential_float64_sums(amd, monkeypatch, m_k):
+    """The normalisation constants of plsa_init's topic rows (utils.py:24-29: one float64 running sum per topic, left to
+    right over the m words) come from per-chunk parity pairs on the device, not from a chain of m dependent adds: the
+    float64 values must equal numpy's strictly sequential accumulation BIT FOR BIT, and the plain chain (PLSA_MT_CHAIN=1)."""
+    m, k = m_k
+    X = sp.csr_matrix((np.ones(2, np.float32), (np.array([0, 1]), np.array([0, m - 1]))), shape=(2, m))
+    for seed in (1, 2):
+        rng_h, rng_d, rng_c = (np.random.RandomState(seed + m) for _ in range(3))
+        want = np.add.accumulate(rng_h.rand(k, m), axis=1)[:, -1]          # accumulate = strictly sequential
+        with amd.Engine() as eng:
+            eng.upload_csr(X)
+            eng.init_factors_numpy_stream(k, rng_d)
+            got = eng.mt_marginals()
+        np.testing.assert_array_equal(got.view(np.int64), want.view(np.int64))
+        monkeypatch.setenv("PLSA_MT_CHAIN", "1")
+        with amd.Engine() as eng:
+            eng.upload_csr(X)
+            eng.init_factors_numpy_stream(k, rng_c)
+            chain = eng.mt_marginals()
+        monkeypatch.delenv("PLSA_MT_CHAIN")
+        np.testing.assert_array_equal(chain.view(np.int64), want.view(np.int64))
+
+
 @pytest.mark.parametrize("streams", [2, 5, 16, 128])
 def test_device_mt19937_jump_ahead_streams_are_bit_identical(amd, monkeypatch, streams):
     """The init stream cut into pieces by MT19937 jump-ahead (csrc/mt_jump.hpp, k_mt_jump) is the one
