@@ -500,16 +500,19 @@ def main():
         barrier()
         t0 = time.perf_counter()
         it, _ = eng.fit(None, n_iter=args.steps, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=flags)
+        t_fit = time.perf_counter() - t0
         stack = gather_components()
+        t_gather = time.perf_counter() - t0 - t_fit
         barrier()
         dt_r = time.perf_counter() - t0
         assert it == args.steps, "early stop inside the timed region (%d of %d)" % (it, args.steps)
         rep_r = eng.timing_report()
         eng.timing(False)
         dt_r = float(comm.allreduce_f64([dt_r], "max")[0])
-        regions.append((dt_r, rep_r))
+        split = comm.allreduce_f64([t_fit, t_gather], "max")
+        regions.append((dt_r, rep_r, float(split[0]), float(split[1])))
     order = sorted(range(3), key=lambda i: regions[i][0])
-    dt, report = regions[order[1]]
+    dt, report, dt_fit, dt_gather = regions[order[1]]
     schedule = eng.balance_info()            # measured XCD boundaries of the column pass (results do not depend on them)
     if stack is not None and rank == 0:
         assert stack.shape == (world, k, m) and np.all(np.isfinite(stack))
@@ -576,6 +579,9 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "value_is": "median of 3 back-to-back timed regions of exactly %d iterations (barrier + synchronize around each, "
                     "max over ranks)" % args.steps,
+        "timed_region_split_s": {"iterations": round(dt_fit, 5), "topic_gather_to_host": round(dt_gather, 5),
+                                 "note": "max over ranks of the two parts of the median region; the gather (D2D into the stack, "
+                                         "all-gather when N > 1, one copy to the host array) is INSIDE the timed region"},
         "timed_regions": [{"value": round(n_gpus * args.steps / r[0], 4), "ms_per_step": round(r[0] / args.steps * 1e3, 4)}
                           for r in regions],
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
