@@ -1409,7 +1409,7 @@ static int mt_init(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/, const f
     CHK(ensure(c, st, sizeof(unsigned) * 624 * (size_t)streams_p2));
     CHK(ensure(c, fin, sizeof(unsigned) * 640 + sizeof(double) * 1024));
     if (levels) CHK(ensure(c, gp, sizeof(unsigned) * polys.size()));
-    if (!V_host && !c->mt_chain)     // chunk sums (u64), parity pairs (2 x u64) and binade guesses (int) of the topic marginals
+    if (!V_host && !c->mt_chain && m <= ((i64)1 << 22))     // chunk sums (u64), parity pairs (2 x u64) and binade guesses (int) of the topic marginals
         CHK(ensure(c, c->mt_seq, (size_t)k * (size_t)((m + plsa::MT_SEQ_L - 1) / plsa::MT_SEQ_L) * (3 * sizeof(plsa::u64) + sizeof(int))));
     hipError_t e = hipMemsetAsync(st.p, 0, sizeof(unsigned) * 624 * (size_t)streams_p2, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(st.p, state_io, sizeof(unsigned) * 624, hipMemcpyHostToDevice, c->stream);
@@ -1437,7 +1437,9 @@ static int mt_init(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/, const f
             // V[k, m] in the reference layout (words are consumed in that order), then the layout transpose
             float *Vtmp = reinterpret_cast<float *>(c->Vt[1].p);     // [m*kp] floats >= k*m: free scratch here
             double *marg = reinterpret_cast<double *>(fin.as<unsigned>() + 632) ;   // k <= 1024 doubles behind the state
-            if (c->mt_chain) {       // PLSA_MT_CHAIN=1: the plain chain of m dependent adds per topic (A/B, tests)
+            // (k_mt_chunk_pairs sums the chunk sums in front of its tile on its own: quadratic in m / 4096, nothing up to
+            //  millions of words; beyond 2^22 words per topic the plain chain is used)
+            if (c->mt_chain || m > ((i64)1 << 22)) {       // PLSA_MT_CHAIN=1: the plain chain of m dependent adds per topic (A/B, tests)
                 hipLaunchKernelGGL(plsa::k_mt_marginal_v, dim3((unsigned)k), dim3(64), 0, c->stream, words.as<unsigned>(), k, (int)m, marg);
             } else {                 // the same roundings from per-chunk parity pairs (plsa_kernels.hpp: k_mt_chunk_pairs)
                 const int nch = (int)((m + plsa::MT_SEQ_L - 1) / plsa::MT_SEQ_L);
