@@ -511,6 +511,17 @@ def main():
         dt_r = float(comm.allreduce_f64([dt_r], "max")[0])
         split = comm.allreduce_f64([t_fit, t_gather], "max")
         regions.append((dt_r, rep_r, float(split[0]), float(split[1])))
+    # one more region of the same K iterations WITHOUT the per-kernel HIP events (two event records per launch cost
+    # ~1.5 % at config 3 and ~25 % at the 20NG shape, whose iteration is seven launches of 6-60 us): reported next to
+    # `value`, never instead of it
+    eng.set_factors(U0, V0)
+    barrier()
+    t0 = time.perf_counter()
+    it, _ = eng.fit(None, n_iter=args.steps, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=flags)
+    gather_components()
+    barrier()
+    dt_plain = float(comm.allreduce_f64([time.perf_counter() - t0], "max")[0])
+    assert it == args.steps
     order = sorted(range(3), key=lambda i: regions[i][0])
     dt, report, dt_fit, dt_gather = regions[order[1]]
     schedule = eng.balance_info()            # measured XCD boundaries of the column pass (results do not depend on them)
@@ -579,6 +590,11 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "value_is": "median of 3 back-to-back timed regions of exactly %d iterations (barrier + synchronize around each, "
                     "max over ranks)" % args.steps,
+        "region_without_per_kernel_events": {"value": round(n_gpus * args.steps / dt_plain, 4),
+                                             "ms_per_step": round(dt_plain / args.steps * 1e3, 4),
+                                             "note": "a fourth region of the same K iterations with the engine's per-kernel "
+                                                     "HIP events off; `value` and the per-kernel figures come from the "
+                                                     "three regions that record them"},
         "timed_region_split_s": {"iterations": round(dt_fit, 5), "topic_gather_to_host": round(dt_gather, 5),
                                  "note": "max over ranks of the two parts of the median region; the gather (D2D into the stack, "
                                          "all-gather when N > 1, one copy to the host array) is INSIDE the timed region"},
