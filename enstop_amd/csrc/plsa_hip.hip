@@ -114,7 +114,10 @@ struct plsa_ctx {
 
     // factors
     int k = 0, kp = 0, lpn = 1, ch = 1;
-    DevBuf U[2], Vt[2], Vacc;
+    DevBuf U[3], Vt[3], Vacc;      // [2]: third buffers of the speculating fit loop (plsa_fit); cu, cv stay in {0, 1} outside it
+    bool rot3 = false;             // inside that loop: the output buffers are (cu + 1) % 3, (cv + 1) % 3
+    int speculate = -1;            // PLSA_SPECULATE: -1 small corpora only, 0 never, 1 whenever the loop allows
+    hipEvent_t ev_ll = nullptr;    // likelihood of a test has reached the host buffer
     int cu = 0, cv = 0;
     i64 fac_n = 0, fac_m = 0;
     DevBuf P;
@@ -378,6 +381,10 @@ int launch_check(plsa_ctx *c, const char *what) {
     if (e != hipSuccess) return fail(c, "launch of %s failed: %s", what, hipGetErrorString(e));
     return 0;
 }
+
+// buffers the passes write (the alternates of the current factors)
+inline int out_u(const plsa_ctx *c) { return c->rot3 ? (c->cu + 1) % 3 : 1 - c->cu; }
+inline int out_v(const plsa_ctx *c) { return c->rot3 ? (c->cv + 1) % 3 : 1 - c->cv; }
 
 int grid_for(plsa_ctx *c, i64 work_items, int items_per_block) {
     i64 need = (work_items + items_per_block - 1) / items_per_block;
@@ -762,7 +769,7 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, floa
         const int *ip = c->indptr, *cl = c->col;
         const float *vl = c->val, *U = c->U[c->cu].as<float>(), *Vt = c->Vt[c->cv].as<float>();
         const float *P = p_base(c);
-        float *Un = c->U[1 - c->cu].as<float>();
+        float *Un = c->U[out_u(c)].as<float>();
         double *llp = c->ll_partials.as<double>();
         const int n = (int)c->n, kp = c->kp;
         auto go = [&](auto FP, auto LL, auto TN, const char *name) {
@@ -985,7 +992,7 @@ int run_v_normalise(plsa_ctx *c) {
         const i64 total4 = c->m * c->kp / 4;
         hipLaunchKernelGGL(plsa::k_v_normalise, dim3(grid_for(c, total4, 256)), dim3(256),
                            c->kp * sizeof(float), c->ls, c->Vacc.as<float>(),
-                           c->Vt[1 - c->cv].as<float>(), (int)c->m, c->kp, c->norm_pwz.as<float>());
+                           c->Vt[out_v(c)].as<float>(), (int)c->m, c->kp, c->norm_pwz.as<float>());
     }
     CHK(launch_check(c, "k_v_normalise"));
     return 0;
@@ -1027,7 +1034,7 @@ int run_col_tail(plsa_ctx *c) {
         hipLaunchKernelGGL((plsa::k_col_reduce_norm<Sh>), dim3(grid2 + c->n_heavy), dim3(256),
                            sizeof(float) * (size_t)(GPB + 1) * c->kp, c->ls, c->item_first.as<int>(), (int)c->m,
                            c->heavy_items, c->heavy_cols.as<int>(), c->n_heavy, c->partial.as<float>(),
-                           c->norm_pwz.as<float>(), c->Vt[1 - c->cv].as<float>(), c->kp);
+                           c->norm_pwz.as<float>(), c->Vt[out_v(c)].as<float>(), c->kp);
     }));
     return launch_check(c, "k_col_reduce_norm");
 }
@@ -1043,7 +1050,15 @@ int finish_ll(plsa_ctx *c, int blocks, double *out) {
     if (c->sharded && c->comm)      // log-likelihood of all shards: one scalar all-reduce per test
         NCCLCHK(c, ncclAllReduce(c->ll_out.p, c->ll_out.p, 1, ncclDouble, ncclSum, c->comm, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_ll, c->ll_out.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (!out) return hipEventRecord(c->ev_ll, c->stream) == hipSuccess ? 0 : fail(c, "event record failed");   // collected by wait_ll
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out = *c->h_ll;
+    return 0;
+}
+
+// second half of finish_ll(c, blocks, nullptr): the host waits for the likelihood only, not for the work enqueued behind it
+int wait_ll(plsa_ctx *c, double *out) {
+    HIPCHK(c, hipEventSynchronize(c->ev_ll));
     *out = *c->h_ll;
     return 0;
 }
@@ -1132,6 +1147,7 @@ int plsa_create(int device, plsa_ctx **out) {
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_row, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_ll, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&c->h_ll, sizeof(double) * 2, hipHostMallocDefault) != hipSuccess) {
         delete c;
         return fail(nullptr, "stream / pinned buffer creation failed");
@@ -1164,6 +1180,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_ROW_SHAPE")) c->row_shape_8x2 = atoi(s) != 0;
     if (const char *s = getenv("PLSA_FORCE_WIDE")) c->force_wide = atoi(s) != 0;
     if (const char *s = getenv("PLSA_MT_CHAIN")) c->mt_chain = atoi(s) != 0;
+    if (const char *s = getenv("PLSA_SPECULATE")) c->speculate = atoi(s);
     *out = c;
     return 0;
 }
@@ -1180,7 +1197,7 @@ void plsa_destroy(plsa_ctx *c) {
     release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly); release(c->mt_seq);
     DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
-                     &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->Vt[0], &c->Vt[1], &c->Vacc,
+                     &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->U[2], &c->Vt[0], &c->Vt[1], &c->Vt[2], &c->Vacc,
                      &c->P, &c->sw, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
                      &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp};
     for (DevBuf *b : all) release(*b);
@@ -1191,6 +1208,7 @@ void plsa_destroy(plsa_ctx *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_row) (void)hipEventDestroy(c->ev_row);
     if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+    if (c->ev_ll) (void)hipEventDestroy(c->ev_ll);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1633,6 +1651,31 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
             plsa_ctx *c; bool on;
             ~PipelineJoin() { if (on) { (void)hipStreamSynchronize(c->stream2); } }
         } pipeline_join{c, pipelined};
+        // Speculation across a likelihood test.  The test after iteration i - 1 rides on iteration i's document pass; the
+        // host used to wait for it before enqueuing iteration i + 1 -- an idle chip for one host round trip plus the launch
+        // latency of the next passes, every n_iter_per_test iterations (config 2: ~40 us per test = 2.3 % of the run).
+        // With a THIRD set of factor buffers iteration i + 1 is enqueued first (it reads iteration i's output and writes the
+        // third set, so the factors a "stop" must return are still untouched) and the host then waits for the likelihood
+        // alone.  "Stop" discards two iterations instead of one; the returned factors, count and trace are the same.
+        const bool speculate = (c->speculate > 0 || (c->speculate < 0 && (double)c->nnz * c->kp < c->overlap_full_limit)) &&
+                               !c->sharded && !graph_requested && n_iter_per_test >= 2 && n_iter >= 3;
+        struct Rot3Scope {       // leaves cu, cv in {0, 1} (everything outside this loop addresses the alternate as 1 - cu)
+            plsa_ctx *c;
+            ~Rot3Scope() {
+                if (!c->rot3) return;
+                c->rot3 = false;
+                if (c->cu == 2) { std::swap(c->U[2], c->U[0]); c->cu = 0; }
+                if (c->cv == 2) { std::swap(c->Vt[2], c->Vt[0]); c->cv = 0; }
+            }
+        } rot3_scope{c};
+        if (speculate) {
+            CHK(ensure(c, c->U[2], sizeof(float) * (size_t)c->n * c->kp));
+            CHK(ensure(c, c->Vt[2], sizeof(float) * (size_t)c->m * c->kp));
+            c->rot3 = true;
+        }
+        auto advance = [&]() {
+            if (c->rot3) { c->cu = (c->cu + 1) % 3; c->cv = (c->cv + 1) % 3; } else { c->cu ^= 1; c->cv ^= 1; }
+        };
         // one fused EM iteration from the factors in (cu, cv) into the alternate buffers (no swap here)
         auto enqueue_iteration = [&](bool want_ll, int *blocks) -> int {
             // PLSA_SHARDED: every collective of the communicator goes on c->stream in program order (accumulator
@@ -1742,6 +1785,27 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 if (ll_trace) ll_trace[nll] = prev;
                 nll++;
                 first_ll_in_pass = false;
+            } else if (pending && speculate && i + 1 < n_iter) {
+                CHK(finish_ll(c, blocks, nullptr));            // on its way to the host; not waited for yet
+                const int su = c->cu, sv = c->cv;              // the factors a stop returns
+                advance();                                     // iteration i + 1 reads iteration i's output ...
+                int blocks2 = 0;
+                const int rc = enqueue_iteration(false, &blocks2);   // ... and writes the third set (n_iter_per_test >= 2: no test rides on it)
+                if (rc) { c->cu = su; c->cv = sv; return rc; }
+                CHK(wait_ll(c, &ll));
+                const float cur = (float)ll;
+                if (ll_trace) ll_trace[nll] = cur;
+                nll++;
+                if (stop_test(cur, prev, tolerance, zero_arm)) {     // discard both passes
+                    c->cu = su; c->cv = sv;
+                    stopped = true;
+                    break;
+                }
+                advance();
+                iters += 2;
+                ++i;                                           // (iteration i + 1 is done; it is no multiple-of-test successor)
+                pending = (i % n_iter_per_test == 0);
+                continue;
             } else if (pending) {
                 CHK(finish_ll(c, blocks, &ll));
                 const float cur = (float)ll;
@@ -1749,7 +1813,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 nll++;
                 if (stop_test(cur, prev, tolerance, zero_arm)) { stopped = true; break; }  // discard this pass
             }
-            c->cu ^= 1; c->cv ^= 1;
+            advance();
             iters++;
             pending = (i % n_iter_per_test == 0);
         }

@@ -1422,8 +1422,9 @@ def test_fuzz_slice(amd):
 def test_schedule_knobs_do_not_change_results(amd):
     """Round-3 scheduling machinery changes WHEN work runs, never WHAT is computed: measured XCD boundaries of the
     column pass (PLSA_BALANCE), the event-linked pipelines of small corpora (PLSA_PIPELINE), hipGraph replay
-    (PLSA_GRAPH), and the address width of the factor-row gathers (PLSA_FORCE_WIDE) -- factors, iteration count and
-    likelihood trace are bit-identical with each switched the other way.
+    (PLSA_GRAPH), the address width of the factor-row gathers (PLSA_FORCE_WIDE), and the iteration enqueued ahead of a
+    likelihood test's verdict on a third set of buffers (PLSA_SPECULATE) -- factors, iteration count and likelihood trace
+    are bit-identical with each switched the other way.
     Two corpora: one large enough for the boundary tuning (nnz * k >= 1e8), one small enough for the pipelines."""
     from enstop_amd.engine import reset_engines
     rs = np.random.RandomState(4)
@@ -1442,7 +1443,7 @@ def test_schedule_knobs_do_not_change_results(amd):
         assert amd.engine.get_engine().balance_info()["timed_launches"] >= 0
         # PLSA_FORCE_WIDE: the 64-bit row addressing that factor tables of 4 GB or more take (32-bit byte offsets below)
         for knob, val in (("PLSA_BALANCE", "0"), ("PLSA_BALANCE", "1"), ("PLSA_PIPELINE", "0"), ("PLSA_GRAPH", "1"),
-                          ("PLSA_FORCE_WIDE", "1")):
+                          ("PLSA_FORCE_WIDE", "1"), ("PLSA_SPECULATE", "0"), ("PLSA_SPECULATE", "1")):
             os.environ[knob] = val
             reset_engines()                       # knobs are read when a context is created
             for (X, k, kw), (U0, V0, i0) in zip(cases, ref):

@@ -20,6 +20,7 @@ ap.add_argument("--flags", default="fused")
 ap.add_argument("--events", action="store_true")
 ap.add_argument("--estep", action="store_true", help="time the materialising E-step kernel instead of fits")
 ap.add_argument("--tag", default="")
+ap.add_argument("--per-test", type=int, default=10, help="n_iter_per_test of the timed fit (a likelihood test = one host round trip)")
 ap.add_argument("--no-zero-arm", action="store_true", help="stop test without the `change == 0` arm (timing experiments)")
 a = ap.parse_args()
 cfg = bench.CONFIGS[a.config]
@@ -52,7 +53,7 @@ for _ in range(a.reps):
         eng.timing(True); eng.timing_reset()
     eng.synchronize()
     t0 = time.perf_counter()
-    it, ll = eng.fit(None, n_iter=a.steps, n_iter_per_test=10, tolerance=0.0, flags=flags)
+    it, ll = eng.fit(None, n_iter=a.steps, n_iter_per_test=a.per_test, tolerance=0.0, flags=flags)
     eng.synchronize()
     dt = time.perf_counter() - t0
     assert it == a.steps
