@@ -7,8 +7,9 @@
 //   rowidx       i32[nnz]   COO row ids of the active matrix (nnz-parallel E-step)
 //   CSC copy     colptr i32[m+1], csc_row/csc_pos i32[nnz], csc_val f32[nnz], column items
 //                (built lazily; not needed with PLSA_ATOMIC_V)
-//   U[2]         f32[n,kp]  P(z|d), double-buffered (a rejected iteration is simply not swapped in)
-//   Vt[2], Vacc  f32[m,kp]  P(w|z) word-major, double-buffered, + the un-normalised accumulator
+//   U[2(+1)]     f32[n,kp]  P(z|d), double-buffered (a rejected iteration is simply not swapped in); a third buffer while a
+//                fit of a small corpus runs one iteration ahead of its likelihood tests (plsa_fit)
+//   Vt[2(+1)], Vacc  f32[m,kp]  P(w|z) word-major, buffered like U, + the un-normalised accumulator
 //   P            f32[nnz,kp] materialised responsibilities (only when not PLSA_FUSED)
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
