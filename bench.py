@@ -155,6 +155,7 @@ def quick_config(eng, cfg_id, steps, warmup, seed, with_cpu=False):
     eng.fit(None, n_iter=warmup, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=PLSA_FUSED)
     eng.synchronize()
     t0 = time.perf_counter()
+    steps = max(steps, 200)        # a 0.17 ms iteration: 50 of them would be dominated by the call's fixed costs
     it, _ = eng.fit(None, n_iter=steps, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=PLSA_FUSED)
     eng.synchronize()
     dt = time.perf_counter() - t0
