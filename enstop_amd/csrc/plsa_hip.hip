@@ -1674,6 +1674,16 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
             CHK(ensure(c, c->Vt[2], sizeof(float) * (size_t)c->m * c->kp));
             c->rot3 = true;
         }
+        bool first_wait = false;     // the initial likelihood is in flight (speculating loop)
+        int first_slot = 0;
+        auto collect_first = [&]() -> int {
+            if (!first_wait) return 0;
+            first_wait = false;
+            CHK(wait_ll(c, &ll));
+            prev = (float)ll;
+            if (ll_trace) ll_trace[first_slot] = prev;
+            return 0;
+        };
         auto advance = [&]() {
             if (c->rot3) { c->cu = (c->cu + 1) % 3; c->cv = (c->cv + 1) % 3; } else { c->cu ^= 1; c->cv ^= 1; }
         };
@@ -1781,12 +1791,19 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
             }
             CHK(enqueue_iteration(want_ll, &blocks));
             if (first_ll_in_pass) {
-                CHK(finish_ll(c, blocks, &ll));
-                prev = (float)ll;
-                if (ll_trace) ll_trace[nll] = prev;
+                if (speculate) {       // nothing is decided on the initial likelihood: it is collected when the first test needs it
+                    CHK(finish_ll(c, blocks, nullptr));
+                    first_wait = true;
+                    first_slot = nll;
+                } else {
+                    CHK(finish_ll(c, blocks, &ll));
+                    prev = (float)ll;
+                    if (ll_trace) ll_trace[nll] = prev;
+                }
                 nll++;
                 first_ll_in_pass = false;
             } else if (pending && speculate && i + 1 < n_iter) {
+                CHK(collect_first());
                 CHK(finish_ll(c, blocks, nullptr));            // on its way to the host; not waited for yet
                 const int su = c->cu, sv = c->cv;              // the factors a stop returns
                 advance();                                     // iteration i + 1 reads iteration i's output ...
@@ -1808,6 +1825,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
                 pending = (i % n_iter_per_test == 0);
                 continue;
             } else if (pending) {
+                CHK(collect_first());
                 CHK(finish_ll(c, blocks, &ll));
                 const float cur = (float)ll;
                 if (ll_trace) ll_trace[nll] = cur;
@@ -1818,6 +1836,7 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
             iters++;
             pending = (i % n_iter_per_test == 0);
         }
+        CHK(collect_first());
         if (pipelined) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_tail, 0));   // the last column chain precedes whatever follows
         if (!stopped && pending && trace) {  // test of the last iteration: result-neutral
             CHK(run_loglik(c, d_sw, &ll));
