@@ -1419,6 +1419,37 @@ def test_fuzz_slice(amd):
     assert "mismatches 0" in out.stdout
 
 
+@pytest.mark.parametrize("per_test", [2, 3, 5])
+def test_speculation_across_likelihood_tests_keeps_every_stop_decision(amd, oracle, per_test):
+    """The fused loop of a small corpus enqueues the iteration BEHIND a likelihood test before the host has the test's
+    value (third set of factor buffers, plsa_fit).  Whatever the test then says -- stop at the very first test, at a later
+    one, never -- iteration count, trace and factors must be those of the loop that waits (PLSA_SPECULATE=0), bit for
+    bit, and the count must be the oracle's (the reference's plsa.py:630-638 loop)."""
+    from enstop_amd.engine import reset_engines
+    X = _corpus(500, 700, 0.05, seed=91, empty_rows=1)
+    sw = np.ones(X.shape[0], np.float32)
+    saved = dict(os.environ)
+    try:
+        for tol in (0.5, 2e-2, 3e-3, 1e-4, 0.0):             # stop at the first test ... never
+            for n_iter in (3, 4, 17):
+                kw = dict(n_iter=n_iter, n_iter_per_test=per_test, tolerance=tol, e_step_thresh=1e-16, random_state=7)
+                got = {}
+                for spec in ("1", "0"):
+                    os.environ["PLSA_SPECULATE"] = spec
+                    reset_engines()
+                    got[spec] = amd.plsa_fit(X, 6, sw, flags=MODES["fused"], return_info=True, **kw)
+                (U1, V1, i1), (U0, V0, i0) = got["1"], got["0"]
+                assert i1["n_iter"] == i0["n_iter"], kw
+                np.testing.assert_array_equal(i1["log_likelihood_trace"], i0["log_likelihood_trace"])
+                np.testing.assert_array_equal(U1, U0)
+                np.testing.assert_array_equal(V1, V0)
+                _, _, _, iters = oracle.plsa_fit(X, 6, sw, return_trace=True, **kw)
+                assert i1["n_iter"] == iters, kw
+    finally:
+        os.environ.clear(); os.environ.update(saved)
+        reset_engines()
+
+
 def test_schedule_knobs_do_not_change_results(amd):
     """Round-3 scheduling machinery changes WHEN work runs, never WHAT is computed: measured XCD boundaries of the
     column pass (PLSA_BALANCE), the event-linked pipelines of small corpora (PLSA_PIPELINE), hipGraph replay
