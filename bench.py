@@ -470,9 +470,8 @@ def main():
 
     from enstop_amd import distributed as plsa_dist
     stack_base = eng.stack_reserve(1, k, m) if world > 1 else None
-    # the result array of the gather, allocated and touched ONCE (a caller that gathers repeatedly re-uses it; the
-    # product's ensemble_of_topics allocates its result once per ensemble)
-    stack_out = np.zeros((world * k, m), np.float32) if world > 1 else None
+    # (the gathered stack is read through a view of the engine's page-locked buffer: distributed.gather_stack(view=True),
+    #  the product's fastest host copy -- no page faults of a fresh result array inside the timed region)
 
     def gather_components():
         """the np.vstack of enstop_.py:231 through the product's own exchange: this member's topics go into the
@@ -480,7 +479,7 @@ def main():
         if world == 1:
             return None
         eng.copy_components_to_device(stack_base)
-        return plsa_dist.gather_stack(eng, world, k, m, out=stack_out).reshape(world, k, m)
+        return plsa_dist.gather_stack(eng, world, k, m, view=True).reshape(world, k, m)     # view of the page-locked buffer
 
     # ---- warmup (untimed): W EM iterations + the collective --------------------------------------
     stage("warm-up gather")

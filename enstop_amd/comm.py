@@ -118,13 +118,15 @@ class SingleComm:
         """[slots, k, m] of this rank -> [slots * world, k, m] of all ranks in run order (host arrays)."""
         return _run_order(self.allgather_array(np.asarray(local)))
 
-    def gather_stack(self, eng, slots, k, m, out=None):
+    def gather_stack(self, eng, slots, k, m, out=None, view=False):
         """The stack of ALL ranks' members in run order, [slots * world, k, m]: `eng` holds this rank's
         members in its device stack (Engine.stack_reserve; run r = slot r // world of rank r % world).
         Communicators without a device path bring the local stack to the host (one copy) and exchange it there.
-        `out`: the caller's own result array (re-used across calls)."""
+        `out`: the caller's own result array (re-used across calls).  `view=True` (RCCL / single rank): a VIEW of the
+        engine's page-locked buffer instead -- the fastest copy (no page faults of a fresh array), valid until the next
+        gather on that engine."""
         if self.world == 1:                                   # nothing to exchange: one device-to-host copy
-            return eng.comm_allgather_stack(slots, k, m, out=out)
+            return eng.comm_allgather_stack(slots, k, m, copy=not view, out=None if view else out)
         g = self.gather_host_stack(eng.comm_allgather_stack(slots, k, m, copy=False))
         if out is not None:
             out.reshape(g.shape)[...] = g
@@ -159,7 +161,7 @@ class RcclComm(SingleComm):
     def broadcast_array(self, a, root=0):
         return self.eng.comm_broadcast_host(np.ascontiguousarray(a), root)
 
-    def gather_stack(self, eng, slots, k, m, out=None):
+    def gather_stack(self, eng, slots, k, m, out=None, view=False):
         if eng is not self.eng:
             # the members were fitted on another engine than the communicator's (ensemble_of_topics(device=d),
             # init_from_env(eng=custom)): bring that engine's stack to the host and exchange it through RCCL's
@@ -169,7 +171,8 @@ class RcclComm(SingleComm):
                 out.reshape(g.shape)[...] = g
                 return out.reshape(g.shape)
             return g
-        return eng.comm_allgather_stack(slots, k, m, out=out)   # one grouped ncclAllGather on the engine's stream + one copy
+        # one grouped ncclAllGather on the engine's stream + one copy (into `out`, a fresh array, or the page-locked buffer)
+        return eng.comm_allgather_stack(slots, k, m, copy=not view, out=None if view else out)
 
     def allreduce_accumulator(self, eng):
         if eng is not self.eng:

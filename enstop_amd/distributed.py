@@ -44,16 +44,17 @@ def gather_host_stack(local, n_runs):
     return g[:n_runs].reshape(n_runs * g.shape[1], g.shape[2])
 
 
-def gather_stack(eng, n_runs, k, m, out=None):
+def gather_stack(eng, n_runs, k, m, out=None, view=False):
     """The (n_runs * k, m) stack of all members in run order on every rank -- the np.vstack of
     enstop/enstop_.py:231.  `eng` holds this rank's members in its device stack (slot s = run s * world + rank,
     written by Engine.copy_components_to_device); with RCCL the stacks are exchanged device to device by ONE
     grouped all-gather and reach the host in ONE copy, straight into the result array
     (plsa_comm_allgather_stack_to).  `out`: a float32 array of n_runs * k * m elements to receive the stack (a caller
-    that gathers repeatedly re-uses it; n_runs must then be a multiple of the number of ranks)."""
+    that gathers repeatedly re-uses it; n_runs must then be a multiple of the number of ranks).  `view=True`: the result
+    is a view of the engine's page-locked host buffer (no page faults, the fastest copy), valid until the next gather."""
     c = _comm.current()
     slots = (n_runs + c.world - 1) // c.world
     if out is not None and slots * c.world != n_runs:
         raise ValueError("out= needs n_runs (%d) to be a multiple of the number of ranks (%d)" % (n_runs, c.world))
-    g = c.gather_stack(eng, slots, k, m, out=out)       # [slots * world, k, m]
+    g = c.gather_stack(eng, slots, k, m, out=out, view=view)       # [slots * world, k, m]
     return g[:n_runs].reshape(n_runs * k, m)

@@ -754,6 +754,10 @@ def test_native_rccl_communicator_single_rank(amd):
         eng.copy_components_to_device(base + 4 * 32 * m_)
         np.testing.assert_array_equal(c.gather_stack(eng, 2, 32, m_), np.stack([V1, V1]))
         np.testing.assert_array_equal(amd.distributed.gather_stack(eng, 2, 32, m_), np.vstack([V1, V1]))
+        out = np.empty((2 * 32, m_), np.float32)               # the caller's own result array, and the page-locked view
+        assert amd.distributed.gather_stack(eng, 2, 32, m_, out=out).base is not None
+        np.testing.assert_array_equal(out, np.vstack([V1, V1]))
+        np.testing.assert_array_equal(amd.distributed.gather_stack(eng, 2, 32, m_, view=True), np.vstack([V1, V1]))
         monkey_env = dict(os.environ)
         os.environ["ENSTOP_AMD_SHARDED_INLOOP"] = "1"
         try:
