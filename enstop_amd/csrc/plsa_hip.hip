@@ -586,8 +586,13 @@ int ensure_csc(plsa_ctx *c) {
     CHK(ensure(c, c->tmp2, sizeof(unsigned long long) * ni * 2));   // sort keys, sorted keys
     CHK(ensure(c, c->tmp1, sizeof(int) * ni));           // item ids
     unsigned long long *d_key = c->tmp2.as<unsigned long long>();
-    // band of the visiting order: 512 KB of P(z|d) rows (2048 documents at k = 64), PLSA_ORDER_BAND documents
-    const int band = c->order_band >= 0 ? c->order_band : std::max(64, (512 << 10) / (c->kp > 0 ? c->kp * 4 : 256));
+    // band of the visiting order (PLSA_ORDER_BAND documents): 2 MB of P(z|d) rows from k = 64 on -- half an XCD's L2; 8192
+    // documents at config 3, 4096 at config 5.  Measured with the final kernels of round 4, config 3: 2048 / 6144 / 8192 /
+    // 10240 / 16384 / 32768 documents -> 313 / 318 / 319 / 316 / 303 / 254 iterations/s; config 5: 1024 / 3072 / 4096 / 6144 ->
+    // 29.0 / 29.4 / 29.9 / 29.8 (round 3 chose 512 KB with 256-entry items).  Narrow k-vectors stay at 512 KB (config 2:
+    // 8192 documents = 1 MB neutral, 16384 = 2 MB 2 % slower)
+    const int band_bytes = (c->kp >= 64 ? 2048 : 512) << 10;
+    const int band = c->order_band >= 0 ? c->order_band : std::max(64, band_bytes / (c->kp > 0 ? c->kp * 4 : 256));
     // key = band index << len_bits | inverted column length (a column holds at most n entries); first document when band <= 0
     int len_bits = 1;
     while (((i64)1 << len_bits) <= c->n) ++len_bits;
