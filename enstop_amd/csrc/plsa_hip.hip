@@ -98,7 +98,7 @@ struct plsa_ctx {
     // row items (documents cut into pieces) for corpora with few / very uneven rows
     bool force_wide = false;           // PLSA_FORCE_WIDE: 64-bit gather addresses whatever the table size
     bool ritems_valid = false, use_ritems = false;
-    int rseg = 64, ritems_mode = -1;   // -1 auto, 0 never, 1 always (PLSA_ROW_ITEMS)
+    int rseg = 64, rseg_override = 0, ritems_mode = -1;   // ritems_mode: -1 auto, 0 never, 1 always (PLSA_ROW_ITEMS); rseg: entries per row item (PLSA_ROW_SEG, 0 = by size)
     i64 n_ritems = 0;
     DevBuf ritem_first, ritem_row, ritem_start, rpartial;
 
@@ -458,7 +458,20 @@ int ensure_ritems(plsa_ctx *c) {
     const i64 n = c->n;
     const i64 group_slots = (i64)c->prop.multiProcessorCount * 32 * (64 / std::max(1, c->row_lpn));
     const double avg = (double)c->nnz / (double)std::max<i64>(n, 1);
-    c->use_ritems = c->ritems_mode == 1 || (c->ritems_mode < 0 && n < 2 * group_slots && avg > 2.0 * c->rseg);
+    // the decision is made for 64-entry items (documents averaging more than 128 entries: config 2's 100-entry documents
+    // stay whole -- items cost it 15 % in the two-stream schedule); the item LENGTH then follows the size of the corpus:
+    // about one item per group slot, a power of two in [16, 64] (20NG shape: 45 entries per slot -> 32; with the final
+    // kernels of round 4 row items of 16 / 24 / 32 / 40 / 48 / 64 entries give 9.9 / 10.7 / 11.1 / 11.1 / 10.9 / 10.4 k
+    // iterations/s at config 1, profiles/r04_small_corpus_item_lengths.txt)
+    const int rseg_decide = c->rseg_override ? c->rseg_override : 64;
+    c->use_ritems = c->ritems_mode == 1 || (c->ritems_mode < 0 && n < 2 * group_slots && avg > 2.0 * rseg_decide);
+    if (c->rseg_override) c->rseg = c->rseg_override;
+    else {
+        const i64 per_slot = c->nnz / std::max<i64>(group_slots, 1);
+        int r = 16;
+        while (r * 2 <= per_slot && r < 64) r *= 2;
+        c->rseg = r;
+    }
     c->n_ritems = 0;
     if (c->use_ritems) {
         CHK(ensure(c, c->ritem_first, sizeof(int) * (size_t)(n + 1)));
@@ -525,7 +538,10 @@ int ensure_csc(plsa_ctx *c) {
         // short items (enough items to fill the chip: config 1 0.244 -> 0.094 ms at 16) and large
         // ones long items (fewer partial rows: 256 measured best at config 3)
         const i64 slots = (i64)c->prop.multiProcessorCount * 32 * (64 / std::max(1, c->lpn));
-        i64 want = c->nnz / std::max<i64>(4 * slots, 1);
+        // (round 4, final kernels: about 1.25 group slots per item instead of 4 -- config 1 now cuts its columns into
+        //  32-entry items, 16 / 32 / 48 / 64 -> 10.5 / 11.1 / 11.0 / 10.9 k iterations/s with 32-entry row items; config 2
+        //  64 instead of 32: the same within noise)
+        i64 want = c->nnz / std::max<i64>(slots + slots / 4, 1);
         int seg = 16;
         // large corpora: with the XCD stretches balanced, SHORTER items win (an item then spans fewer documents
         // and stays inside the band its XCD's L2 holds): config 3 (k = 64) 256 / 128 / 96 / 64 / 48 entries ->
@@ -1162,7 +1178,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_OVERLAP")) c->overlap = atoi(s) != 0;
     if (const char *s = getenv("PLSA_OVERLAP_FULL_LIMIT")) c->overlap_full_limit = atof(s);
     if (const char *s = getenv("PLSA_ROW_ITEMS")) c->ritems_mode = atoi(s);
-    if (const char *s = getenv("PLSA_ROW_SEG")) c->rseg = std::max(1, atoi(s));
+    if (const char *s = getenv("PLSA_ROW_SEG")) c->rseg_override = std::max(1, atoi(s));
     int mult = 128;  // blocks per CU a grid may hold: large (but bounded) grids measured best
     if (const char *s = getenv("PLSA_GRID_MULT")) mult = std::max(1, atoi(s));
     c->grid_cap = c->prop.multiProcessorCount * mult;
