@@ -46,7 +46,8 @@ def _fit_members(A, k, runs, seeds, member_kw, device, n_jobs, world=1, n_runs=N
     jobs = min(concurrent_members(A.nnz, k, n_jobs), max(len(runs), 1))
     engines = get_member_engines(device, jobs)
     for e in engines[1:]:
-        e.upload_csr(A)                  # (the first one holds the corpus already)
+        e.upload_csr(A)                  # (the first one holds the corpus already; uploading inside the worker threads
+                                         #  instead measured no better: 9 130 against 8 950 fits/min at the 20NG shape)
     m = A.shape[1]
     # every rank reserves the same number of slots (the all-gather is slot by slot), filled or not
     slots = max(1, max((r // world for r in runs), default=0) + 1) if n_runs is None else max(1, (n_runs + world - 1) // world)
