@@ -30,6 +30,7 @@ _vp = C.c_void_p          # nullable array arguments are passed as raw addresses
 # name -> (restype, argtypes); must list every symbol include/plsa_hip.h declares
 SIGNATURES = {
     "plsa_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "plsa_hw_queues": (C.c_int, []),
     "plsa_create": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
     "plsa_destroy": (None, [_ctx]),
     "plsa_last_error": (C.c_char_p, [_ctx]),
@@ -90,9 +91,40 @@ SIGNATURES = {
     "plsa_host_mt19937_jump": (C.c_int, [C.POINTER(C.c_uint32), _i32]),
     "plsa_generate_synthetic": (C.c_int, [_ctx, _i64, _i64, _i64, C.c_double, C.c_uint64,
                                           C.POINTER(_i64)]),
+    "plsa_generate_synthetic_topics": (C.c_int, [_ctx, _i64, _i64, _i64, C.c_double, C.c_uint64, _i32, C.c_double,
+                                                 C.c_double, C.POINTER(_i64)]),
 }
 
 _lib = None
+HW_QUEUES = {"set_by": None, "hip_mapped_before_load": None}
+
+
+def _default_hw_queues():
+    """Ensemble members of a small corpus are fitted on up to four contexts of one GPU (enstop_.py's thread pool,
+    enstop_.py:209-217); with the HIP runtime's default of 4 hardware queues their streams share queues and wait for each
+    other (20NG shape: +10 % fits/min with 8).  The runtime reads GPU_MAX_HW_QUEUES at its first call, so it is set
+    HERE, visibly, before the library is loaded -- never by the library itself -- unless the user set it or opted out
+    with ENSTOP_AMD_HW_QUEUES=0 (any other value of that variable is the number to use).  It cannot take effect when the
+    process initialised HIP earlier (e.g. torch.cuda): `hw_queues()` says whether the runtime was already mapped."""
+    try:
+        with open("/proc/self/maps") as f:
+            HW_QUEUES["hip_mapped_before_load"] = "libamdhip64" in f.read()
+    except OSError:
+        pass
+    want = os.environ.get("ENSTOP_AMD_HW_QUEUES", "8")
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        HW_QUEUES["set_by"] = "user"
+    elif want == "0":
+        HW_QUEUES["set_by"] = "opt-out"
+    else:
+        os.environ["GPU_MAX_HW_QUEUES"] = want
+        HW_QUEUES["set_by"] = "enstop_amd"
+
+
+def hw_queues():
+    """{'value': hardware queues this process asks the HIP runtime for, 'set_by': 'enstop_amd' | 'user' | 'opt-out',
+    'hip_mapped_before_load': True when libamdhip64 was already in the process (the setting may have come too late)}"""
+    return dict(HW_QUEUES, value=int(load().plsa_hw_queues()))
 
 
 def load():
@@ -104,6 +136,7 @@ def load():
         raise ImportError(
             "enstop_amd: %s not found -- build the HIP extension first "
             "(python -m enstop_amd.build). There is no CPU fallback." % LIB_PATH)
+    _default_hw_queues()
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export it

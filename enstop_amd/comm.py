@@ -5,16 +5,15 @@ doc-sharded fit (enstop/distributed_plsa.py:116-131).  One process per GPU.
 The product path is `RcclComm`: RCCL collectives issued from the C ABI (plsa_comm_* in
 include/plsa_hip.h, librccl linked into libplsa_hip.so) on the engine's own HIP streams -- no PyTorch in
 the process.  Only the 128-byte RCCL unique id has to reach the other ranks out of band; on one node that
-is a file (`rendezvous_id`).  Two more implementations of the same small interface exist:
+is a file (`rendezvous_id`).  One more implementation of the same small interface lives here:
 
-  TorchComm   rides on a torch.distributed process group the CALLER initialised (gloo on CPUs, or nccl);
-              optional -- lets the package run inside an existing torch.distributed job, and is what the
-              CPU test-suite uses (world_size-2 gloo tests)
   FileComm    host files in a shared directory; a test double (single-GPU boxes cannot host two RCCL ranks:
               RCCL refuses two ranks on one device), never selected automatically
 
-`current()` returns the communicator in force: an explicitly installed one (`install`, `init_from_env`),
-else a TorchComm when torch.distributed is initialised, else the single-process identity.
+`current()` returns the communicator in force: an explicitly installed one (`install`, `init_from_env`), else the
+single-process identity.  Nothing here imports, detects or dispatches on PyTorch (rounds 1-4 auto-selected a
+torch.distributed-backed communicator when a process group was initialised; that adapter is test scaffolding now:
+tests/torch_comm.py, installed explicitly by the world-size-2 gloo tests).
 """
 import os
 import sys
@@ -185,64 +184,6 @@ class RcclComm(SingleComm):
         self.eng.comm_destroy()
 
 
-class TorchComm(SingleComm):
-    """Over the caller's torch.distributed process group (gloo: host tensors; nccl: device tensors)."""
-    name = "torch"
-
-    def __init__(self):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.on_device = dist.get_backend() == "nccl"
-        self.name = "torch/" + dist.get_backend()
-
-    def _dev(self, eng=None):
-        if not self.on_device:
-            return self.torch.device("cpu")
-        # an Engine lives on LOCAL_RANK / ENSTOP_AMD_DEVICE, which need not be torch's current device
-        return self.torch.device("cuda", eng.device if eng is not None else self.torch.cuda.current_device())
-
-    def barrier(self):
-        self.dist.barrier()
-
-    def allgather_array(self, a):
-        a = np.ascontiguousarray(a)
-        t = self.torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(self._dev())
-        out = [self.torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(out, t)
-        return np.stack([o.cpu().numpy().view(a.dtype).reshape(a.shape) for o in out])
-
-    def allreduce_f64(self, values, op="sum"):
-        t = self.torch.tensor(np.atleast_1d(np.asarray(values, np.float64)), dtype=self.torch.float64, device=self._dev())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
-        return t.cpu().numpy()
-
-    def broadcast_array(self, a, root=0):
-        a = np.ascontiguousarray(a)
-        t = self.torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(self._dev())
-        self.dist.broadcast(t, src=root)
-        return t.cpu().numpy().view(a.dtype).reshape(a.shape)
-
-    def allreduce_accumulator(self, eng):
-        torch, dist = self.torch, self.dist
-        if self.on_device:
-            ptr, n = eng.accumulator_device()
-
-            class _View:        # zero-copy view of the engine's accumulator
-                __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-            eng.synchronize()
-            with torch.cuda.device(eng.device):
-                t = torch.as_tensor(_View(), device=self._dev(eng))
-                assert t.data_ptr() == ptr, "torch copied the accumulator instead of viewing it"
-                dist.all_reduce(t)
-                torch.cuda.synchronize(eng.device)
-        else:
-            t = torch.from_numpy(eng.accumulator_get())
-            dist.all_reduce(t)
-            eng.accumulator_set(t.numpy())
-
-
 class FileComm(SingleComm):
     """Test double: exchanges through .npy files in a directory shared by the ranks of one node."""
     name = "files"
@@ -264,14 +205,24 @@ class FileComm(SingleComm):
                                "same launch token; remove the directory" % (self.dir, self.rank, stale[0]))
 
     def close(self):
-        """Final barrier (every rank has read everything), then this rank's last file goes; the directory is removed
-        by whoever finds it empty."""
+        """Final barrier, then every rank leaves a `done` marker -- written AFTER it has read the barrier's payloads --
+        and only rank 0 removes files, once all markers are there: nothing a slower rank still polls for or loads can
+        disappear under it (round 4 unlinked after a 10 ms sleep and a slow peer spun until its timeout)."""
         if self.seq == 0:
             return
         try:
             self.barrier()
-            time.sleep(0.01)                       # the others may still be loading the barrier payload
-            os.unlink(self._path(self.seq, self.rank))
+            with open(os.path.join(self.dir, "done_r%d" % self.rank), "w"):
+                pass
+            if self.rank != 0:
+                return
+            t0 = time.time()
+            while not all(os.path.exists(os.path.join(self.dir, "done_r%d" % r)) for r in range(self.world)):
+                if time.time() - t0 > min(self.timeout, 30.0):
+                    return                          # a peer died: leave the directory for inspection
+                time.sleep(0.001)
+            for f in os.listdir(self.dir):
+                os.unlink(os.path.join(self.dir, f))
             os.rmdir(self.dir)
         except (OSError, TimeoutError):
             pass
@@ -333,21 +284,24 @@ def install(comm):
 
 
 def current():
-    if _installed is not None:
-        return _installed
-    dist = sys.modules.get("torch.distributed")      # never import torch just to find out
-    if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return TorchComm()
-    return SingleComm()
+    """The installed communicator, else the single-process identity -- no detection of anything else in the process."""
+    return _installed if _installed is not None else SingleComm()
+
+
+def _launcher_nonce():
+    """The per-launch nonce a launcher exports: PLSA_LAUNCH_NONCE (bench.py's spawner, or the user) or torchrun's
+    TORCHELASTIC_RUN_ID -- except its static-rendezvous constant 'none', which identifies nothing."""
+    nonce = os.environ.get("PLSA_LAUNCH_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+    if nonce == "none":
+        nonce = ""
+    return "".join(ch if ch.isalnum() else "_" for ch in nonce)[:40]
 
 
 def launch_token():
-    """Identifies ONE launch of the ranks: the launcher's own nonce when it exports one (torchrun's
-    TORCHELASTIC_RUN_ID, PLSA_LAUNCH_NONCE from bench.py's spawner), always combined with the parent pid and the
-    parent's start time -- two launches from the same parent pid (containers restart at the same pid) differ in it."""
-    nonce = os.environ.get("PLSA_LAUNCH_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or "x"
-    nonce = "".join(ch if ch.isalnum() else "_" for ch in nonce)[:40]
-    return "%s_%d_%d" % (nonce, os.getppid(), int(_parent_start_ticks()))
+    """Identifies ONE launch of the ranks: the launcher's own nonce when it exports one (`_launcher_nonce`), always
+    combined with the parent pid and the parent's start time -- two launches from the same parent pid (containers
+    restart at the same pid) differ in it."""
+    return "%s_%d_%d" % (_launcher_nonce() or "x", os.getppid(), int(_parent_start_ticks()))
 
 
 def _parent_start_ticks():
@@ -371,14 +325,17 @@ def default_id_file():
 
 
 def _rendezvous_token(path):
-    """What the id file must carry for a waiting rank to accept it.  A path chosen by `default_id_file` belongs to
-    one launcher: the full launch token (nonce + parent pid + parent start).  An explicit PLSA_COMM_ID_FILE may be
-    shared by ranks of DIFFERENT launchers (a second torchrun, ssh sessions): only the nonce the launchers export
-    (PLSA_LAUNCH_NONCE / TORCHELASTIC_RUN_ID) can be compared -- without one any well-formed file is accepted, so
-    an explicit path must be fresh for each launch (rank 0 removes what it finds there before publishing)."""
-    if os.environ.get("PLSA_COMM_ID_FILE") and path == os.environ["PLSA_COMM_ID_FILE"]:
-        nonce = os.environ.get("PLSA_LAUNCH_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
-        tok = "".join(ch if ch.isalnum() else "_" for ch in nonce)[:40]
+    """What the id file must carry for a waiting rank to accept it -- always something only THIS launch knows.
+    A real launcher nonce (PLSA_LAUNCH_NONCE, a non-static TORCHELASTIC_RUN_ID) on an explicit PLSA_COMM_ID_FILE is
+    compared alone: the ranks may belong to different launchers (a second torchrun, ssh sessions) that share nothing
+    else.  In every other case -- the default path, or an explicit path without a nonce (plain
+    `torchrun --nproc_per_node=N`: TORCHELASTIC_RUN_ID is the constant 'none') -- the ranks are children of ONE
+    launcher and the full launch token (nonce + parent pid + parent start time) is compared, so a file a crashed launch
+    left behind is never accepted (round 4 accepted any well-formed file there).  Ranks of different launchers on an
+    explicit path therefore need PLSA_LAUNCH_NONCE; a waiting rank says so when it sees a foreign token."""
+    nonce = _launcher_nonce()
+    if nonce and os.environ.get("PLSA_COMM_ID_FILE") and path == os.environ["PLSA_COMM_ID_FILE"]:
+        tok = nonce
     else:
         tok = launch_token()
     return tok.encode()[:TOKEN_BYTES].ljust(TOKEN_BYTES, b"\0")
@@ -388,7 +345,7 @@ def rendezvous_id(rank, path=None, timeout=600.0):
     """Rank 0 creates the RCCL unique id and publishes it atomically (after removing whatever an earlier, crashed
     launch left at that path; the file is private to the user) as  magic | launch token | 128 id bytes;  the
     others wait for a file that carries THEIR launch's token -- a stale id would otherwise be read before rank 0
-    replaces it and ncclCommInitRank would hang.  No clock is compared."""
+    replaces it and ncclCommInitRank would hang.  No clock is compared (`_rendezvous_token`)."""
     from . import _lib
     path = path or default_id_file()
     _STATE["id_file"] = path
@@ -413,6 +370,7 @@ def rendezvous_id(rank, path=None, timeout=600.0):
     t0 = time.time()
     want = len(ID_MAGIC) + TOKEN_BYTES + ID_BYTES
     seen = "no file"
+    hinted = False
     while True:
         try:
             with open(path, "rb") as f:
@@ -420,7 +378,12 @@ def rendezvous_id(rank, path=None, timeout=600.0):
             if len(data) == want and data.startswith(ID_MAGIC):
                 if data[len(ID_MAGIC):len(ID_MAGIC) + TOKEN_BYTES] == token:
                     return data[-ID_BYTES:]
-                seen = "a file of another launch (token mismatch)"
+                seen = ("a file of another launch (token mismatch: a stale file rank 0 has not replaced yet, or ranks "
+                        "started by different launchers -- those must share PLSA_LAUNCH_NONCE)")
+                if not hinted and time.time() - t0 > 10.0:
+                    hinted = True
+                    sys.stderr.write("[enstop_amd rank %d] still waiting for this launch's RCCL id at %s; saw %s\n"
+                                     % (rank, path, seen))
             else:
                 seen = "a malformed / half-written file (%d bytes)" % len(data)
         except FileNotFoundError:

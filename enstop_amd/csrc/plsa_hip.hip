@@ -38,12 +38,13 @@ thread_local std::string g_err;  // errors before a context exists
 
 // Ensemble members of a small corpus are fitted concurrently on several contexts of ONE device (two streams each).  The
 // HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES = 4 hardware queues by default, and streams that
-// share a queue run in submission order: a member's 1.9 ms single-workgroup initialisation chain then stalls another
-// member's EM kernels (20NG shape, four contexts: 7.0 -> 6.5 ms per member at engine level, 7 060 -> 7 770 ... 8 500
-// fits/min through ensemble_of_topics; single fits unchanged).  The runtime reads the variable at its first API call, so
-// a default set when this library is loaded is in time unless the host process has used HIP before; a value set by the
-// user is never overwritten.
-__attribute__((constructor)) void plsa_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+// share a queue run in submission order: a member's initialisation chain then stalls another member's EM kernels (20NG
+// shape, four contexts: 7 060 -> 7 770 ... 8 500 fits/min through ensemble_of_topics; single fits unchanged).  Rounds 3-4
+// set GPU_MAX_HW_QUEUES=8 from a constructor of this library; a drop-in must not edit its host's environment behind its
+// back, so since round 5 the LIBRARY never does: enstop_amd/_lib.py (the Python host layer) sets it before loading the
+// library unless ENSTOP_AMD_HW_QUEUES=0, and a C host that wants concurrent members calls
+// setenv("GPU_MAX_HW_QUEUES", "8", 0) itself before its first HIP call.  plsa_hw_queues() reports what
+// this process runs with.
 
 struct DevBuf {
     void *p = nullptr;
@@ -157,8 +158,9 @@ struct plsa_ctx {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     bool sharded = false;            // PLSA_SHARDED fit in progress: accumulators / likelihoods are all-reduced
-    bool sw_resident = false;   // plsa_set_sample_weight: c->sw holds weights that apply whenever a call passes sw = NULL
-    i64 sw_n = 0;
+    bool sw_resident = false;   // plsa_set_sample_weight: sw_res holds weights that apply whenever a call passes sw = NULL
+    i64 sw_n = 0;               // (their own buffer: a call that passes explicit weights stages them in c->sw and leaves these alone)
+    DevBuf sw_res;
     DevBuf comm_send, comm_recv, comm_small, comm_stack;   // comm_stack: the member stack (plsa_stack_reserve)
     float *comm_host = nullptr;      // pinned landing buffer of plsa_comm_allgather_stack
     size_t comm_host_cap = 0;
@@ -658,7 +660,7 @@ int upload_sw(plsa_ctx *c, const float *sw, const float **d_sw) {
         if (c->sw_resident) {
             if (c->sw_n != c->n) return fail(c, "resident sample weights were set for %lld documents, the active matrix has %lld",
                                               (long long)c->sw_n, (long long)c->n);
-            *d_sw = c->sw.as<float>();
+            *d_sw = c->sw_res.as<float>();
         }
         return 0;
     }
@@ -1220,7 +1222,7 @@ void plsa_destroy(plsa_ctx *c) {
     DevBuf *all[] = {&c->b_indptr, &c->b_col, &c->b_val, &c->a_indptr, &c->a_col, &c->a_val, &c->rowidx,
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->U[2], &c->Vt[0], &c->Vt[1], &c->Vt[2], &c->Vacc,
-                     &c->P, &c->sw, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
+                     &c->P, &c->sw, &c->sw_res, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
                      &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp};
     for (DevBuf *b : all) release(*b);
     for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -1240,6 +1242,11 @@ int plsa_synchronize(plsa_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
+}
+
+int plsa_hw_queues(void) {
+    const char *s = getenv("GPU_MAX_HW_QUEUES");
+    return s && atoi(s) > 0 ? atoi(s) : 4;           // 4: the HIP runtime's default
 }
 
 int plsa_device_info(plsa_ctx *c, char *name64, char *arch64, int *cus, int64_t *hbm_bytes) {
@@ -1266,7 +1273,23 @@ int plsa_upload_csr(plsa_ctx *c, const int32_t *indptr, const int32_t *indices, 
         HIPCHK(c, hipMemcpyAsync(c->b_col.p, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->b_val.p, data, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
     }
+    // the header's contract, checked on the device (the arrays are there now; one streaming pass): a violation is a
+    // status code for the caller, not a GPU fault three calls later
+    CHK(ensure(c, c->tmp2, 16));
+    int bad = 0;
+    HIPCHK(c, hipMemsetAsync(c->tmp2.p, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(plsa::k_validate_csr, dim3(grid_for(c, std::max<i64>(n, nnz), 256)), dim3(256), 0, c->stream,
+                       c->b_indptr.as<int>(), c->b_col.as<int>(), (i64)n, (i64)m, (i64)nnz, c->tmp2.as<int>());
+    CHK(launch_check(c, "k_validate_csr"));
+    HIPCHK(c, hipMemcpyAsync(&bad, c->tmp2.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bad) {
+        c->bn = c->bm = c->bnnz = 0;                   // nothing usable is resident
+        c->n = c->m = c->nnz = 0;
+        c->active_is_base = true;
+        return fail(c, "plsa_upload_csr: %s%s%s", (bad & 1) ? "indptr is not non-decreasing within [0, nnz]" : "",
+                    bad == 3 ? "; " : "", (bad & 2) ? "column index outside [0, m)" : "");
+    }
     c->bn = n; c->bm = m; c->bnnz = nnz;
     c->active_is_base = true;
     set_active_pointers(c);
@@ -1450,7 +1473,7 @@ static int mt_init(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/, const f
     CHK(ensure(c, fin, sizeof(unsigned) * 640 + sizeof(double) * 1024));
     if (levels) CHK(ensure(c, gp, sizeof(unsigned) * polys.size()));
     if (!V_host && !c->mt_chain && m <= ((i64)1 << 22))     // chunk sums (u64), parity pairs (2 x u64) and binade guesses (int) of the topic marginals
-        CHK(ensure(c, c->mt_seq, (size_t)k * (size_t)((m + plsa::MT_SEQ_L - 1) / plsa::MT_SEQ_L) * (3 * sizeof(plsa::u64) + sizeof(int))));
+        CHK(ensure(c, c->mt_seq, (size_t)k * (size_t)((m + plsa::MT_SEQ_L - 1) / plsa::MT_SEQ_L) * (3 * sizeof(plsa::u64) + sizeof(int) + sizeof(double))));
     hipError_t e = hipMemsetAsync(st.p, 0, sizeof(unsigned) * 624 * (size_t)streams_p2, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(st.p, state_io, sizeof(unsigned) * 624, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && levels)
@@ -1477,19 +1500,18 @@ static int mt_init(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/, const f
             // V[k, m] in the reference layout (words are consumed in that order), then the layout transpose
             float *Vtmp = reinterpret_cast<float *>(c->Vt[1].p);     // [m*kp] floats >= k*m: free scratch here
             double *marg = reinterpret_cast<double *>(fin.as<unsigned>() + 632) ;   // k <= 1024 doubles behind the state
-            // (k_mt_chunk_pairs sums the chunk sums in front of its tile on its own: quadratic in m / 4096, nothing up to
-            //  millions of words; beyond 2^22 words per topic the plain chain is used)
-            if (c->mt_chain || m > ((i64)1 << 22)) {       // PLSA_MT_CHAIN=1: the plain chain of m dependent adds per topic (A/B, tests)
+            if (c->mt_chain) {       // PLSA_MT_CHAIN=1: the plain chain of m dependent adds per topic (A/B, tests)
                 hipLaunchKernelGGL(plsa::k_mt_marginal_v, dim3((unsigned)k), dim3(64), 0, c->stream, words.as<unsigned>(), k, (int)m, marg);
             } else {                 // the same roundings from per-chunk parity pairs (plsa_kernels.hpp: k_mt_chunk_pairs)
                 const int nch = (int)((m + plsa::MT_SEQ_L - 1) / plsa::MT_SEQ_L);
                 const size_t per = (size_t)k * nch;
                 plsa::u64 *csum = c->mt_seq.as<plsa::u64>(), *pairs = csum + per;
-                int *guess = reinterpret_cast<int *>(pairs + 2 * per);
+                double *tsum = reinterpret_cast<double *>(pairs + 2 * per);          // [k][tiles] <= per doubles
+                int *guess = reinterpret_cast<int *>(tsum + per);
                 const dim3 tiles((unsigned)((nch + plsa::MT_SEQ_L - 1) / plsa::MT_SEQ_L), (unsigned)k);
-                hipLaunchKernelGGL(plsa::k_mt_chunk_sums, tiles, dim3(64), 0, c->stream, words.as<unsigned>(), (int)m, nch, csum);
+                hipLaunchKernelGGL(plsa::k_mt_chunk_sums, tiles, dim3(64), 0, c->stream, words.as<unsigned>(), (int)m, nch, csum, tsum);
                 hipLaunchKernelGGL(plsa::k_mt_chunk_pairs, tiles, dim3(64), 0, c->stream, words.as<unsigned>(), (int)m, nch,
-                                   csum, pairs, guess);
+                                   csum, tsum, pairs, guess);
                 hipLaunchKernelGGL(plsa::k_mt_marginal_walk, dim3((unsigned)k), dim3(64), 0, c->stream, words.as<unsigned>(),
                                    (int)m, nch, pairs, guess, marg);
             }
@@ -1967,8 +1989,9 @@ int plsa_set_sample_weight(plsa_ctx *c, const float *sw) {
     c->sw_resident = false;
     if (!sw) return 0;
     if (c->n <= 0) return fail(c, "plsa_set_sample_weight: no matrix uploaded");
-    const float *unused = nullptr;
-    CHK(upload_sw(c, sw, &unused));          // copies and waits: `sw` may be freed on return
+    CHK(ensure(c, c->sw_res, sizeof(float) * (size_t)c->n));
+    HIPCHK(c, hipMemcpyAsync(c->sw_res.p, sw, sizeof(float) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // `sw` may be freed on return
     c->sw_resident = true;
     c->sw_n = c->n;
     return 0;
@@ -2195,8 +2218,10 @@ int plsa_release_scratch(plsa_ctx *c) {
     release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly); release(c->mt_seq);
     // member stack + gather buffers of the ensemble exchange (16 runs x 64 topics x 100 k words = 0.4 GB): re-created
     // by the next plsa_stack_reserve / plsa_comm_allgather_stack
+    // The page-locked landing buffer of plsa_comm_allgather_stack (c->comm_host) is NOT freed here: the caller may still
+    // hold the pointer that call returned (a NumPy view in enstop_amd: gather_stack(view=True)); it lives until the next
+    // gather that needs a larger one, or plsa_destroy.
     release(c->comm_stack); release(c->comm_recv); release(c->comm_send);
-    if (c->comm_host) { (void)hipHostFree(c->comm_host); c->comm_host = nullptr; c->comm_host_cap = 0; }
     c->p_valid = false;
     c->p_shift = 0;
     return 0;
@@ -2420,11 +2445,13 @@ int plsa_host_mt19937_jump(uint32_t *key, int32_t log2_blocks) {
 // Synthetic corpus in HBM (see plsa_synth.hpp).  The mean token count per document is calibrated
 // by a short secant iteration so that the number of DISTINCT (doc, word) pairs lands within 0.5 %
 // of nnz_target; the final matrix depends only on the arguments.
-int plsa_generate_synthetic(plsa_ctx *c, int64_t n, int64_t m, int64_t nnz_target, double zipf_s,
-                            uint64_t seed, int64_t *nnz_out) {
+static int generate_synthetic_impl(plsa_ctx *c, int64_t n, int64_t m, int64_t nnz_target, double zipf_s,
+                                   uint64_t seed, int k0, double alpha, double background, int64_t *nnz_out) {
     HIPCHK(c, hipSetDevice(c->device));
     if (n <= 0 || m <= 1 || nnz_target < n || n >= INT32_MAX || m >= INT32_MAX)
         return fail(c, "plsa_generate_synthetic: bad arguments (need nnz_target >= n, m > 1)");
+    if (k0 < 0 || k0 > 256 || (k0 > 0 && (!(alpha > 0.0) || background < 0.0 || background > 1.0)))
+        return fail(c, "plsa_generate_synthetic_topics: need 1 <= k0 <= 256, alpha > 0, 0 <= background <= 1");
     // Zipf CDF over ranks (host, float64) and an affine permutation rank -> word id
     std::vector<double> cdf((size_t)m);
     double tot = 0.0;
@@ -2435,9 +2462,22 @@ int plsa_generate_synthetic(plsa_ctx *c, int64_t n, int64_t m, int64_t nnz_targe
     auto gcd = [](uint64_t x, uint64_t y) { while (y) { uint64_t t = x % y; x = y; y = t; } return x; };
     while (gcd(a, (uint64_t)m) != 1) a += 2;
     const uint64_t b = plsa::mix64(seed ^ 0xABCDEFull) % (uint64_t)m;
-    DevBuf d_cdf, d_tok, d_ptr, d_keys, d_keys2, d_flag, d_pos;
+    // topical corpus: one affine ranking per latent topic (odd multipliers spread by the hash, made coprime with m),
+    // the shared ranking above in slot k0
+    std::vector<uint64_t> perm;
+    if (k0 > 0) {
+        perm.resize(2 * (size_t)(k0 + 1));
+        for (int t = 0; t < k0; ++t) {
+            uint64_t at = (plsa::mix64(seed ^ plsa::mix64(0x70C1Cull + (uint64_t)t)) % (uint64_t)m) | 1ull;
+            while (gcd(at, (uint64_t)m) != 1) at += 2;
+            perm[2 * (size_t)t] = at % (uint64_t)m ? at % (uint64_t)m : 1;
+            perm[2 * (size_t)t + 1] = plsa::mix64(seed ^ plsa::mix64(0xB0FF5E7ull + (uint64_t)t)) % (uint64_t)m;
+        }
+        perm[2 * (size_t)k0] = a; perm[2 * (size_t)k0 + 1] = b;
+    }
+    DevBuf d_cdf, d_tok, d_ptr, d_keys, d_keys2, d_flag, d_pos, d_perm;
     auto cleanup = [&]() { release(d_cdf); release(d_tok); release(d_ptr); release(d_keys);
-                           release(d_keys2); release(d_flag); release(d_pos); };
+                           release(d_keys2); release(d_flag); release(d_pos); release(d_perm); };
 #define SYN(expr) do { int r_ = (expr); if (r_) { cleanup(); return r_; } } while (0)
 #define SYNHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); \
         return fail(c, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
@@ -2445,6 +2485,10 @@ int plsa_generate_synthetic(plsa_ctx *c, int64_t n, int64_t m, int64_t nnz_targe
     SYNHIP(hipMemcpyAsync(d_cdf.p, cdf.data(), sizeof(double) * (size_t)m, hipMemcpyHostToDevice, c->stream));
     SYN(ensure(c, d_tok, sizeof(int) * (size_t)(n + 1)));
     SYN(ensure(c, d_ptr, sizeof(i64) * (size_t)(n + 1)));
+    if (k0 > 0) {
+        SYN(ensure(c, d_perm, sizeof(uint64_t) * perm.size()));
+        SYNHIP(hipMemcpyAsync(d_perm.p, perm.data(), sizeof(uint64_t) * perm.size(), hipMemcpyHostToDevice, c->stream));
+    }
     const double sigma = 0.6;
     double mean_tokens = 1.4 * (double)nnz_target / (double)n;
     i64 T = 0;
@@ -2469,8 +2513,13 @@ int plsa_generate_synthetic(plsa_ctx *c, int64_t n, int64_t m, int64_t nnz_targe
         SYN(ensure(c, d_keys2, sizeof(unsigned long long) * (size_t)T));
         SYN(ensure(c, d_flag, sizeof(int) * (size_t)T));
         SYN(ensure(c, d_pos, sizeof(int) * (size_t)T));
-        hipLaunchKernelGGL(plsa::k_synth_draw, dim3(grid_for(c, n, 4)), dim3(256), 0, c->stream, (int)n, (int)m,
-                           d_ptr.as<i64>(), d_cdf.as<double>(), a, b, seed, d_keys.as<unsigned long long>());
+        if (k0 > 0)
+            hipLaunchKernelGGL(plsa::k_synth_draw_topics, dim3(grid_for(c, n, 4)), dim3(256), 0, c->stream, (int)n, (int)m,
+                               d_ptr.as<i64>(), d_cdf.as<double>(), d_perm.as<uint64_t>(), k0, alpha, background, seed,
+                               d_keys.as<unsigned long long>());
+        else
+            hipLaunchKernelGGL(plsa::k_synth_draw, dim3(grid_for(c, n, 4)), dim3(256), 0, c->stream, (int)n, (int)m,
+                               d_ptr.as<i64>(), d_cdf.as<double>(), a, b, seed, d_keys.as<unsigned long long>());
         {
             size_t bytes = 0;
             SYNHIP(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, d_keys.as<unsigned long long>(),
@@ -2513,6 +2562,17 @@ int plsa_generate_synthetic(plsa_ctx *c, int64_t n, int64_t m, int64_t nnz_targe
     set_active_pointers(c);
     if (nnz_out) *nnz_out = nnz;
     return 0;
+}
+
+int plsa_generate_synthetic(plsa_ctx *c, int64_t n, int64_t m, int64_t nnz_target, double zipf_s,
+                            uint64_t seed, int64_t *nnz_out) {
+    return generate_synthetic_impl(c, n, m, nnz_target, zipf_s, seed, 0, 0.0, 0.0, nnz_out);
+}
+
+int plsa_generate_synthetic_topics(plsa_ctx *c, int64_t n, int64_t m, int64_t nnz_target, double zipf_s,
+                                   uint64_t seed, int32_t k0, double alpha, double background, int64_t *nnz_out) {
+    if (k0 < 1) return fail(c, "plsa_generate_synthetic_topics: need 1 <= k0 <= 256");
+    return generate_synthetic_impl(c, n, m, nnz_target, zipf_s, seed, k0, alpha, background, nnz_out);
 }
 
 }  // extern "C"

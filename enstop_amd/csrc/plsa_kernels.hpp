@@ -1095,6 +1095,24 @@ __global__ void k_vt_to_v(const float *__restrict__ Vt, float *__restrict__ V, i
     }
 }
 
+// plsa_upload_csr: the contract of include/plsa_hip.h ("indices must be < m, indptr non-decreasing") checked where the
+// data already is -- one streaming pass over indptr and indices; bad |= 1 row pointers out of order / out of [0, nnz],
+// bad |= 2 column index outside [0, m).  (The Python layer raises ValueError for the same; a C caller gets a status.)
+__global__ void k_validate_csr(const int *__restrict__ indptr, const int *__restrict__ indices, i64 n, i64 m, i64 nnz,
+                               int *__restrict__ bad) {
+    int b = 0;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int a = indptr[i], e = indptr[i + 1];
+        if (a > e || a < 0 || (i64)e > nnz) b |= 1;
+    }
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += stride) {
+        const int w = indices[j];
+        if (w < 0 || (i64)w >= m) b |= 2;
+    }
+    if (b) atomicOr(bad, b);
+}
+
 // bootstrap (enstop_.py:87-88): out row i := base row idx[i]
 __global__ void k_boot_lengths(const int *__restrict__ base_indptr, const i64 *__restrict__ idx,
                                i64 n_out, i64 n_base, int *__restrict__ lens, int *__restrict__ bad) {
@@ -1429,9 +1447,10 @@ __device__ __forceinline__ void mt_load_tile(const unsigned *__restrict__ words,
     __syncthreads();
 }
 
-// exact integer sum of every chunk (< 2^59): grid (ceil(nch / 64), k), 64 threads
+// exact integer sum of every chunk (< 2^59) and the approximate (float64) sum of every tile of 64 chunks:
+// grid (ceil(nch / 64), k), 64 threads
 __global__ __launch_bounds__(64) void k_mt_chunk_sums(const unsigned *__restrict__ words, int m, int nch,
-                                                      u64 *__restrict__ csum) {
+                                                      u64 *__restrict__ csum, double *__restrict__ tsum) {
     __shared__ u64 tile[MT_SEQ_L][MT_SEQ_L + 1];
     const int z = blockIdx.y, lane = threadIdx.x;
     const i64 c0 = (i64)blockIdx.x * MT_SEQ_L;
@@ -1440,21 +1459,27 @@ __global__ __launch_bounds__(64) void k_mt_chunk_sums(const unsigned *__restrict
 #pragma unroll 8
     for (int j = 0; j < MT_SEQ_L; ++j) t += tile[lane][j];
     if (c0 + lane < nch) csum[(i64)z * nch + c0 + lane] = t;
+    double tt = (c0 + lane < nch) ? (double)t : 0.0;
+    for (int o = 32; o > 0; o >>= 1) tt += __shfl_xor(tt, o, 64);
+    if (lane == 0) tsum[(i64)z * gridDim.x + blockIdx.x] = tt;
 }
 
 // per chunk: guessed binade e (from the approximate prefix sum of the chunk sums; -1: s < 1 or no guess) and the
 // parity -> increment pair at that binade's granularity.  Same grid.
 __global__ __launch_bounds__(64) void k_mt_chunk_pairs(const unsigned *__restrict__ words, int m, int nch,
-                                                       const u64 *__restrict__ csum, u64 *__restrict__ pairs /*[2]*/,
-                                                       int *__restrict__ guess) {
+                                                       const u64 *__restrict__ csum, const double *__restrict__ tsum,
+                                                       u64 *__restrict__ pairs /*[2]*/, int *__restrict__ guess) {
     __shared__ u64 tile[MT_SEQ_L][MT_SEQ_L + 1];
     __shared__ double pre[MT_SEQ_L];
     const int z = blockIdx.y, lane = threadIdx.x;
     const i64 c0 = (i64)blockIdx.x * MT_SEQ_L;
     const u64 *cs = csum + (i64)z * nch;
-    // approximate real prefix at this tile's first chunk, then at each of its chunks (any summation order will do)
+    // approximate real prefix at this tile's first chunk -- the sums of the TILES in front of it (k_mt_chunk_sums; one
+    // value per 4096 draws: linear in m per topic where summing the chunk sums was quadratic) -- then at each of its
+    // chunks (any summation order will do: the walk checks every guess)
     double before = 0.0;
-    for (i64 c = lane; c < c0; c += 64) before += (double)cs[c];
+    const double *ts = tsum + (i64)z * gridDim.x;
+    for (int t = lane; t < (int)blockIdx.x; t += 64) before += ts[t];
     for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
     pre[lane] = (c0 + lane < nch) ? (double)cs[c0 + lane] : 0.0;
     mt_load_tile(words, (i64)z * m, m, c0, tile);     // (synchronises)

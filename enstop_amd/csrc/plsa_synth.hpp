@@ -5,6 +5,14 @@
 // the CSR stores the multiplicity of every distinct (doc, word) pair as a float32 count.  The
 // matrix is a pure function of (n, m, tokens-per-doc mean, s, seed): counter-based hashing, no
 // generator state, identical on every device.
+//
+// Round 5 -- TOPICAL variant (k_synth_draw_topics): the corpus above draws every token independently, so no two
+// words co-occur more often than chance and nothing about it resembles text (20-Newsgroups, the reference's
+// only corpus, notebooks/EnsTop with 20-Newsgroups.ipynb:49).  Here document d first draws a topic mixture
+// theta_d ~ Dirichlet(alpha) over k0 latent topics (gamma variates by Marsaglia-Tsang from the counter-based
+// hash), every topic owns its OWN Zipf(s) ranking of the vocabulary (an affine permutation per topic), and a
+// token is: with probability `background` a draw from the shared ranking (function words), otherwise topic
+// t ~ theta_d and a word from topic t's ranking -- the generative model pLSA itself assumes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -54,6 +62,83 @@ __global__ void k_synth_draw(int n, int m, const long long *__restrict__ tok_ptr
             const uint64_t word = (perm_a * (uint64_t)lo + perm_b) % (uint64_t)m;
             keys[t] = ((unsigned long long)d << 32) | (unsigned long long)word;
         }
+    }
+}
+
+// one gamma(shape, 1) variate, shape >= 1 (Marsaglia & Tsang 2000), from the hash stream (key, 0), (key, 1), ...
+__device__ __forceinline__ double gamma_mt(double shape, uint64_t key) {
+    const double dd = shape - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * dd);
+    for (uint64_t j = 0; j < 64; ++j) {
+        const uint64_t h1 = mix64(key ^ mix64(3 * j + 1)), h2 = mix64(key ^ mix64(3 * j + 2)),
+                       h3 = mix64(key ^ mix64(3 * j + 3));
+        const double x = sqrt(-2.0 * log(u01(h1))) * cos(6.283185307179586 * u01(h2));
+        double v = 1.0 + cc * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        if (log(u01(h3)) < 0.5 * x * x + dd - dd * v + dd * log(v)) return dd * v;
+    }
+    return dd;      // (never reached in practice: acceptance > 95 % per round)
+}
+
+// one wave per document, four documents per workgroup.  Topic mixture: g_t = gamma(alpha + 1) * u^(1/alpha)
+// (= gamma(alpha) for any alpha > 0), normalised -> cumulative theta in LDS; tokens as described in the header.
+// perm[2*t], perm[2*t+1]: the affine ranking (a * rank + b) mod m of topic t; t == k0 is the shared ranking.
+__global__ void k_synth_draw_topics(int n, int m, const long long *__restrict__ tok_ptr,
+                                    const double *__restrict__ cdf, const uint64_t *__restrict__ perm, int k0,
+                                    double alpha, double background, uint64_t seed,
+                                    unsigned long long *__restrict__ keys) {
+    __shared__ double tcdf[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (long long base = (long long)blockIdx.x * 4; base < n; base += (long long)gridDim.x * 4) {
+        const long long d = base + w;
+        if (d < n) {
+            for (int t = lane; t < k0; t += 64) {
+                const uint64_t key = mix64(seed ^ 0x7091C5ull ^ mix64((uint64_t)d * 1024ull + (uint64_t)t));
+                const double g = gamma_mt(alpha + 1.0, key) * pow(u01(mix64(key ^ 0xA5A5A5A5ull)), 1.0 / alpha);
+                tcdf[w][t] = g;
+            }
+        }
+        __syncthreads();
+        if (d < n && lane == 0) {
+            double tot = 0.0;
+            for (int t = 0; t < k0; ++t) { tot += tcdf[w][t]; tcdf[w][t] = tot; }
+            // a document whose every gamma underflowed (alpha tiny) falls back to one hashed topic
+            if (!(tot > 0.0)) {
+                const int t1 = (int)(mix64(seed ^ (uint64_t)d) % (uint64_t)k0);
+                for (int t = 0; t < k0; ++t) tcdf[w][t] = t >= t1 ? 1.0 : 0.0;
+                tot = 1.0;
+            }
+            const double inv = 1.0 / tot;
+            for (int t = 0; t < k0; ++t) tcdf[w][t] *= inv;
+            tcdf[w][k0 - 1] = 1.0;
+        }
+        __syncthreads();
+        if (d < n) {
+            const long long t0 = tok_ptr[d], t1 = tok_ptr[d + 1];
+            for (long long t = t0 + lane; t < t1; t += 64) {
+                const uint64_t ht = mix64((uint64_t)t * 0x9E3779B97F4A7C15ull + 0x5851F42D4C957F2Dull);
+                const double u = u01(mix64(seed ^ ht));
+                const double ub = u01(mix64(seed ^ ht ^ 0xB5297A4D3F84D5B5ull));
+                int topic = k0;                                   // shared ranking
+                if (ub >= background) {
+                    const double ut = u01(mix64(seed ^ ht ^ 0x68E31DA4C2B2AE35ull));
+                    int lo = 0, hi = k0 - 1;                      // first topic with tcdf >= ut
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (tcdf[w][mid] < ut) lo = mid + 1; else hi = mid;
+                    }
+                    topic = lo;
+                }
+                int lo = 0, hi = m - 1;                           // first rank with cdf[rank] >= u
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (cdf[mid] < u) lo = mid + 1; else hi = mid;
+                }
+                const uint64_t word = (perm[2 * topic] * (uint64_t)lo + perm[2 * topic + 1]) % (uint64_t)m;
+                keys[t] = ((unsigned long long)d << 32) | (unsigned long long)word;
+            }
+        }
+        __syncthreads();                                           // tcdf is rewritten by the next four documents
     }
 }
 

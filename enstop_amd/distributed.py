@@ -2,8 +2,8 @@
 members' topic matrices are brought together by ONE all-gather -- the np.vstack over thread results of
 enstop/enstop_.py:231.  No collective sits on the EM data path: members are independent.
 
-The exchange itself lives in `comm.py` (RCCL through the C ABI by default; a caller-initialised
-torch.distributed group is honoured).  Typical use under a launcher that sets RANK / WORLD_SIZE /
+The exchange itself lives in `comm.py`: RCCL through the C ABI (or a communicator the caller installed with
+`comm.install`); nothing else in the process is consulted.  Typical use under a launcher that sets RANK / WORLD_SIZE /
 LOCAL_RANK (torchrun, or `python bench.py --gpus N`):
 
     import enstop_amd

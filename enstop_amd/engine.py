@@ -105,9 +105,16 @@ class Engine:
         self.base_rows = n
         return self
 
-    def generate_synthetic(self, n, m, nnz, zipf_s=1.07, seed=0):
+    def generate_synthetic(self, n, m, nnz, zipf_s=1.07, seed=0, topics=0, alpha=0.1, background=0.25):
+        """Synthetic bag-of-words corpus generated in HBM (becomes base + active matrix); returns the exact nnz.
+        topics = 0: every token an independent Zipf draw.  topics = k0 > 0: documents are Dirichlet(alpha) mixtures
+        of k0 latent topics with their own Zipf rankings plus a shared `background` ranking (text-like co-occurrence)."""
         out = C.c_int64(0)
-        self._ok(self._L.plsa_generate_synthetic(self._h, n, m, nnz, float(zipf_s), int(seed), C.byref(out)))
+        if topics:
+            self._ok(self._L.plsa_generate_synthetic_topics(self._h, n, m, nnz, float(zipf_s), int(seed), int(topics),
+                                                            float(alpha), float(background), C.byref(out)))
+        else:
+            self._ok(self._L.plsa_generate_synthetic(self._h, n, m, nnz, float(zipf_s), int(seed), C.byref(out)))
         self.base_rows = n
         return out.value
 

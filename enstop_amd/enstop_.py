@@ -157,9 +157,10 @@ def _ensemble_of_plsa_topics(X, k, n_jobs=4, n_runs=16, parallelism="dask", **kw
       "none"            members run serially on this process' GPU sharing `random_state` exactly
                         like the reference's serial branch (enstop_.py:220-223).
       "dask" / "joblib" accepted for drop-in compatibility; the thread fan-out they name is
-                        replaced by the one-GPU-per-process model: with torch.distributed
-                        initialised (torchrun) run r executes on rank r % world_size and the stack
-                        is all-gathered over RCCL.  `n_jobs`: members fitted CONCURRENTLY on this
+                        replaced by the one-GPU-per-process model: after
+                        `enstop_amd.distributed.init()` under a launcher that sets RANK / WORLD_SIZE
+                        (torchrun, `bench.py --gpus N`) run r executes on rank r % world_size and
+                        the stack is all-gathered over RCCL.  `n_jobs`: members fitted CONCURRENTLY on this
                         process' GPU (at most 4 contexts, and 1 once a single fit fills the GPU:
                         nnz * k >= 2e9); the stack does not depend on it.
     Per-run streams: with an int (or None) `random_state` run r uses seed `random_state + r`

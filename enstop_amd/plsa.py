@@ -493,8 +493,8 @@ class DistributedPLSA(BlockParallelPLSA):
     """Drop-in name for enstop.distributed_plsa.DistributedPLSA (distributed_plsa.py:374-460).  The
     reference takes a dask array and sums per-tile partial factors with a dask graph
     (distributed_plsa.py:99-131).  Here the distribution unit is the GPU: with a communicator of more than
-    one rank in force (`enstop_amd.distributed.init()`: RCCL through the C ABI, one process per GPU; or a
-    caller's torch.distributed group), every rank passes the same X and the documents are sharded over the
+    one rank in force (`enstop_amd.distributed.init()`: RCCL through the C ABI, one process per GPU; or one the
+    caller installed with `comm.install`), every rank passes the same X and the documents are sharded over the
     ranks -- one all-reduce of the P(w|z) accumulator per EM iteration (`sharded_plsa_fit`, DESIGN.md section
     6) -- and every rank receives the full result; in a single process it is `BlockParallelPLSA`.  Like the
     reference's loop (distributed_plsa.py:277-278, 450) it never sees sample weights and its stop test has

@@ -12,7 +12,7 @@ one-pass-late decision as the single-GPU fused driver.
 The loop is three ABI calls per iteration (`plsa_em_accumulate`, `plsa_allreduce_accumulator` -- RCCL on the
 engine's stream -- or any external all-reduce of the buffer `plsa_accumulator_device` exposes,
 `plsa_em_finish`), driven by `sharded_em` below; that form runs on the RCCL communicator (`distributed.init()`),
-on a caller's torch.distributed group, and inside one process over several engines on one device (tests: N
+on any communicator the caller installs (`comm.install`), and inside one process over several engines on one device (tests: N
 shards without N GPUs).  The same loop also exists entirely inside the C ABI -- `plsa_fit(..., PLSA_SHARDED)`:
 every collective of the communicator on the context's one stream, no host synchronisation between likelihood
 tests -- behind ENSTOP_AMD_SHARDED_INLOOP=1: opt-in until a run on two real GPUs has compared it with the
@@ -64,7 +64,7 @@ class LocalComm:
 
 class RankComm:
     """One shard per process: the exchanges go through the communicator in force (comm.current():
-    RCCL through the C ABI, or the caller's torch.distributed group)."""
+    RCCL through the C ABI, or one the caller installed)."""
 
     def __init__(self, comm):
         self.comm = comm
@@ -127,7 +127,7 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
                      tolerance=0.001, e_step_thresh=1e-32, random_state=None, device=None,
                      local_shards=None, return_info=False, flags=None, zero_arm=True):
     """pLSA fit of X with the documents sharded over the ranks of the communicator in force (one process
-    per GPU; `distributed.init()` or a torch.distributed group) or, when `local_shards` is given, over
+    per GPU; `distributed.init()` or `comm.install`) or, when `local_shards` is given, over
     that many engines of this process (single-GPU emulation used by the tests).  Every rank passes the
     same X and arguments; returns the full (P(z|d), P(w|z)) on every rank.  Same initial factors as
     `plsa_fit` for the same seed.

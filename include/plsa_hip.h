@@ -50,11 +50,13 @@ enum {
 
 /* ---- lifetime / errors -----------------------------------------------------------------------
  * Several contexts may live on one device (the reference's thread pool of ensemble members, enstop_.py:209-217: one
- * context per thread).  Loading the library sets GPU_MAX_HW_QUEUES=8 in the process environment UNLESS the variable is
- * already set: the HIP runtime otherwise multiplexes every stream of the process onto 4 hardware queues and members that
- * share a queue run in submission order (20NG shape, four contexts: +10 % ensemble throughput with 8).  It takes effect
- * when the process has not called HIP before the library is loaded. */
+ * context per thread).  The HIP runtime multiplexes every stream of a process onto GPU_MAX_HW_QUEUES (default 4) hardware
+ * queues and members that share a queue run in submission order (20NG shape, four contexts: +10 % ensemble throughput with
+ * 8).  The library does NOT touch the environment (rounds 3-4 did, from a constructor): a host that fits members
+ * concurrently sets GPU_MAX_HW_QUEUES=8 itself before its first HIP call -- enstop_amd/_lib.py does so unless
+ * ENSTOP_AMD_HW_QUEUES=0 or the variable is already set; plsa_hw_queues() returns the value this process runs with. */
 int plsa_device_count(int *count);
+int plsa_hw_queues(void);
 int plsa_create(int device, plsa_ctx **out);
 void plsa_destroy(plsa_ctx *ctx);
 /* ctx may be NULL: returns the last error of a failed plsa_create()/plsa_device_count(). */
@@ -66,7 +68,9 @@ int plsa_device_info(plsa_ctx *ctx, char *name64, char *arch64, int *cus, int64_
 /* ---- corpus ------------------------------------------------------------------------------------
  * plsa_upload_csr: the doc-term matrix X, replaces `A = X.tocoo().astype(np.float32)`
  *   (enstop/plsa.py:714, 975).  The uploaded matrix becomes both the *base* corpus and the *active*
- *   matrix the EM kernels iterate over.  indices must be < m, indptr non-decreasing.
+ *   matrix the EM kernels iterate over.  indices must be in [0, m), indptr non-decreasing from 0 to nnz: checked on
+ *   the device after the copy (one streaming pass); a violation returns a non-zero status and leaves NO corpus
+ *   resident (later calls answer "no corpus uploaded").
  * plsa_bootstrap: active := base[idx, :] gathered on the device; replaces
  *   `B = A[bootstrap_sample_indices]` (enstop/enstop_.py:87-88).  idx == NULL restores active := base.
  * plsa_active_shape / plsa_download_active_csr: read back the active matrix (tests).           */
@@ -180,7 +184,8 @@ int plsa_accumulator_set(plsa_ctx *ctx, const float *host);
  *                         ncclAllGather launch on the context's stream, then one copy into a page-locked host
  *                         buffer owned by the context.  Run r of the ensemble is fitted by rank r % world in
  *                         slot r / world, so *host is the stack in run order, [slots * world][k][m] (valid until
- *                         the next call on ctx).  Without a communicator: the local stack.
+ *                         the next plsa_comm_allgather_stack on ctx or plsa_destroy; plsa_release_scratch keeps
+ *                         it).  Without a communicator: the local stack.
  *   plsa_allreduce_accumulator       in-place ncclAllReduce(sum) of the un-normalised P(w|z) accumulator,
  *                         stream-ordered between plsa_em_accumulate and plsa_em_finish; plsa_fit with
  *                         PLSA_SHARDED issues the same call itself -- every collective of a communicator goes on
@@ -223,8 +228,9 @@ int plsa_placement_info(plsa_ctx *ctx, int32_t *candidates, double *best_gbps, d
 int plsa_schedule_info(plsa_ctx *ctx, int32_t *xcd_lo /*[9]*/, double *xcd_end_us /*[8]*/, int32_t *timed_launches,
                        int32_t *item_len, int64_t *n_items);
 
-/* frees the large scratch buffers (materialised P, column-pass partials, the ensemble member stack and its gather
- * buffers); they are re-created on demand */
+/* frees the large scratch buffers (materialised P, column-pass partials, the ensemble member stack and its DEVICE gather
+ * buffers); they are re-created on demand.  The page-locked host buffer whose address plsa_comm_allgather_stack handed
+ * out stays valid. */
 int plsa_release_scratch(plsa_ctx *ctx);
 
 /* ---- measurement --------------------------------------------------------------------------------
@@ -275,6 +281,13 @@ int plsa_host_mt19937_jump(uint32_t *key /*[624]*/, int32_t log2_blocks);
  * becomes base + active matrix.  nnz_target is approximate; the exact nnz is returned.            */
 int plsa_generate_synthetic(plsa_ctx *ctx, int64_t n, int64_t m, int64_t nnz_target, double zipf_s,
                             uint64_t seed, int64_t *nnz_out);
+/* the same with TOPICAL structure (round 5; the corpus above draws every token independently -- no co-occurrence, unlike
+ * text such as the reference's 20-Newsgroups, notebooks/EnsTop with 20-Newsgroups.ipynb:49): document d draws a topic
+ * mixture theta_d ~ Dirichlet(alpha) over k0 latent topics, every topic has its own Zipf(s) ranking of the vocabulary,
+ * a token comes from the shared ranking with probability `background` and otherwise from topic t ~ theta_d: the
+ * generative model pLSA assumes.  1 <= k0 <= 256, alpha > 0, 0 <= background <= 1; deterministic in all arguments. */
+int plsa_generate_synthetic_topics(plsa_ctx *ctx, int64_t n, int64_t m, int64_t nnz_target, double zipf_s,
+                                   uint64_t seed, int32_t k0, double alpha, double background, int64_t *nnz_out);
 
 #ifdef __cplusplus
 }

@@ -268,8 +268,11 @@ int oracle_refit_inner(const int32_t *rows, const int32_t *cols, const float *va
 }
 
 /* ---------------------------------------------------------------------------------------------------
- * enstop/streamed_plsa.py -- the block-streamed loops (checker arithmetic only: float32 everywhere,
- * whatever the build's acc_t / norm_t; pinned bit for bit by tests/golden/stream*.npz).
+ * enstop/streamed_plsa.py -- the block-streamed loops.  The checker build is float32 everywhere and pinned
+ * bit for bit by tests/golden/stream*.npz.  The FIT loop also honours the diagnostic builds (round 5:
+ * norm_pwz in norm_t, and under ORACLE_WIDE_FACTORS the P(w|z) / P(z|d) sums and norm_pdz in float64
+ * side buffers) so that BASELINE config 5 -- whose nnz x k array cannot exist on any host -- has an
+ * exact-arithmetic comparison; the refit loop stays float32.
  * ------------------------------------------------------------------------------------------------- */
 
 /* streamed_plsa.py:102-119  plsa_e_step_on_a_block: P block row (nz - block_start) */
@@ -290,9 +293,10 @@ static void streamed_e_block(const int32_t *rows, const int32_t *cols, const flo
 }
 
 /* streamed_plsa.py:204-219 (plsa_partial_m_step_on_a_block), :304-320 (..._w_sample_weight; sw != NULL),
- * :774-785 (plsa_partial_refit_m_step_on_a_block; nV == NULL) */
-static void streamed_m_block(const int32_t *rows, const int32_t *cols, const float *vals, float *nV, float *nU,
-                             const float *Pb, const float *sw, float *norm_pwz, float *norm_pdz,
+ * (the refit variant :774-785 follows below).  In the checker build acc_t = norm_t = float and
+ * nV / nU / norm_pdz ARE the reference's float32 arrays. */
+static void streamed_m_block(const int32_t *rows, const int32_t *cols, const float *vals, acc_t *nV, acc_t *nU,
+                             const float *Pb, const float *sw, norm_t *norm_pwz, acc_t *norm_pdz,
                              int64_t b0, int64_t b1, int64_t m, int64_t k) {
     for (int64_t nz = b0; nz < b1; nz++) {
         const int64_t d = rows[nz], w = cols[nz];
@@ -317,12 +321,15 @@ int oracle_streamed_fit_inner(const int32_t *rows, const int32_t *cols, const fl
                               float thresh, int32_t use_sample_weights, float *ll_trace, int32_t *n_ll,
                               int32_t *iters) {
     float *Pb = (float *)calloc((size_t)(block_size * k) + 1, sizeof(float));      /* :543 */
-    float *norm_pwz = (float *)calloc((size_t)k + 1, sizeof(float));
-    float *norm_pdz = (float *)calloc((size_t)n + 1, sizeof(float));
+    norm_t *norm_pwz = (norm_t *)calloc((size_t)k + 1, sizeof(norm_t));
+    acc_t *norm_pdz = (acc_t *)calloc((size_t)n + 1, sizeof(acc_t));
     float *bufV = (float *)calloc((size_t)(k * m) + 1, sizeof(float));             /* :552-553 */
     float *bufU = (float *)calloc((size_t)(n * k) + 1, sizeof(float));
-    if (!Pb || !norm_pwz || !norm_pdz || !bufV || !bufU) {
-        free(Pb); free(norm_pwz); free(norm_pdz); free(bufV); free(bufU); return -1;
+    /* diagnostic wide build only: float64 sums beside the float32 "next" factors */
+    acc_t *wV = ORACLE_WIDE_ACC ? (acc_t *)calloc((size_t)(k * m) + 1, sizeof(acc_t)) : NULL;
+    acc_t *wU = ORACLE_WIDE_ACC ? (acc_t *)calloc((size_t)(n * k) + 1, sizeof(acc_t)) : NULL;
+    if (!Pb || !norm_pwz || !norm_pdz || !bufV || !bufU || (ORACLE_WIDE_ACC && (!wV || !wU))) {
+        free(Pb); free(norm_pwz); free(norm_pdz); free(bufV); free(bufU); free(wV); free(wU); return -1;
     }
     float *pV = V, *pU = U, *nV = bufV, *nU = bufU;
     int32_t nll = 0, it = 0;
@@ -331,20 +338,33 @@ int oracle_streamed_fit_inner(const int32_t *rows, const int32_t *cols, const fl
     nll++;
     const int64_t n_blocks = nnz / block_size + 1;
     for (int32_t i = 0; i < n_iter; i++) {
-        memset(norm_pdz, 0, sizeof(float) * (size_t)n);                             /* :345-346 */
-        memset(norm_pwz, 0, sizeof(float) * (size_t)k);
+        memset(norm_pdz, 0, sizeof(acc_t) * (size_t)n);                             /* :345-346 */
+        memset(norm_pwz, 0, sizeof(norm_t) * (size_t)k);
+        acc_t *aV = ORACLE_WIDE_ACC ? wV : (acc_t *)(void *)nV;
+        acc_t *aU = ORACLE_WIDE_ACC ? wU : (acc_t *)(void *)nU;
+        if (ORACLE_WIDE_ACC) {
+            memset(wV, 0, sizeof(acc_t) * (size_t)(k * m));
+            memset(wU, 0, sizeof(acc_t) * (size_t)(n * k));
+        }
         for (int64_t b = 0; b < n_blocks; b++) {
             const int64_t b0 = b * block_size;
             const int64_t b1 = nnz < b0 + block_size ? nnz : b0 + block_size;
             streamed_e_block(rows, cols, pV, pU, Pb, b0, b1, m, k, thresh);
-            streamed_m_block(rows, cols, vals, nV, nU, Pb, use_sample_weights ? sw : NULL, norm_pwz, norm_pdz,
+            streamed_m_block(rows, cols, vals, aV, aU, Pb, use_sample_weights ? sw : NULL, norm_pwz, norm_pdz,
                              b0, b1, m, k);
         }
         for (int64_t z = 0; z < k; z++) {                                           /* :378-384 */
-            if (norm_pwz[z] > 0.0f)
-                for (int64_t w = 0; w < m; w++) nV[z * m + w] /= norm_pwz[z];
-            for (int64_t d = 0; d < n; d++)
-                if (norm_pdz[d] > 0.0f) nU[d * k + z] /= norm_pdz[d];
+            if (ORACLE_WIDE_ACC) {
+                for (int64_t w = 0; w < m; w++)
+                    nV[z * m + w] = (float)(norm_pwz[z] > 0 ? aV[z * m + w] / norm_pwz[z] : aV[z * m + w]);
+                for (int64_t d = 0; d < n; d++)
+                    nU[d * k + z] = (float)(norm_pdz[d] > 0 ? aU[d * k + z] / norm_pdz[d] : aU[d * k + z]);
+            } else {
+                if (norm_pwz[z] > 0)
+                    for (int64_t w = 0; w < m; w++) nV[z * m + w] = (float)(nV[z * m + w] / norm_pwz[z]);
+                for (int64_t d = 0; d < n; d++)
+                    if (norm_pdz[d] > 0) nU[d * k + z] = (float)(nU[d * k + z] / norm_pdz[d]);
+            }
         }
         memset(pV, 0, sizeof(float) * (size_t)(k * m));                             /* :388-389 */
         memset(pU, 0, sizeof(float) * (size_t)(n * k));
@@ -363,8 +383,23 @@ int oracle_streamed_fit_inner(const int32_t *rows, const int32_t *cols, const fl
     if (pU != U) memcpy(U, pU, sizeof(float) * (size_t)(n * k));
     if (n_ll) *n_ll = nll;
     if (iters) *iters = it;
-    free(Pb); free(norm_pwz); free(norm_pdz); free(bufV); free(bufU);
+    free(Pb); free(norm_pwz); free(norm_pdz); free(bufV); free(bufU); free(wV); free(wU);
     return 0;
+}
+
+/* streamed_plsa.py:774-785  plsa_partial_refit_m_step_on_a_block: float32 in every build */
+static void streamed_refit_m_block(const int32_t *rows, const float *vals, float *nU, const float *Pb,
+                                   float *norm_pdz, int64_t b0, int64_t b1, int64_t k) {
+    for (int64_t nz = b0; nz < b1; nz++) {
+        const int64_t d = rows[nz];
+        const float x = vals[nz];
+        const float *p = Pb + (nz - b0) * k;
+        for (int64_t z = 0; z < k; z++) {
+            float s = x * p[z];
+            nU[d * k + z] += s;
+            norm_pdz[d] += s;
+        }
+    }
 }
 
 /* streamed_plsa.py:851-956  plsa_refit_inner_blockwise with :788-847 (plsa_refit_em_step) inlined.  The caller's
@@ -391,7 +426,7 @@ int oracle_streamed_refit_inner(const int32_t *rows, const int32_t *cols, const 
             const int64_t b0 = b * block_size;
             const int64_t b1 = nnz < b0 + block_size ? nnz : b0 + block_size;
             streamed_e_block(rows, cols, topics, pU, Pb, b0, b1, m, k, 1e-32f);
-            streamed_m_block(rows, cols, vals, NULL, nU, Pb, NULL, NULL, norm_pdz, b0, b1, m, k);
+            streamed_refit_m_block(rows, vals, nU, Pb, norm_pdz, b0, b1, k);
         }
         for (int64_t z = 0; z < k; z++)
             for (int64_t d = 0; d < n; d++)

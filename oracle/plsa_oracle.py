@@ -194,6 +194,25 @@ class Oracle:
                                      n_iter, n_iter_per_test, tolerance, e_step_thresh,
                                      return_trace=return_trace)
 
+    # -- enstop/streamed_plsa.py:469-603 plsa_fit_inner_blockwise on caller-held factors (V, U mutated in place) ---
+    def streamed_plsa_fit_inner(self, X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, sample_weight,
+                                block_size=65536, n_iter=100, n_iter_per_test=10, tolerance=0.001,
+                                e_step_thresh=1e-32, use_sample_weights=False, return_trace=False):
+        k, m = p_w_given_z.shape
+        n = p_z_given_d.shape[0]
+        trace = np.zeros(n_iter + 2, np.float32)
+        nll, iters = C.c_int32(0), C.c_int32(0)
+        rc = self.lib.oracle_streamed_fit_inner(X_rows, X_cols, X_vals, X_vals.shape[0], p_w_given_z, p_z_given_d,
+                                                sample_weight, n, m, k, int(block_size), n_iter, n_iter_per_test,
+                                                float(tolerance), np.float32(e_step_thresh),
+                                                int(bool(use_sample_weights)), trace.ctypes.data, C.byref(nll),
+                                                C.byref(iters))
+        if rc:
+            raise MemoryError("oracle_streamed_fit_inner")
+        if return_trace:
+            return p_z_given_d, p_w_given_z, trace[: nll.value].copy(), iters.value
+        return p_z_given_d, p_w_given_z
+
     # -- enstop/streamed_plsa.py: plsa_fit (:606-699) and plsa_refit (:959-1039) -----------------
     def streamed_plsa_fit(self, X, k, sample_weight, init="random", block_size=65536, n_iter=100,
                           n_iter_per_test=10, tolerance=0.001, e_step_thresh=1e-32, random_state=None,

@@ -45,18 +45,29 @@ def test_library_has_gfx950_code_object():
     assert b"gfx950" in data and b"k_e_step" in data and b"k_row_pass" in data
 
 
-def test_library_load_sets_a_default_hardware_queue_count_and_respects_the_users():
-    """libplsa_hip.so asks the HIP runtime for 8 hardware queues when it is loaded (concurrent ensemble members on one
-    device must not serialise on the default 4) -- unless GPU_MAX_HW_QUEUES is already set."""
+def test_python_loader_sets_a_default_hardware_queue_count_the_library_itself_never_does():
+    """enstop_amd/_lib.py asks the HIP runtime for 8 hardware queues before it loads the library (concurrent ensemble
+    members on one device must not serialise on the default 4) -- unless GPU_MAX_HW_QUEUES is already set or the user
+    opted out with ENSTOP_AMD_HW_QUEUES=0.  Loading libplsa_hip.so by itself (a C host) leaves the environment alone
+    (rounds 3-4 set the variable from a constructor of the library)."""
     import subprocess
     import sys
-    code = ("import ctypes, os, sys; sys.path.insert(0, %r); from enstop_amd import _lib; _lib.load(); "
-            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
-            "print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())" % ROOT)
-    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "8"
-    env["GPU_MAX_HW_QUEUES"] = "2"
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "2"
+    probe = ("libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; v = libc.getenv(b'GPU_MAX_HW_QUEUES'); "
+             "print(v.decode() if v else 'unset')")
+    code = ("import ctypes, os, sys; sys.path.insert(0, %r); from enstop_amd import _lib; _lib.load(); " % ROOT) + probe + \
+           "; print(_lib.hw_queues()['set_by'], _lib.hw_queues()['value'])"
+    raw = ("import ctypes; L = ctypes.CDLL(%r); " % os.path.join(ROOT, "enstop_amd", "libplsa_hip.so")) + probe + \
+          "; print(L.plsa_hw_queues())"
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "ENSTOP_AMD_HW_QUEUES")}
+
+    def run(c, e):
+        return subprocess.run([sys.executable, "-c", c], env=e, capture_output=True, text=True).stdout.split()
+
+    assert run(code, env) == ["8", "enstop_amd", "8"]
+    assert run(code, dict(env, GPU_MAX_HW_QUEUES="2")) == ["2", "user", "2"]
+    assert run(code, dict(env, ENSTOP_AMD_HW_QUEUES="0")) == ["unset", "opt-out", "4"]
+    assert run(code, dict(env, ENSTOP_AMD_HW_QUEUES="6")) == ["6", "enstop_amd", "6"]
+    assert run(raw, env) == ["unset", "4"]
 
 
 def test_no_cpu_fallback_without_device():

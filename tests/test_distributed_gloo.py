@@ -1,6 +1,7 @@
 """N > 1 plumbing on CPU: world_size-2 processes exercise the run -> rank dealing and the all-gather
 that rebuilds the np.vstack order of enstop_.py:231, once over a torch.distributed gloo group
-(comm.TorchComm) and once over the host-file test double (comm.FileComm).  The product communicator
+(tests/torch_comm.py: test scaffolding the worker installs explicitly -- the product never looks for torch) and once
+over the host-file test double (comm.FileComm).  The product communicator
 (comm.RcclComm, RCCL through the C ABI) implements the same interface and is covered by the GPU tests;
 its rendezvous (a file carrying the RCCL unique id) is exercised here for the waiting ranks."""
 import os
@@ -19,8 +20,13 @@ WORKER = textwrap.dedent("""
     import numpy as np
     import torch.distributed as dist
     sys.path.insert(0, os.environ["REPO_ROOT"])
-    from enstop_amd import distributed
+    sys.path.insert(0, os.path.join(os.environ["REPO_ROOT"], "tests"))
+    from enstop_amd import comm, distributed
     dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    assert distributed.rank_world() == (0, 1)        # an initialised process group alone changes nothing in the product
+    assert "torch" in sys.modules and comm.current().name == "single"
+    from torch_comm import TorchComm
+    comm.install(TorchComm())
     rank, world = distributed.rank_world()
     assert (rank, world) == (int(os.environ["RANK"]), 2)
     n_runs, k, m = int(os.environ["N_RUNS"]), 3, 7
@@ -188,17 +194,31 @@ def test_stale_rendezvous_file_is_ignored(tmp_path, monkeypatch):
 
 
 def test_explicit_id_file_shared_by_two_launchers(tmp_path, monkeypatch):
-    """PLSA_COMM_ID_FILE shared by ranks whose parents differ (a second torchrun, ssh sessions): the parent pid is
-    not part of the token there -- only the nonce the launchers export is compared (none: any well-formed file)."""
+    """PLSA_COMM_ID_FILE shared by ranks whose parents differ (a second torchrun, ssh sessions): with a launcher nonce
+    the parent pid is not part of the token -- only the nonce is compared.  WITHOUT a nonce (plain
+    `torchrun --nproc_per_node=N`: TORCHELASTIC_RUN_ID is the constant 'none') the token never degenerates to "any
+    well-formed file" (ADVICE r04): the ranks are children of one launcher and the full launch token applies, so an id
+    a crashed launch left at the explicit path is refused."""
     from enstop_amd import comm
     path = str(tmp_path / "shared.id")
     monkeypatch.setenv("PLSA_COMM_ID_FILE", path)
     monkeypatch.delenv("PLSA_LAUNCH_NONCE", raising=False)
+    for static_id in (None, "none"):
+        if static_id is None:
+            monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+        else:
+            monkeypatch.setenv("TORCHELASTIC_RUN_ID", static_id)
+        tok = comm._rendezvous_token(path)
+        assert tok == comm.launch_token().encode().ljust(comm.TOKEN_BYTES, b"\0") and str(os.getppid()).encode() in tok
+        stale = b"x_1_1".ljust(comm.TOKEN_BYTES, b"\0")                       # what another (dead) launcher wrote there
+        _publish(comm, path, bytes([9]) * 128, token=stale, delay=0)
+        with pytest.raises(TimeoutError, match="token mismatch"):
+            comm.rendezvous_id(1, path, timeout=0.3)
+        _publish(comm, path, bytes(range(128)), delay=0)
+        assert comm.rendezvous_id(1, path, timeout=1) == bytes(range(128))
     monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
-    assert comm._rendezvous_token(path) == b"".ljust(comm.TOKEN_BYTES, b"\0")
-    _publish(comm, path, bytes(range(128)), delay=0)
-    assert comm.rendezvous_id(1, path, timeout=1) == bytes(range(128))
     monkeypatch.setenv("PLSA_LAUNCH_NONCE", "job7")
+    assert comm._rendezvous_token(path) == b"job7".ljust(comm.TOKEN_BYTES, b"\0")
     with pytest.raises(TimeoutError, match="token mismatch"):          # written without the nonce: another launch
         comm.rendezvous_id(1, path, timeout=0.3)
     _publish(comm, path, bytes(range(128)), delay=0)

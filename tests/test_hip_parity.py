@@ -893,9 +893,13 @@ def test_sharded_fit_two_ranks_sharing_one_gpu(tmp_path):
         import numpy as np, scipy.sparse as sp
         import torch, torch.distributed as dist
         sys.path.insert(0, os.environ["REPO_ROOT"])
+        sys.path.insert(0, os.path.join(os.environ["REPO_ROOT"], "tests"))
         rank = int(os.environ["RANK"])
         dist.init_process_group("gloo", rank=rank, world_size=2)
         import enstop_amd
+        from torch_comm import TorchComm                    # test scaffolding: the product never selects it by itself
+        assert enstop_amd.comm.current().world == 1
+        enstop_amd.comm.install(TorchComm())
         rs = np.random.RandomState(0)
         X = sp.random(2500, 1500, density=0.02, format="csr", random_state=rs, dtype=np.float32)
         X.data = np.ceil(X.data * 5).astype(np.float32)
