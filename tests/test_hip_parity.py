@@ -585,6 +585,40 @@ def test_full_size_properties(amd, cfg):
         close_factors(Uf, Um, tol=2e-5); close_factors(Vf, Vm, tol=2e-5)
 
 
+def test_topical_generator_is_deterministic_and_has_cooccurrence_structure(amd):
+    """plsa_generate_synthetic_topics (round 5): same arguments -> the same matrix, bit for bit; a different seed, topic
+    count or concentration -> another one; and, unlike the independent-token corpus, documents share words in CLUSTERS:
+    the word overlap of random document pairs is bimodal (same dominant topic: large, otherwise only the shared
+    ranking's head words), so its coefficient of variation is several times that of the independent corpus."""
+    n, m, target = 4000, 3000, 200_000
+    kw = dict(topics=16, alpha=0.05, background=0.1)
+    with amd.Engine() as eng:
+        nnz = eng.generate_synthetic(n, m, target, seed=11, **kw)
+        A = eng.download_active_csr()
+        assert abs(nnz - target) / target < 0.02 and A.nnz == nnz and A.shape == (n, m)
+        assert A.has_sorted_indices and A.data.min() >= 1 and np.diff(A.indptr).min() >= 1
+        assert eng.generate_synthetic(n, m, target, seed=11, **kw) == nnz
+        B = eng.download_active_csr()
+        assert (A != B).nnz == 0 and np.array_equal(A.data, B.data)
+        for other in (dict(kw, topics=17), dict(kw, alpha=0.5), dict(kw, background=0.5)):
+            eng.generate_synthetic(n, m, target, seed=11, **other)
+            assert (eng.download_active_csr() != A).nnz > 0
+        eng.generate_synthetic(n, m, target, seed=12, **kw)
+        assert (eng.download_active_csr() != A).nnz > 0
+        eng.generate_synthetic(n, m, target, seed=11)
+        I = eng.download_active_csr()
+        with pytest.raises(amd.DeviceError):
+            eng.generate_synthetic(n, m, target, seed=11, topics=300)
+
+    def overlap_cv(X):
+        Xb = (X[:600] > 0).astype(np.float64)
+        S = np.asarray((Xb @ Xb.T).todense())
+        off = S[~np.eye(600, dtype=bool)]
+        return off.std() / off.mean()
+    cv_t, cv_i = overlap_cv(A), overlap_cv(I)
+    assert cv_t > 2.5 * cv_i, (cv_t, cv_i)
+
+
 def test_count_scaling_invariance(amd):
     """X -> 2X leaves every EM iterate bit-identical (all norms scale by an exact power of two)
     and doubles the log-likelihood."""
@@ -1111,6 +1145,37 @@ def test_c_abi_from_plain_c(tmp_path):
                            "-l:libplsa_hip.so", "-Wl,-rpath," + os.path.join(ROOT, "enstop_amd"), "-lm", "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "c-abi ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_upload_contract_is_checked_on_the_device(amd):
+    """include/plsa_hip.h: "indices must be in [0, m), indptr non-decreasing from 0 to nnz".  Straight through the C ABI
+    (the Python layer's own ValueError check bypassed): a violation is a non-zero status with a message, nothing stays
+    resident, and the context works again with a valid matrix."""
+    import ctypes as C
+    X = _corpus(300, 200, 0.05, seed=77)
+    n, m = X.shape
+    ip, ix, dt = X.indptr.astype(np.int32), X.indices.astype(np.int32), X.data.astype(np.float32)
+    with amd.Engine() as eng:
+        L, h = eng._L, eng._h
+        bad = ix.copy(); bad[len(bad) // 3] = m
+        assert L.plsa_upload_csr(h, ip, bad, dt, n, m, len(dt)) != 0
+        assert "column index" in L.plsa_last_error(h).decode()
+        bad[len(bad) // 3] = -5
+        assert L.plsa_upload_csr(h, ip, bad, dt, n, m, len(dt)) != 0
+        bp = ip.copy(); bp[7] = bp[8] + 3                      # indptr steps back between rows 7 and 8
+        assert L.plsa_upload_csr(h, bp, ix, dt, n, m, len(dt)) != 0
+        assert "indptr" in L.plsa_last_error(h).decode()
+        bp = ip.copy(); bp[n // 2] = len(dt) + 9               # beyond nnz (and decreasing afterwards)
+        assert L.plsa_upload_csr(h, bp, ix, dt, n, m, len(dt)) != 0
+        assert eng.shape[0] == 0
+        with pytest.raises(amd.DeviceError, match="corpus"):
+            eng.set_factors(np.ones((n, 4), np.float32) / 4, np.ones((4, m), np.float32) / m)
+        with pytest.raises(ValueError):                        # the Python layer answers the same input before any copy
+            eng.upload_csr(sp.csr_matrix((dt, bad, ip), shape=(n, m)))
+        eng.upload_csr(X)                                      # ... and the context is fine
+        eng.set_factors(np.ones((n, 4), np.float32) / 4, np.ones((4, m), np.float32) / m)
+        iters, _ = eng.fit(None, n_iter=2, n_iter_per_test=1, tolerance=0.0)
+        assert iters == 2
 
 
 def test_thread_pool_callers_are_serialised(amd):

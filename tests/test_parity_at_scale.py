@@ -1,14 +1,23 @@
-"""HIP path against the CPU oracle AT THE BASELINE.json CONFIGURATIONS (needs a real MI355X: -m gpu).
+"""HIP path against the CPU oracle AT THE BASELINE.json CONFIGURATIONS, at the sizes AND iteration counts BASELINE.json
+states (needs a real MI355X: -m gpu).  What is compared with what (round 5):
 
-  config 1  20NG-shaped synthetic CSR 18 846 x 173 762, 2.95 M nnz, k = 20   fit, both schedules, 5 iterations
-  config 2  synthetic CSR 100 k x 50 k, 10 M nnz, k = 32                      fit, both schedules, 3 iterations
-  config 4  ensemble_of_topics(n_runs = 32) on the config-1 corpus            stack == serial members (bitwise),
-                                                                              one member against the oracle
-  config 5  5 M x 200 k, 500 M nnz, k = 128                                   size-independent properties
-  config 3  its shape on the first 150 000 documents (15 M nnz, k = 64)              fit, both schedules, 2 iterations
-            (the full corpus: test_hip_parity.py::test_full_size_properties and bench.py)
+  config 1  20NG-shaped synthetic CSR 18 846 x 173 762, 2.95 M nnz, k = 20
+            * 50 iterations (BASELINE: "50 EM iters"), tolerance 0, both schedules vs strict / n64 / wide      [asserted]
+            * the DEFAULT tolerance 1e-3 (PLSA(): n_iter 100, test every 10): the iteration the fit stops at, HIP (both
+              schedules) == n64 == wide [asserted]; strict on 1 thread and on N threads [recorded: the reference's float32
+              log-likelihood carries an error larger than the tolerance there]
+            * the reference's OWN output, 2 iterations (tests/golden/fit_cfg1_shape.npz)                        [asserted]
+  config 2  synthetic CSR 100 k x 50 k, 10 M nnz, k = 32       3 iterations, both schedules vs strict / n64 / wide
+  config 3  1 M x 100 k, 100 M nnz, k = 64: the WHOLE corpus, 2 iterations, both schedules vs n64               [asserted]
+            (the first 150 000 documents vs strict / wide stay as the quick check)
+  config 4  ensemble_of_topics(n_runs = 32) on the config-1 corpus: stack == serial members (bitwise), one member vs oracle
+  config 5  5 M x 200 k, 500 M nnz, k = 128: the first 500 000 documents (50 M nnz, full vocabulary) vs the
+            block-streamed oracle (enstop/streamed_plsa.py's loop: no nnz x k array) in n64 / wide arithmetic  [asserted];
+            the full size through size-independent properties
+  long run  a topical corpus (plsa_generate_synthetic_topics), k = 20, 150 iterations: P(z|d) entries really fall below
+            e_step_thresh and become exact zeros; the zero PATTERN of P(z|d) and P(w|z) vs the oracle           [asserted]
 
-The corpora are produced by the engine's deterministic generator (plsa_generate_synthetic) and
+The corpora are produced by the engine's deterministic generator (plsa_generate_synthetic[_topics]) and
 downloaded for the oracle.  Every comparison is made against three builds of the one oracle source:
 
   strict  the reference's arithmetic: every accumulator float32, M-step scatter sequential
@@ -20,10 +29,7 @@ downloaded for the oracle.  Every comparison is made against three builds of the
 Asserted: HIP == wide and HIP == n64 inside the north-star tolerances (factors 1e-4 of the largest entry,
 log-likelihood 1e-5 relative; measured ~1e-6), and HIP's distance to strict is no larger than strict's
 own distance to wide (i.e. the gap IS the reference's rounding, not a defect of the port).
-Every figure is written to gpurun_out/r04_parity_at_scale.json (copied to profiles/ by hand).
-
-Round 4: `test_cfg1_reference_run` compares with the REFERENCE'S OWN output at config 1's exact shape
-(tests/golden/fit_cfg1_shape.npz, generated by running enstop/plsa.py on the downloaded corpus).
+Every figure is written to gpurun_out/r05_parity_at_scale.json (copied to profiles/ by hand).
 """
 import json
 import os
@@ -46,7 +52,7 @@ CONFIG2 = dict(n=100_000, m=50_000, nnz=10_000_000, k=32)
 def _flush_report():
     try:
         os.makedirs(REPORT_DIR, exist_ok=True)
-        with open(os.path.join(REPORT_DIR, "r04_parity_at_scale.json"), "w") as f:
+        with open(os.path.join(REPORT_DIR, "r05_parity_at_scale.json"), "w") as f:
             json.dump(REPORT, f, indent=1, sort_keys=True)
     except OSError:
         pass
@@ -187,7 +193,48 @@ def _fit_case(amd, oracles, cfg, name, n_iter, n_iter_per_test):
 
 
 def test_config1_fit_vs_oracle(amd, oracles):
-    _fit_case(amd, oracles, CONFIG1, "config1", n_iter=5, n_iter_per_test=2)
+    """BASELINE configs[0]: "PLSA(n_components=20), 50 EM iters" -- all fifty, likelihood test every 10 (the default)."""
+    _fit_case(amd, oracles, CONFIG1, "config1_50_iterations", n_iter=50, n_iter_per_test=10)
+
+
+def test_config1_default_tolerance_stops_where_the_oracle_stops(amd, oracles):
+    """The user-visible behaviour of a default `PLSA(n_components=20).fit(X)` at config 1: n_iter = 100, a likelihood
+    test every 10 iterations, tolerance 1e-3 (plsa.py:1074-1084, 630-638).  The iteration the fit stops at must be the
+    one the algorithm stops at in accurate arithmetic (n64, wide); the float32 reference arithmetic is RECORDED on one
+    thread (numba without parallel reductions) and on N threads (prange partial sums): its log-likelihood error at this
+    size (3e-3 relative on one thread) exceeds the tolerance, so its own stop iteration depends on the thread count."""
+    X = corpus(amd, CONFIG1)
+    n, m = X.shape
+    k = CONFIG1["k"]
+    r, c, v = coo_arrays(X)
+    U0, V0 = host_init(n, m, k, 42)
+    ones = np.ones(n, np.float32)
+    kw = dict(n_iter=100, n_iter_per_test=10, tolerance=1e-3, e_step_thresh=1e-32)
+    rec = REPORT.setdefault("config1_default_tolerance", {"shape": [n, m], "nnz": int(X.nnz), "k": k, **kw})
+    stops, traces = {}, {}
+    for name, variant, threads in (("n64", "n64", oracles["threads"]), ("wide", "wide", oracles["threads"]),
+                                   ("strict_1_thread", "strict", 1),
+                                   ("strict_%d_threads" % oracles["threads"], "strict", oracles["threads"])):
+        o = oracles[variant]
+        o.set_threads(threads)
+        t0 = time.time()
+        _, _, trace, iters = o.plsa_fit_inner(r, c, v, V0.copy(), U0.copy(), ones, return_trace=True, **kw)
+        o.set_threads(oracles["threads"])
+        stops[name], traces[name] = int(iters), [float(x) for x in trace]
+        rec.setdefault("oracle_seconds", {})[name] = round(time.time() - t0, 1)
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        for sched, flags in (("hip_fused", amd.PLSA_FUSED), ("hip_materialised", 0)):
+            eng.set_factors(U0, V0)
+            iters, trace = eng.fit(None, flags=flags, trace=True, **kw)
+            stops[sched], traces[sched] = int(iters), [float(x) for x in trace]
+    rec["stop_iteration"] = stops
+    rec["log_likelihood_traces"] = traces
+    _flush_report()
+    assert stops["hip_fused"] == stops["hip_materialised"] == stops["n64"] == stops["wide"], stops
+    nl = len(traces["n64"])
+    assert len(traces["hip_fused"]) == nl and ll_rel(traces["hip_fused"], traces["n64"]) <= 1e-5
+    assert ll_rel(traces["hip_materialised"][:nl], traces["n64"]) <= 1e-5
 
 
 def test_cfg1_reference_run(amd, oracles):
@@ -275,6 +322,144 @@ def test_config3_shape_row_sample_vs_oracle(amd, oracles):
             s_, w_ = out["vs_strict"], rec["strict_vs_wide"]
             for f in ("U", "V"):
                 assert s_[f]["peak_rel"] <= 1.5 * w_[f]["peak_rel"] + 2e-5, (sched, f, s_[f], w_[f])
+
+
+def test_config3_full_corpus_vs_oracle(amd, oracles):
+    """BASELINE configs[2] WHOLE: 1 M documents x 100 k words, 100 M non-zeros, k = 64 -- two EM iterations of both
+    schedules against the n64 oracle (the reference's algorithm with float64 norm_pwz / log-likelihood sums; its 25.7 GB
+    P(z|w,d) array lives in host memory, ~25 s per iteration on the serial M-step).  This is the asserted config-3 check:
+    a defect above 2^31 bytes / 1e8 entries that both schedules share cannot hide here."""
+    from enstop_amd.engine import reset_engines
+    reset_engines()
+    with amd.Engine() as eng:
+        eng.generate_synthetic(1_000_000, 100_000, 100_000_000, seed=0)
+        X = eng.download_active_csr()
+    n, m = X.shape
+    k = 64
+    r, c, v = coo_arrays(X)
+    U0, V0 = host_init(n, m, k, 42)
+    ones = np.ones(n, np.float32)
+    n_iter = 2
+    rec = REPORT.setdefault("config3_full_corpus", {"shape": [n, m], "nnz": int(X.nnz), "k": k, "n_iter": n_iter,
+                                                    "oracle": "n64", "oracle_threads": oracles["threads"]})
+    t0 = time.time()
+    Uo, Vo = U0.copy(), V0.copy()
+    _, _, tr_o, it_o = oracles["n64"].plsa_fit_inner(r, c, v, Vo, Uo, ones, n_iter=n_iter, n_iter_per_test=1,
+                                                     tolerance=0.0, e_step_thresh=1e-32, return_trace=True)
+    rec["oracle_seconds"] = round(time.time() - t0, 1)
+    del r, c, v
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
+            eng.set_factors(U0, V0)
+            iters, trace = eng.fit(None, n_iter=n_iter, n_iter_per_test=1, tolerance=0.0, e_step_thresh=1e-32,
+                                   flags=flags, trace=True)
+            U, V = eng.get_factors()
+            assert iters == it_o == n_iter
+            e = rec[sched] = {"U": errs(U, Uo), "V": errs(V, Vo), "ll_rel": ll_rel(trace, tr_o),
+                              "U_rowsum_max_dev": float(np.abs(U.sum(axis=1, dtype=np.float64) - 1).max()),
+                              "V_rowsum_max_dev": float(np.abs(V.sum(axis=1, dtype=np.float64) - 1).max())}
+            _flush_report()
+            assert e["U"]["peak_rel"] <= 1e-4 and e["V"]["peak_rel"] <= 1e-4 and e["ll_rel"] <= 1e-5, (sched, e)
+            eng.release_scratch()
+
+
+def test_config5_row_sample_vs_streamed_oracle(amd, oracles):
+    """BASELINE configs[4] (5 M x 200 k, 500 M nnz, k = 128): the first 500 000 documents of that corpus -- 50 M
+    non-zeros over the full 200 k vocabulary -- against the block-streamed oracle (the loop of
+    enstop/streamed_plsa.py:469-603, which never holds an nnz x k array; the config-5 route of the reference's
+    block_parallel / streamed classes) in n64 and wide arithmetic; one EM iteration + both likelihoods, both schedules,
+    the streamed loop's stop rule (PLSA_STOP_NO_ZERO_ARM)."""
+    from enstop_amd.engine import reset_engines
+    reset_engines()
+    with amd.Engine() as eng:
+        eng.generate_synthetic(5_000_000, 200_000, 500_000_000, seed=0)
+        eng.bootstrap(np.arange(500_000, dtype=np.int64))
+        X = eng.download_active_csr()
+    n, m = X.shape
+    k = 128
+    r, c, v = coo_arrays(X)
+    U0, V0 = host_init(n, m, k, 42)
+    ones = np.ones(n, np.float32)
+    rec = REPORT.setdefault("config5_first_500k_docs", {"shape": [n, m], "nnz": int(X.nnz), "k": k, "n_iter": 1,
+                                                        "oracle": "streamed loop, block_size 1048576"})
+    ref = {}
+    for variant in ("n64", "wide"):
+        t0 = time.time()
+        U, V = U0.copy(), V0.copy()
+        _, _, trace, iters = oracles[variant].streamed_plsa_fit_inner(r, c, v, V, U, ones, block_size=1 << 20, n_iter=1,
+                                                                      n_iter_per_test=1, tolerance=0.0,
+                                                                      e_step_thresh=1e-32, return_trace=True)
+        ref[variant] = (U, V, trace, iters)
+        rec.setdefault("oracle_seconds", {})[variant] = round(time.time() - t0, 1)
+    del r, c, v
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
+            eng.set_factors(U0, V0)
+            iters, trace = eng.fit(None, n_iter=1, n_iter_per_test=1, tolerance=0.0, e_step_thresh=1e-32,
+                                   flags=flags | amd.engine.PLSA_STOP_NO_ZERO_ARM, trace=True)
+            U, V = eng.get_factors()
+            out = rec.setdefault(sched, {})
+            for variant in ("n64", "wide"):
+                Uo, Vo, tr_o, it_o = ref[variant]
+                assert iters == it_o == 1
+                out["vs_" + variant] = {"U": errs(U, Uo), "V": errs(V, Vo), "ll_rel": ll_rel(trace, tr_o)}
+            _flush_report()
+            for variant in ("n64", "wide"):
+                e = out["vs_" + variant]
+                assert e["U"]["peak_rel"] <= 1e-4 and e["V"]["peak_rel"] <= 1e-4 and e["ll_rel"] <= 1e-5, (sched, variant, e)
+            eng.release_scratch()
+
+
+def test_long_run_reaches_the_threshold_regime(amd, oracles):
+    """A fit that runs long enough on a corpus WITH topical structure (plsa_generate_synthetic_topics: documents are
+    sparse Dirichlet mixtures of 24 latent topics) for P(z|d) entries to decay below e_step_thresh: every product
+    P(w|z) P(z|d) of such an entry fails `v > thresh` (plsa.py:97-102) and the entry becomes an exact zero, for good.
+    150 iterations, k = 20, default threshold 1e-32.  Asserted: a substantial part of P(z|d) IS exactly zero in the
+    oracle (57 % on a host-made corpus of the same model), and the zero pattern of both factors is the oracle's (strict
+    arithmetic, one thread: the reference's)."""
+    with amd.Engine() as eng:
+        nnz = eng.generate_synthetic(6000, 5000, 360_000, seed=5, topics=24, alpha=0.05, background=0.1)
+        X = eng.download_active_csr()
+    n, m = X.shape
+    k = 20
+    r, c, v = coo_arrays(X)
+    U0, V0 = host_init(n, m, k, 42)
+    ones = np.ones(n, np.float32)
+    kw = dict(n_iter=150, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32)
+    o = oracles["strict"]
+    o.set_threads(1)
+    Uo, Vo = U0.copy(), V0.copy()
+    _, _, tr_o, it_o = o.plsa_fit_inner(r, c, v, Vo, Uo, ones, return_trace=True, **kw)
+    o.set_threads(oracles["threads"])
+    zero_u, zero_v = float((Uo == 0).mean()), float((Vo == 0).mean())
+    rec = REPORT.setdefault("long_run_threshold_regime", {"shape": [n, m], "nnz": int(nnz), "k": k, **kw,
+                                                          "oracle_zero_fraction_U": zero_u, "oracle_zero_fraction_V": zero_v,
+                                                          "oracle_smallest_positive_U": float(Uo[Uo > 0].min())})
+    assert zero_u >= 0.05, "the run never reached the threshold regime: %.4f of P(z|d) is zero" % zero_u
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
+            eng.set_factors(U0, V0)
+            iters, trace = eng.fit(None, flags=flags, trace=True, **kw)
+            U, V = eng.get_factors()
+            assert iters == it_o == 150
+            mism_u, mism_v = int(((U == 0) != (Uo == 0)).sum()), int(((V == 0) != (Vo == 0)).sum())
+            rec[sched] = {"U": errs(U, Uo), "V": errs(V, Vo), "ll_rel": ll_rel(trace, tr_o),
+                          "zero_pattern_mismatches_U": mism_u, "zero_pattern_mismatches_V": mism_v,
+                          "zero_fraction_U": float((U == 0).mean()), "zero_fraction_V": float((V == 0).mean())}
+            _flush_report()
+            # An entry about to die holds ~1e-30; whether its LAST surviving product passes `> 1e-32` in this iteration or
+            # the next can hinge on the 7th digit, which summation order owns (the reference's own prange has the same
+            # freedom).  Such an entry is zero on both sides one iteration later.  Hence: the patterns agree except for at
+            # most 3 entries, and a disagreeing entry is negligible (< 1e-25) on the side where it still lives.
+            assert mism_u <= 3 and mism_v <= 3, (sched, rec[sched])
+            for A, B in ((U, Uo), (V, Vo)):
+                dis = (A == 0) != (B == 0)
+                assert not dis.any() or max(A[dis].max(), B[dis].max()) < 1e-25, (sched, A[dis], B[dis])
+            assert rec[sched]["U"]["peak_rel"] <= 1e-4 and rec[sched]["V"]["peak_rel"] <= 1e-4, (sched, rec[sched])
+            assert rec[sched]["ll_rel"] <= 1e-5, (sched, rec[sched])
 
 
 def test_config4_ensemble_on_20ng_shaped_corpus(amd, oracles):
