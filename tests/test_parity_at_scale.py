@@ -144,6 +144,10 @@ def _fit_case(amd, oracles, cfg, name, n_iter, n_iter_per_test):
                              "ll_rel": ll_rel(ref["strict"][2], ref["wide"][2])}
     rec["strict_vs_n64"] = {"U": errs(ref["strict"][0], ref["n64"][0]), "V": errs(ref["strict"][1], ref["n64"][1]),
                             "ll_rel": ll_rel(ref["strict"][2], ref["n64"][2])}
+    # n64 still adds the P(w|z) / P(z|d) sums themselves in float32, sequentially (plsa.py:190-191): over 50 iterations
+    # at config 1 that alone carries it 1.3e-4 away from exact arithmetic
+    rec["n64_vs_wide"] = {"U": errs(ref["n64"][0], ref["wide"][0]), "V": errs(ref["n64"][1], ref["wide"][1]),
+                          "ll_rel": ll_rel(ref["n64"][2], ref["wide"][2])}
     with amd.Engine() as eng:
         eng.upload_csr(X)
         for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
@@ -157,15 +161,16 @@ def _fit_case(amd, oracles, cfg, name, n_iter, n_iter_per_test):
                 assert iters == it_o == n_iter
                 out["vs_" + variant] = {"U": errs(U, Uo), "V": errs(V, Vo), "ll_rel": ll_rel(trace, tr_o)}
             _flush_report()
-            for variant in ("n64", "wide"):
-                e = out["vs_" + variant]
-                assert e["U"]["peak_rel"] <= 1e-4 and e["V"]["peak_rel"] <= 1e-4, (sched, variant, e)
-                assert e["ll_rel"] <= 1e-5, (sched, variant, e)
-            # distance to the float32 reference arithmetic: bounded by that arithmetic's own error
-            s, w = out["vs_strict"], rec["strict_vs_wide"]
-            for f in ("U", "V"):
-                assert s[f]["peak_rel"] <= 1.5 * w[f]["peak_rel"] + 2e-5, (sched, f, s[f], w[f])
-            assert s["ll_rel"] <= 1.5 * w["ll_rel"] + 1e-5, (sched, s["ll_rel"], w["ll_rel"])
+            e = out["vs_wide"]                   # the north-star tolerances against exact arithmetic
+            assert e["U"]["peak_rel"] <= 1e-4 and e["V"]["peak_rel"] <= 1e-4, (sched, e)
+            assert e["ll_rel"] <= 1e-5, (sched, e)
+            # distance to the float32 arithmetics (the reference's, and n64's float32 factor sums): bounded by each
+            # arithmetic's OWN distance to exact -- at short horizons that bound is itself below 1e-4 for n64
+            for variant in ("strict", "n64"):
+                s_, w = out["vs_" + variant], rec[variant + "_vs_wide"]
+                for f in ("U", "V"):
+                    assert s_[f]["peak_rel"] <= 1.5 * w[f]["peak_rel"] + 2e-5, (sched, variant, f, s_[f], w[f])
+                assert s_["ll_rel"] <= 1.5 * w["ll_rel"] + 1e-5, (sched, variant, s_["ll_rel"], w["ll_rel"])
         # kernel level, one step from the initial factors: norm_pwz and the un-normalised P(w|z)
         eng.set_factors(U0, V0)
         eng.e_step(1e-32, want_host_copy=False)
@@ -326,9 +331,11 @@ def test_config3_shape_row_sample_vs_oracle(amd, oracles):
 
 def test_config3_full_corpus_vs_oracle(amd, oracles):
     """BASELINE configs[2] WHOLE: 1 M documents x 100 k words, 100 M non-zeros, k = 64 -- two EM iterations of both
-    schedules against the n64 oracle (the reference's algorithm with float64 norm_pwz / log-likelihood sums; its 25.7 GB
-    P(z|w,d) array lives in host memory, ~25 s per iteration on the serial M-step).  This is the asserted config-3 check:
-    a defect above 2^31 bytes / 1e8 entries that both schedules share cannot hide here."""
+    schedules against the oracle in n64 arithmetic (the reference's algorithm with float64 norm_pwz / log-likelihood
+    sums) and in exact (wide) arithmetic; its 25.7 GB P(z|w,d) array lives in host memory, ~20 s per iteration on the
+    serial M-step.  This is the asserted config-3 check: a defect above 2^31 bytes / 1e8 entries that both schedules
+    share cannot hide here.  Asserted: within 1e-4 / 1e-5 of exact arithmetic; no further from n64 than n64 is from
+    exact (measured: HIP 9.9e-5 from n64 on P(w|z) -- n64's float32 column sums)."""
     from enstop_amd.engine import reset_engines
     reset_engines()
     with amd.Engine() as eng:
@@ -341,13 +348,19 @@ def test_config3_full_corpus_vs_oracle(amd, oracles):
     ones = np.ones(n, np.float32)
     n_iter = 2
     rec = REPORT.setdefault("config3_full_corpus", {"shape": [n, m], "nnz": int(X.nnz), "k": k, "n_iter": n_iter,
-                                                    "oracle": "n64", "oracle_threads": oracles["threads"]})
-    t0 = time.time()
-    Uo, Vo = U0.copy(), V0.copy()
-    _, _, tr_o, it_o = oracles["n64"].plsa_fit_inner(r, c, v, Vo, Uo, ones, n_iter=n_iter, n_iter_per_test=1,
-                                                     tolerance=0.0, e_step_thresh=1e-32, return_trace=True)
-    rec["oracle_seconds"] = round(time.time() - t0, 1)
+                                                    "oracle_threads": oracles["threads"]})
+    ref = {}
+    for variant in ("n64", "wide"):
+        t0 = time.time()
+        Uo, Vo = U0.copy(), V0.copy()
+        _, _, tr_o, it_o = oracles[variant].plsa_fit_inner(r, c, v, Vo, Uo, ones, n_iter=n_iter, n_iter_per_test=1,
+                                                           tolerance=0.0, e_step_thresh=1e-32, return_trace=True)
+        ref[variant] = (Uo, Vo, tr_o, it_o)
+        rec.setdefault("oracle_seconds", {})[variant] = round(time.time() - t0, 1)
     del r, c, v
+    # n64 adds a head word's column (up to 1 M entries) into ONE float32, sequentially: its own distance to exact
+    rec["n64_vs_wide"] = {"U": errs(ref["n64"][0], ref["wide"][0]), "V": errs(ref["n64"][1], ref["wide"][1]),
+                          "ll_rel": ll_rel(ref["n64"][2], ref["wide"][2])}
     with amd.Engine() as eng:
         eng.upload_csr(X)
         for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
@@ -355,12 +368,19 @@ def test_config3_full_corpus_vs_oracle(amd, oracles):
             iters, trace = eng.fit(None, n_iter=n_iter, n_iter_per_test=1, tolerance=0.0, e_step_thresh=1e-32,
                                    flags=flags, trace=True)
             U, V = eng.get_factors()
-            assert iters == it_o == n_iter
-            e = rec[sched] = {"U": errs(U, Uo), "V": errs(V, Vo), "ll_rel": ll_rel(trace, tr_o),
-                              "U_rowsum_max_dev": float(np.abs(U.sum(axis=1, dtype=np.float64) - 1).max()),
-                              "V_rowsum_max_dev": float(np.abs(V.sum(axis=1, dtype=np.float64) - 1).max())}
+            out = rec.setdefault(sched, {"U_rowsum_max_dev": float(np.abs(U.sum(axis=1, dtype=np.float64) - 1).max()),
+                                         "V_rowsum_max_dev": float(np.abs(V.sum(axis=1, dtype=np.float64) - 1).max())})
+            for variant in ("n64", "wide"):
+                Uo, Vo, tr_o, it_o = ref[variant]
+                assert iters == it_o == n_iter
+                out["vs_" + variant] = {"U": errs(U, Uo), "V": errs(V, Vo), "ll_rel": ll_rel(trace, tr_o)}
             _flush_report()
+            e = out["vs_wide"]
             assert e["U"]["peak_rel"] <= 1e-4 and e["V"]["peak_rel"] <= 1e-4 and e["ll_rel"] <= 1e-5, (sched, e)
+            e, w = out["vs_n64"], rec["n64_vs_wide"]
+            for f in ("U", "V"):
+                assert e[f]["peak_rel"] <= 1.5 * w[f]["peak_rel"] + 2e-5, (sched, f, e[f], w[f])
+            assert e["ll_rel"] <= 1.5 * w["ll_rel"] + 1e-5, (sched, e, w)
             eng.release_scratch()
 
 
@@ -428,15 +448,23 @@ def test_long_run_reaches_the_threshold_regime(amd, oracles):
     U0, V0 = host_init(n, m, k, 42)
     ones = np.ones(n, np.float32)
     kw = dict(n_iter=150, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32)
-    o = oracles["strict"]
-    o.set_threads(1)
-    Uo, Vo = U0.copy(), V0.copy()
-    _, _, tr_o, it_o = o.plsa_fit_inner(r, c, v, Vo, Uo, ones, return_trace=True, **kw)
-    o.set_threads(oracles["threads"])
-    zero_u, zero_v = float((Uo == 0).mean()), float((Vo == 0).mean())
+    ref = {}
+    for variant in ("strict", "wide"):
+        o = oracles[variant]
+        o.set_threads(1)
+        Uo, Vo = U0.copy(), V0.copy()
+        _, _, tr_o, it_o = o.plsa_fit_inner(r, c, v, Vo, Uo, ones, return_trace=True, **kw)
+        o.set_threads(oracles["threads"])
+        ref[variant] = (Uo, Vo, tr_o, it_o)
+    Us, Vs = ref["strict"][:2]
+    zero_u, zero_v = float((Us == 0).mean()), float((Vs == 0).mean())
     rec = REPORT.setdefault("long_run_threshold_regime", {"shape": [n, m], "nnz": int(nnz), "k": k, **kw,
                                                           "oracle_zero_fraction_U": zero_u, "oracle_zero_fraction_V": zero_v,
-                                                          "oracle_smallest_positive_U": float(Uo[Uo > 0].min())})
+                                                          "oracle_smallest_positive_U": float(Us[Us > 0].min())})
+    rec["strict_vs_wide"] = {"U": errs(Us, ref["wide"][0]), "V": errs(Vs, ref["wide"][1]),
+                             "ll_rel": ll_rel(ref["strict"][2], ref["wide"][2]),
+                             "zero_pattern_mismatches_U": int(((Us == 0) != (ref["wide"][0] == 0)).sum()),
+                             "zero_pattern_mismatches_V": int(((Vs == 0) != (ref["wide"][1] == 0)).sum())}
     assert zero_u >= 0.05, "the run never reached the threshold regime: %.4f of P(z|d) is zero" % zero_u
     with amd.Engine() as eng:
         eng.upload_csr(X)
@@ -444,22 +472,33 @@ def test_long_run_reaches_the_threshold_regime(amd, oracles):
             eng.set_factors(U0, V0)
             iters, trace = eng.fit(None, flags=flags, trace=True, **kw)
             U, V = eng.get_factors()
-            assert iters == it_o == 150
-            mism_u, mism_v = int(((U == 0) != (Uo == 0)).sum()), int(((V == 0) != (Vo == 0)).sum())
-            rec[sched] = {"U": errs(U, Uo), "V": errs(V, Vo), "ll_rel": ll_rel(trace, tr_o),
-                          "zero_pattern_mismatches_U": mism_u, "zero_pattern_mismatches_V": mism_v,
-                          "zero_fraction_U": float((U == 0).mean()), "zero_fraction_V": float((V == 0).mean())}
+            out = rec.setdefault(sched, {"zero_fraction_U": float((U == 0).mean()), "zero_fraction_V": float((V == 0).mean())})
+            for variant in ("strict", "wide"):
+                Uo, Vo, tr_o, it_o = ref[variant]
+                assert iters == it_o == 150
+                out["vs_" + variant] = {"U": errs(U, Uo), "V": errs(V, Vo), "ll_rel": ll_rel(trace, tr_o),
+                                        "zero_pattern_mismatches_U": int(((U == 0) != (Uo == 0)).sum()),
+                                        "zero_pattern_mismatches_V": int(((V == 0) != (Vo == 0)).sum())}
             _flush_report()
-            # An entry about to die holds ~1e-30; whether its LAST surviving product passes `> 1e-32` in this iteration or
-            # the next can hinge on the 7th digit, which summation order owns (the reference's own prange has the same
-            # freedom).  Such an entry is zero on both sides one iteration later.  Hence: the patterns agree except for at
-            # most 3 entries, and a disagreeing entry is negligible (< 1e-25) on the side where it still lives.
-            assert mism_u <= 3 and mism_v <= 3, (sched, rec[sched])
-            for A, B in ((U, Uo), (V, Vo)):
+            # The zero PATTERN against the reference's own arithmetic (strict, one thread).  An entry about to die holds
+            # ~1e-30; whether its LAST surviving product passes `> 1e-32` in this iteration or the next can hinge on the
+            # 7th digit, which summation order owns (the reference's own prange has the same freedom); such an entry is
+            # zero on both sides one iteration later.  Hence: at most 3 disagreeing entries, each negligible (< 1e-25)
+            # on the side where it still lives.  Measured: 0 mismatches among 120 000 + 100 000 entries, 59.6 % zeros.
+            e = out["vs_strict"]
+            assert e["zero_pattern_mismatches_U"] <= 3 and e["zero_pattern_mismatches_V"] <= 3, (sched, e)
+            for A, B in ((U, Us), (V, Vs)):
                 dis = (A == 0) != (B == 0)
                 assert not dis.any() or max(A[dis].max(), B[dis].max()) < 1e-25, (sched, A[dis], B[dis])
-            assert rec[sched]["U"]["peak_rel"] <= 1e-4 and rec[sched]["V"]["peak_rel"] <= 1e-4, (sched, rec[sched])
-            assert rec[sched]["ll_rel"] <= 1e-5, (sched, rec[sched])
+            # the VALUES after 150 iterations: the north-star tolerances against exact arithmetic; against the float32
+            # reference arithmetic no further than that arithmetic is from exact (its float32 norm_pwz running sum
+            # compounds over 150 iterations: 6e-5 on the likelihood)
+            e = out["vs_wide"]
+            assert e["U"]["peak_rel"] <= 1e-4 and e["V"]["peak_rel"] <= 1e-4 and e["ll_rel"] <= 1e-5, (sched, e)
+            e, w = out["vs_strict"], rec["strict_vs_wide"]
+            for f in ("U", "V"):
+                assert e[f]["peak_rel"] <= 1.5 * w[f]["peak_rel"] + 2e-5, (sched, f, e[f], w[f])
+            assert e["ll_rel"] <= 1.5 * w["ll_rel"] + 1e-5, (sched, e, w)
 
 
 def test_config4_ensemble_on_20ng_shaped_corpus(amd, oracles):
