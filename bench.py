@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- EM iterations/sec of the pLSA hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--schedule fused|materialised]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--schedule fused|materialised] [--topics 64]
+    python bench.py --gpus 8 --config 4        BASELINE configs[3]: the 32-member ensemble on the 20NG shape over 8 GPUs
 
 A "step" is one EM iteration (E-step + M-step, plus the log-likelihood test at the reference's
 schedule, plsa.py:630) over the whole synthetic corpus, driven through the C ABI (plsa_fit).
@@ -38,8 +39,13 @@ Extra objects in the JSON line:
                 the reference's own kernel sequence (E-step -> M-step -> LL) on the same data
   roofline_dominant_fused   same figures for the dominant kernel of the main (fused) timed region
   cpu_baseline  the CPU port (oracle/plsa_oracle.c, -O3 -ffast-math, OpenMP, reference thread
-                structure) timed on a bounded row-sample of the same corpus ("sampled": true), rank 0 /
-                N = 1 only; next to it `whole_config2`: the same port on the WHOLE of BASELINE configs[1]
+                structure) timed on the WHOLE corpus (2 EM iterations, "sampled": false; --cpu-baseline-sampled: a
+                bounded row sample, extrapolated), rank 0 / N = 1 only; next to it `whole_config2`: the same port on
+                the WHOLE of BASELINE configs[1]
+  other_configs (N = 1, --config 3) every other BASELINE.json configuration in compact form, each with steps /
+                ms_per_step: config1, config2, config5 (EM iterations/s + k_e_step roofline fraction),
+                ensemble_20ng_shape (configs[3]: 32 members through enstop_amd.ensemble_of_topics, fits/min),
+                config3_topical (config 3's shape on a corpus WITH co-occurrence structure)
   hot_kernels   per hot kernel: VGPRs / waves per SIMD / LDS (hipcc's own remarks, captured when the library was
                 built: enstop_amd/kernel_resources.json) and traffic_ratio = counter bytes / algorithmic bytes
   roofline.traffic   HBM-side bytes per launch from rocprofv3 PMC passes run by this script itself
@@ -67,8 +73,13 @@ CONFIGS = {
     1: dict(n=18_846, m=173_762, nnz=2_950_000, k=20, name="20NG-shaped synthetic CSR 18846 x 173762, 2.95M nnz, k=20"),
     2: dict(n=100_000, m=50_000, nnz=10_000_000, k=32, name="synthetic CSR 100k docs x 50k vocab, 10M nnz, k=32"),
     3: dict(n=1_000_000, m=100_000, nnz=100_000_000, k=64, name="synthetic CSR 1M docs x 100k vocab, 100M nnz, k=64"),
+    # configs[3]: "EnsembleTopics n_components=20, n_runs=32 on 20-Newsgroups, sharded across 8 GPUs" -- config 1's corpus;
+    # with --config 4 the measured ensemble leg fits 32 members in all (32 / N per rank)
+    4: dict(n=18_846, m=173_762, nnz=2_950_000, k=20, ensemble_runs=32,
+            name="20NG-shaped synthetic CSR 18846 x 173762, 2.95M nnz, k=20; ensemble of 32 bootstrapped fits"),
     5: dict(n=5_000_000, m=200_000, nnz=500_000_000, k=128, name="synthetic CSR 5M docs x 200k vocab, 500M nnz, k=128"),
 }
+TOPICAL = dict(topics=64, alpha=0.1, background=0.25)      # --topics: documents as Dirichlet mixtures of latent topics
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 FITS_ITERS = 50                # EM iterations per ensemble member when quoting fits/min
 
@@ -142,41 +153,91 @@ def cpu_baseline(eng, cfg, k, budget_cells=1.2e9, iters=3, whole=False):
     }
 
 
-def quick_config(eng, cfg_id, steps, warmup, seed, with_cpu=False):
+def quick_config(eng, cfg_id, steps, warmup, seed, with_cpu=False, e_step=True, min_steps=200, device_init=False,
+                 corpus_kw=None, pass_times=False):
     """Compact measurement of another BASELINE.json config on the same device (N = 1 only): fused EM
-    iterations/s and the materialising E-step's roofline fraction, same method as the main legs."""
+    iterations/s and the materialising E-step's roofline fraction, same method as the main legs.
+    device_init: the factors come from the device MT19937 initialisation (the same RandomState(42) stream, bit-identical
+    to the host's: config 5's 665 M draws take the host ~10 s).  corpus_kw: generator options (topical corpora).
+    pass_times: per-kernel HIP-event averages of the two fused passes over 10 further iterations."""
     from enstop_amd.engine import PLSA_FUSED
     cfg = CONFIGS[cfg_id]
     n, m, k = cfg["n"], cfg["m"], cfg["k"]
-    nnz = eng.generate_synthetic(n, m, cfg["nnz"], zipf_s=1.07, seed=seed)
-    U0, V0 = init_factors(n, m, k, 42)
     eng.release_scratch()
-    eng.set_factors(U0, V0)
+    nnz = eng.generate_synthetic(n, m, cfg["nnz"], zipf_s=1.07, seed=seed, **(corpus_kw or {}))
+    if device_init:
+        def reset():
+            eng.init_factors_numpy_stream(k, np.random.RandomState(42))
+    else:
+        U0, V0 = init_factors(n, m, k, 42)
+
+        def reset():
+            eng.set_factors(U0, V0)
+    reset()
     eng.fit(None, n_iter=warmup, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=PLSA_FUSED)
     eng.synchronize()
     t0 = time.perf_counter()
-    steps = max(steps, 200)        # a 0.17 ms iteration: 50 of them would be dominated by the call's fixed costs
+    steps = max(steps, min_steps)  # a 0.17 ms iteration: 50 of them would be dominated by the call's fixed costs
     it, _ = eng.fit(None, n_iter=steps, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=PLSA_FUSED)
     eng.synchronize()
     dt = time.perf_counter() - t0
-    eng.timing(True)
-    eng.e_step(1e-32, want_host_copy=False)
-    eng.timing_reset()
-    for _ in range(5):
+    out = {"workload": cfg["name"] + ("" if not corpus_kw else " -- TOPICAL corpus %r" % (corpus_kw,)), "nnz": nnz, "k": k,
+           "steps": it, "value": round(it / dt, 2), "unit": "iter/s", "ms_per_step": round(dt / it * 1e3, 4),
+           "gcell_per_s": round(nnz * k * it / dt / 1e9, 2)}
+    if pass_times:
+        eng.timing(True)
+        eng.timing_reset()
+        eng.fit(None, n_iter=10, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=PLSA_FUSED)
+        out["fused_pass_avg_ms"] = {kk: round(v[1] / v[0], 4) for kk, v in eng.timing_report().items() if "pass" in kk}
+        eng.timing(False)
+    if e_step:
+        reset()
+        eng.timing(True)
         eng.e_step(1e-32, want_host_copy=False)
-    ms, cnt = eng.timing_get("k_e_step")
-    eng.timing(False)
-    b = algorithmic_bytes("e_step", n, m, nnz, k)
-    out = {"workload": cfg["name"], "nnz": nnz, "k": k, "steps": it, "value": round(it / dt, 2), "unit": "iter/s",
-           "ms_per_step": round(dt / it * 1e3, 4),
-           "e_step": {"avg_launch_ms": round(ms / cnt, 5), "achieved_GBps": round(b / 1e9 / (ms / cnt / 1e3), 1),
-                      "frac": round(b / 1e9 / (ms / cnt / 1e3) / HBM_PEAK_GBS, 4)}}
+        eng.timing_reset()
+        for _ in range(5):
+            eng.e_step(1e-32, want_host_copy=False)
+        ms, cnt = eng.timing_get("k_e_step")
+        eng.timing(False)
+        b = algorithmic_bytes("e_step", n, m, nnz, k)
+        out["e_step"] = {"avg_launch_ms": round(ms / cnt, 5), "launches": cnt, "algorithmic_GB": round(b / 1e9, 3),
+                         "achieved_GBps": round(b / 1e9 / (ms / cnt / 1e3), 1),
+                         "frac": round(b / 1e9 / (ms / cnt / 1e3) / HBM_PEAK_GBS, 4)}
+        eng.release_scratch()
     if with_cpu:
         try:
             out["cpu_baseline"] = cpu_baseline(eng, cfg, k, whole=True)
         except Exception as e:
             out["cpu_baseline"] = "failed: %r" % (e,)
     return out
+
+
+def ensemble_20ng_shape(eng, seed, n_runs=32, n_jobs=4):
+    """BASELINE configs[3] on one GPU: EnsembleTopics' member fan-out -- enstop_amd.ensemble_of_topics(X, 20, n_runs=32)
+    on the 20NG-shaped corpus, 50 EM iterations per member (BASELINE configs[0]), up to four members in flight
+    (n_jobs: the reference's thread pool, enstop_.py:209-217).  Wall clock of the whole call, upload included."""
+    import enstop_amd
+    cfg = CONFIGS[4]
+    eng.release_scratch()
+    eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], zipf_s=1.07, seed=seed)
+    X = eng.download_active_csr()
+    kw = dict(n_iter=FITS_ITERS, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, random_state=seed + 7, n_jobs=n_jobs)
+    enstop_amd.ensemble_of_topics(X, cfg["k"], n_runs=n_jobs, **kw)          # warm-up: member contexts and their buffers
+    walls = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        stack = enstop_amd.ensemble_of_topics(X, cfg["k"], n_runs=n_runs, **kw)
+        walls.append(time.perf_counter() - t0)
+    assert stack.shape == (n_runs * cfg["k"], cfg["m"]) and np.all(np.isfinite(stack))
+    assert np.abs(stack.sum(axis=1, dtype=np.float64) - 1.0).max() < 1e-3
+    wall = sorted(walls)[1]
+    return {"workload": cfg["name"], "nnz": int(X.nnz), "k": cfg["k"], "fits": n_runs, "iters_per_member": FITS_ITERS,
+            "n_jobs": n_jobs, "steps": n_runs * FITS_ITERS, "wall_s": round(wall, 4), "walls_s": [round(w, 4) for w in walls],
+            "ms_per_step": round(wall / (n_runs * FITS_ITERS) * 1e3, 5), "ms_per_fit": round(wall / n_runs * 1e3, 3),
+            "value": round(n_runs / wall * 60.0, 1), "unit": "fits/min",
+            "path": "enstop_amd.ensemble_of_topics(X_host, 20, n_runs=32, n_iter=50, tolerance=0, n_jobs=4): upload + per member "
+                    "(device bootstrap gather, CSC / item build, MT19937 init on the device, fit, D2D into the stack) + one copy "
+                    "of the stack to the host; median of three calls"}
 
 
 def ensemble_leg(eng, comm, k, world, rank, args, rccl_init_s):
@@ -187,7 +248,10 @@ def ensemble_leg(eng, comm, k, world, rank, args, rccl_init_s):
     from enstop_amd import enstop_ as product
     eng.bootstrap(None)
     X = eng.download_active_csr()                      # host copy of the corpus: what a caller of the API holds
-    n_runs = args.members_per_rank * world
+    members = args.members_per_rank
+    if members <= 0:                                   # default: 2 per rank; --config 4: BASELINE's 32 runs over the ranks
+        members = max(1, CONFIGS[args.config].get("ensemble_runs", 2 * world) // world)
+    n_runs = members * world
     kw = dict(n_runs=n_runs, n_iter=FITS_ITERS, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32,
               random_state=args.seed + 7, n_jobs=4)
     eng.synchronize()
@@ -204,7 +268,7 @@ def ensemble_leg(eng, comm, k, world, rank, args, rccl_init_s):
     mine = np.array([dt, tm.get("fit_s", 0.0), tm.get("gather_s", 0.0), rccl_init_s], np.float64)
     per_rank = comm.allgather_array(mine)              # [world, 4]
     wall = float(per_rank[:, 0].max())
-    return {"fits": n_runs, "members_per_rank": args.members_per_rank, "iters_per_member": FITS_ITERS,
+    return {"fits": n_runs, "members_per_rank": members, "iters_per_member": FITS_ITERS,
             "wall_s": round(wall, 4), "fits_per_min": round(n_runs / wall * 60.0, 2),
             "per_rank": [{"rank": r, "wall_s": round(float(per_rank[r, 0]), 4), "fit_s": round(float(per_rank[r, 1]), 4),
                           "gather_s": round(float(per_rank[r, 2]), 4), "rccl_init_s": round(float(per_rank[r, 3]), 4)}
@@ -250,13 +314,17 @@ def spawn_ranks(args):
     return rc
 
 
+def corpus_options(args):
+    return dict(TOPICAL, topics=args.topics) if args.topics > 0 else {}
+
+
 def pmc_child(args):
     """Short run for the counter passes (`rocprofv3 --pmc ... -- python bench.py --pmc-child`): the same
     corpus and factors, two launches of the materialising E-step and four fused EM iterations."""
     from enstop_amd.engine import Engine, PLSA_FUSED
     cfg = CONFIGS[args.config]
     eng = Engine(0)
-    eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], zipf_s=1.07, seed=args.seed)
+    eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], zipf_s=1.07, seed=args.seed, **corpus_options(args))
     U0, V0 = init_factors(cfg["n"], cfg["m"], cfg["k"], 42)
     eng.set_factors(U0, V0)
     # four iterations: the first two document passes carry a log-likelihood (k_row_pass<fused,LL>), the others do not
@@ -300,7 +368,7 @@ def measure_traffic(args):
             out = os.path.join(tmpdir, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "b", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(args.config),
-                   "--seed", str(args.seed)]
+                   "--seed", str(args.seed), "--topics", str(args.topics)]
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            timeout=float(os.environ.get("PLSA_BENCH_PMC_TIMEOUT", "150")), check=True)
@@ -378,12 +446,17 @@ def main():
     ap.add_argument("--schedule", default=os.environ.get("PLSA_BENCH_SCHEDULE", "fused"),
                     choices=["fused", "materialised"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="additionally time the CPU port on the WHOLE corpus for 2 iterations (config 3: ~1.5 min of "
-                         "host time, 26 GB of host memory) -> cpu_baseline.whole_corpus")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="(default since round 5; kept for old command lines)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
     ap.add_argument("--no-ensemble", action="store_true", help="skip the measured ensemble leg")
-    ap.add_argument("--members-per-rank", type=int, default=2)
+    ap.add_argument("--members-per-rank", type=int, default=0,
+                    help="members each rank fits in the measured ensemble leg (0 = 2, or 32 / N with --config 4)")
+    ap.add_argument("--topics", type=int, default=0,
+                    help="generate a TOPICAL corpus of the config's shape (documents as Dirichlet mixtures of this many latent "
+                         "topics; plsa_generate_synthetic_topics) instead of independent Zipf tokens; labelled in `config`")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the compact legs of the other BASELINE configs")
+    ap.add_argument("--cpu-baseline-sampled", action="store_true",
+                    help="time the CPU port on a bounded row sample (~15 s) instead of the whole corpus (config 3: ~45 s, 26 GB)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "files"],
                     help="files: TEST MODE for boxes with fewer GPUs than ranks (host-file exchange, shared GPUs)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -455,7 +528,7 @@ def main():
             comm = plsa_comm.install(plsa_comm.FileComm(os.environ.get("PLSA_BENCH_FILES_DIR", "/tmp/plsa_bench_x"),
                                                         rank, world))
     t_gen = time.perf_counter()
-    nnz = eng.generate_synthetic(n, m, cfg["nnz"], zipf_s=1.07, seed=args.seed)
+    nnz = eng.generate_synthetic(n, m, cfg["nnz"], zipf_s=1.07, seed=args.seed, **corpus_options(args))
     if world > 1:  # ensemble member `rank`: bootstrap rows on the device (enstop_.py:87-88)
         idx = np.random.RandomState(args.seed + 1000 + rank).randint(0, n, size=n)
         eng.bootstrap(idx)
@@ -601,7 +674,8 @@ def main():
         "timed_regions": [{"value": round(n_gpus * args.steps / r[0], 4), "ms_per_step": round(r[0] / args.steps * 1e3, 4)}
                           for r in regions],
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["name"], "n_docs": n, "n_vocab": m, "nnz": nnz, "k": k,
+        "config": {"workload": cfg["name"] + ("" if not args.topics else " -- TOPICAL corpus %r" % (corpus_options(args),)),
+                   "n_docs": n, "n_vocab": m, "nnz": nnz, "k": k,
                    "schedule": args.schedule,
                    "parallelism": "single fit" if n_gpus == 1 else
                    "ensemble: one bootstrap member per GPU x%d, all-gather of topics: %s" % (n_gpus, exchange),
@@ -627,16 +701,14 @@ def main():
     }
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
+            # the WHOLE corpus by default (config 3: 2 iterations, ~45 s of host time, 26 GB of host memory: nothing is
+            # extrapolated); --cpu-baseline-sampled: the bounded row sample of rounds 1-4 (~15 s, "sampled": true)
             try:
-                out["cpu_baseline"] = cpu_baseline(eng, cfg, k)
+                out["cpu_baseline"] = cpu_baseline(eng, cfg, k) if args.cpu_baseline_sampled else \
+                    cpu_baseline(eng, cfg, k, iters=2, whole=True)
             except Exception as e:       # the baseline must never cost the GPU measurement
                 out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-            if args.cpu_baseline_full and isinstance(out.get("cpu_baseline"), dict):
-                try:
-                    out["cpu_baseline"]["whole_corpus"] = cpu_baseline(eng, cfg, k, iters=2, whole=True)
-                except Exception as e:
-                    out["cpu_baseline"]["whole_corpus"] = "failed: %r" % (e,)
     # ---- measured ensemble: the product's own call, two members per rank (see the module docstring) -------------
     if not args.no_ensemble:
         stage("ensemble")
@@ -648,16 +720,34 @@ def main():
                 plsa_comm.report_failure(e, rank, world, eng)
                 raise                                     # a rank that fails here would leave the others in a collective
             out["ensemble"] = "failed: %r" % (e,)
-    if rank == 0 and n_gpus == 1 and args.config == 3 and not args.no_cpu_baseline:
-        # BASELINE.json configs[1] (100k x 50k, 10M nnz, k=32) on the same device, compact form, with the
-        # CPU port on the WHOLE of that corpus beside it
-        try:
-            c2 = quick_config(eng, 2, args.steps, args.warmup, args.seed, with_cpu=True)
-            if isinstance(out.get("cpu_baseline"), dict) and isinstance(c2.get("cpu_baseline"), dict):
-                out["cpu_baseline"]["whole_config2"] = c2["cpu_baseline"]
-            out["other_configs"] = {"config2": c2}
-        except Exception as e:
-            out["other_configs"] = {"config2": "failed: %r" % (e,)}
+    if rank == 0 and n_gpus == 1 and args.config == 3 and not args.topics and not args.no_other_configs:
+        # every other BASELINE.json configuration on the same device in compact form (same method as the main legs), so
+        # that each is a number the driver's own run observes: configs[0] / [1] / [4] as EM iterations/s + the
+        # materialising E-step's roofline fraction, configs[3] (the 32-member ensemble on the 20NG shape) as fits/min
+        # through the product's own call; config 2 with the CPU port on the WHOLE of its corpus; and config 3's shape with
+        # TOPICAL structure (the corpus above has no co-occurrence: DESIGN.md section 5)
+        other = out["other_configs"] = {}
+
+        def leg(name, fn):
+            t_leg = time.perf_counter()
+            try:
+                other[name] = fn()
+                if isinstance(other[name], dict):
+                    other[name]["leg_wall_s"] = round(time.perf_counter() - t_leg, 1)
+            except Exception as e:
+                other[name] = "failed: %r" % (e,)
+        leg("config2", lambda: quick_config(eng, 2, args.steps, args.warmup, args.seed, with_cpu=not args.no_cpu_baseline))
+        c2 = other["config2"]
+        if isinstance(out.get("cpu_baseline"), dict) and isinstance(c2, dict) and isinstance(c2.get("cpu_baseline"), dict):
+            out["cpu_baseline"]["whole_config2"] = c2["cpu_baseline"]
+        leg("config1", lambda: quick_config(eng, 1, args.steps, args.warmup, args.seed, min_steps=1000))
+        leg("ensemble_20ng_shape", lambda: ensemble_20ng_shape(eng, args.seed))
+        leg("config3_topical", lambda: quick_config(eng, 3, args.steps, args.warmup, args.seed, e_step=False, min_steps=50,
+                                                    corpus_kw=dict(TOPICAL), pass_times=True))
+        from enstop_amd.engine import reset_engines as _reset
+        _reset()                                   # config 5's materialised leg needs ~270 of the 288 GB
+        eng = get_engine(device)
+        leg("config5", lambda: quick_config(eng, 5, args.steps, args.warmup, args.seed, min_steps=20, device_init=True))
     if world > 1:
         comm.barrier()
         plsa_comm.shutdown()

@@ -38,6 +38,8 @@ def test_config_table_is_baseline_json():
     assert b.CONFIGS[2]["n"] == 100_000 and b.CONFIGS[2]["m"] == 50_000 and b.CONFIGS[2]["nnz"] == 10_000_000 and b.CONFIGS[2]["k"] == 32
     assert b.CONFIGS[3]["n"] == 1_000_000 and b.CONFIGS[3]["m"] == 100_000 and b.CONFIGS[3]["nnz"] == 100_000_000 and b.CONFIGS[3]["k"] == 64
     assert b.CONFIGS[5]["n"] == 5_000_000 and b.CONFIGS[5]["m"] == 200_000 and b.CONFIGS[5]["nnz"] == 500_000_000 and b.CONFIGS[5]["k"] == 128
+    assert b.CONFIGS[4]["n"] == b.CONFIGS[1]["n"] == 18_846 and b.CONFIGS[4]["k"] == 20 and b.CONFIGS[4]["ensemble_runs"] == 32
+    assert "n_runs=32" in base["configs"][3] and "n_components=20" in base["configs"][3]
     assert "100k docs" in base["configs"][1] and "1M docs" in base["configs"][2] and "5M docs" in base["configs"][4]
     assert base["metric"].startswith("EM iterations/sec")
 
