@@ -1472,7 +1472,7 @@ static int mt_init(plsa_ctx *c, int32_t k, uint32_t *state_io /*[625]*/, const f
     CHK(ensure(c, st, sizeof(unsigned) * 624 * (size_t)streams_p2));
     CHK(ensure(c, fin, sizeof(unsigned) * 640 + sizeof(double) * 1024));
     if (levels) CHK(ensure(c, gp, sizeof(unsigned) * polys.size()));
-    if (!V_host && !c->mt_chain && m <= ((i64)1 << 22))     // chunk sums (u64), parity pairs (2 x u64) and binade guesses (int) of the topic marginals
+    if (!V_host && !c->mt_chain)     // chunk sums (u64), parity pairs (2 x u64), tile sums (f64) and binade guesses (int) of the topic marginals
         CHK(ensure(c, c->mt_seq, (size_t)k * (size_t)((m + plsa::MT_SEQ_L - 1) / plsa::MT_SEQ_L) * (3 * sizeof(plsa::u64) + sizeof(int) + sizeof(double))));
     hipError_t e = hipMemsetAsync(st.p, 0, sizeof(unsigned) * 624 * (size_t)streams_p2, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(st.p, state_io, sizeof(unsigned) * 624, hipMemcpyHostToDevice, c->stream);

@@ -992,7 +992,8 @@ def test_device_mt19937_init_is_bit_identical_to_numpy(amd, n_m_k):
         np.testing.assert_array_equal(rng_h.rand(5), rng_d.rand(5))      # same continuation
 
 
-@pytest.mark.parametrize("m_k", [(1, 3), (63, 2), (64, 5), (65, 4), (4097, 7), (100_000, 64), (173_762, 20), (1_000_003, 3)])
+@pytest.mark.parametrize("m_k", [(1, 3), (63, 2), (64, 5), (65, 4), (4097, 7), (100_000, 64), (173_762, 20), (1_000_003, 3),
+                                 (4_500_001, 2)])        # beyond 2^22 words per topic (rounds 3-4 fell back to the chain there)
 def test_device_topic_marginals_are_the_sequential_float64_sums(amd, monkeypatch, m_k):
     """The normalisation constants of plsa_init's topic rows (utils.py:24-29: one float64 running sum per topic, left to
     right over the m words) come from per-chunk parity pairs on the device, not from a chain of m dependent adds: the
