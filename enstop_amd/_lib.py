@@ -93,6 +93,7 @@ SIGNATURES = {
                                           C.POINTER(_i64)]),
     "plsa_generate_synthetic_topics": (C.c_int, [_ctx, _i64, _i64, _i64, C.c_double, C.c_uint64, _i32, C.c_double,
                                                  C.c_double, C.POINTER(_i64)]),
+    "plsa_synthetic_dominant_topics": (C.c_int, [_ctx, _i32p]),
 }
 
 _lib = None

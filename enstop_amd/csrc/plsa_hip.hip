@@ -113,6 +113,10 @@ struct plsa_ctx {
     // rows in descending-length order (row-owned kernels: groups of a wave finish together)
     bool sort_rows = true, roworder_valid = false;
     DevBuf row_order;
+    // parameters of the last topical corpus generated on this context (plsa_synthetic_dominant_topics)
+    i64 syn_n = 0; int syn_k0 = 0; double syn_alpha = 0.0; uint64_t syn_seed = 0;
+    bool row_xcd = false;            // PLSA_ROW_XCD=1 (experiment): XCD x walks the x-th eighth of the documents (k_row_pass)
+    int roworder_range = 0;          // documents per range the current row_order was built for (0: plain length order)
 
     // factors
     int k = 0, kp = 0, lpn = 1, ch = 1;
@@ -427,17 +431,26 @@ int ensure_rowidx(plsa_ctx *c) {
 }
 
 // row ids sorted by descending row length (stable), or nullptr when sorting is disabled
+// documents per range of the XCD-contiguous document schedule for the current corpus and lane shape (0: not in use)
+int row_xcd_range(const plsa_ctx *c) {
+    const i64 gpb = 256 / std::max(1, c->row_lpn);
+    if (!c->row_xcd || c->n < 64 * gpb) return 0;
+    return (int)(((c->n + gpb - 1) / gpb + 7) / 8 * gpb);
+}
+
 int ensure_roworder(plsa_ctx *c, const int **out) {
     *out = nullptr;
     if (!c->sort_rows) return 0;
-    if (!c->roworder_valid) {
+    const int range = row_xcd_range(c);
+    if (!c->roworder_valid || c->roworder_range != range) {
+        c->roworder_range = range;
         const i64 n = c->n;
         CHK(ensure(c, c->row_order, sizeof(int) * (size_t)n));
         CHK(ensure(c, c->tmp0, sizeof(int) * (size_t)n * 2));
         CHK(ensure(c, c->tmp1, sizeof(int) * (size_t)n));
         int *len = c->tmp0.as<int>(), *len_sorted = c->tmp0.as<int>() + n, *ids = c->tmp1.as<int>();
         hipLaunchKernelGGL(plsa::k_row_lengths, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                           c->indptr, (int)n, len, ids);
+                           c->indptr, (int)n, len, ids, range);
         CHK(launch_check(c, "k_row_lengths"));
         size_t bytes = 0;
         HIPCHK(c, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, len, len_sorted, ids,
@@ -778,8 +791,13 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, floa
                  float *d_norm_pdz, int *ll_blocks) {
     CHK(ensure_ritems(c));
     const bool items = c->use_ritems && c->n_ritems > 0;
-    const int grid = grid_for(c, items ? c->n_ritems : c->n, 256 / c->row_lpn);
+    int grid = grid_for(c, items ? c->n_ritems : c->n, 256 / c->row_lpn);
     const int *order = nullptr;
+    // PLSA_ROW_XCD (experiment): one trip, grid a multiple of 8, XCD x takes the x-th eighth of the visiting list, which is
+    // ordered range by range (range = the documents of one eighth), longest document first inside a range
+    const int gpb_row = 256 / c->row_lpn;
+    const bool xcd_rows = !items && !from_p && c->sort_rows && row_xcd_range(c) > 0;
+    if (xcd_rows) grid = (int)(((c->n + gpb_row - 1) / gpb_row + 7) / 8 * 8);
     if (!items) CHK(ensure_roworder(c, &order));
     if (items) CHK(ensure(c, c->rpartial, sizeof(float) * (size_t)c->n_ritems * c->kp));
     const int *ri_row = items ? c->ritem_row.as<int>() : nullptr;
@@ -800,7 +818,7 @@ int run_row_pass(plsa_ctx *c, bool from_p, bool want_ll, const float *d_sw, floa
             Scope s(c, name);
             hipLaunchKernelGGL((plsa::k_row_pass<Sh, decltype(FP)::value, decltype(LL)::value, decltype(TN)::value>),
                                dim3(grid), dim3(256), 0, c->ls, ip, cl, vl, n, order, U, Vt, P, Un,
-                               d_sw, d_norm_pdz, kp, thresh, llp, ri_row, ri_start, rseg, n_ritems, rpart);
+                               d_sw, d_norm_pdz, kp, thresh, llp, ri_row, ri_start, rseg, n_ritems, rpart, xcd_rows ? 1 : 0);
         };
         using T = std::true_type;
         using F = std::false_type;
@@ -1189,6 +1207,7 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_COL_SEG")) c->seg_override = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_HEAVY_ITEMS")) c->heavy_items = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_SORT_ROWS")) c->sort_rows = atoi(s) != 0;
+    if (const char *s = getenv("PLSA_ROW_XCD")) c->row_xcd = atoi(s) != 0;
     if (const char *s = getenv("PLSA_ITEM_ORDER")) c->use_item_order = atoi(s) != 0;
     if (const char *s = getenv("PLSA_XCD_SPLIT")) c->xcd_split = atoi(s) != 0;
     if (const char *s = getenv("PLSA_BALANCE")) c->balance = atoi(s);
@@ -1291,6 +1310,7 @@ int plsa_upload_csr(plsa_ctx *c, const int32_t *indptr, const int32_t *indices, 
                     bad == 3 ? "; " : "", (bad & 2) ? "column index outside [0, m)" : "");
     }
     c->bn = n; c->bm = m; c->bnnz = nnz;
+    c->syn_n = 0;
     c->active_is_base = true;
     set_active_pointers(c);
     return 0;
@@ -2560,7 +2580,21 @@ static int generate_synthetic_impl(plsa_ctx *c, int64_t n, int64_t m, int64_t nn
     c->bn = n; c->bm = m; c->bnnz = nnz;
     c->active_is_base = true;
     set_active_pointers(c);
+    c->syn_n = k0 > 0 ? n : 0; c->syn_k0 = k0; c->syn_alpha = alpha; c->syn_seed = seed;
     if (nnz_out) *nnz_out = nnz;
+    return 0;
+}
+
+int plsa_synthetic_dominant_topics(plsa_ctx *c, int32_t *out /*[n] host*/) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->syn_n <= 0 || c->syn_n != c->bn) return fail(c, "plsa_synthetic_dominant_topics: the base corpus is not a topical synthetic corpus");
+    if (!out) return fail(c, "plsa_synthetic_dominant_topics: out is NULL");
+    CHK(ensure(c, c->tmp1, sizeof(int) * (size_t)c->syn_n));
+    hipLaunchKernelGGL(plsa::k_synth_dominant_topic, dim3((unsigned)((c->syn_n + 255) / 256)), dim3(256), 0, c->stream,
+                       (int)c->syn_n, c->syn_k0, c->syn_alpha, c->syn_seed, c->tmp1.as<int>());
+    CHK(launch_check(c, "k_synth_dominant_topic"));
+    HIPCHK(c, hipMemcpyAsync(out, c->tmp1.p, sizeof(int) * (size_t)c->syn_n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -345,20 +345,24 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_row_pass(const int *__restr
                                                   float thresh, double *__restrict__ ll_partials,
                                                   const int *__restrict__ ritem_row,
                                                   const int *__restrict__ ritem_start, int rseg,
-                                                  i64 n_ritems, float *__restrict__ rpartial) {
+                                                  i64 n_ritems, float *__restrict__ rpartial, int xcd_rows) {
     constexpr int LPN = S::LPN, CH = S::CH, UNR = S::UNR;
     constexpr int GPB = 256 / LPN;  // groups per block
     const int kp = S::kp(kp_rt);
     const int li = threadIdx.x % LPN;
     const int gid = threadIdx.x / LPN;
     double ll = 0.0;
+    // xcd_rows (PLSA_ROW_XCD, experiment): workgroup b runs on XCD b % 8; XCD x takes the x-th EIGHTH of the visiting list
+    // (the grid covers the list in one trip and is a multiple of 8), so that an XCD's L2 sees the P(w|z) rows of one
+    // contiguous range of documents only -- worth something when neighbouring documents share vocabulary
+    const i64 first_block = xcd_rows ? (i64)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
     constexpr bool tiny = !FROM_P && TINY;
     // item mode (ritem_row != nullptr): rows are cut into items of <= rseg entries, a group owns
     // one item and writes an un-normalised partial row that k_row_reduce adds up in item order.
     // Used when there are too few / too uneven rows to fill the chip (few long documents).
     const bool items = ritem_row != nullptr;
     const i64 n_work = items ? n_ritems : (i64)n;
-    for (i64 r = (i64)blockIdx.x * GPB + gid; r < n_work; r += (i64)gridDim.x * GPB) {
+    for (i64 r = first_block * GPB + gid; r < n_work; r += (i64)gridDim.x * GPB) {
         const int d = items ? ritem_row[r] : (row_order ? row_order[r] : (int)r);
         const int j0 = items ? ritem_start[r] : indptr[d];
         const int j1 = items ? min(j0 + rseg, indptr[d + 1]) : indptr[d + 1];
@@ -1058,10 +1062,17 @@ __global__ void k_expand_rows(const int *__restrict__ indptr, int n, int *__rest
     }
 }
 
+// sort key of the document order: the row length (sorted DESCENDING), or -- range > 0, the XCD-contiguous document
+// schedule (PLSA_ROW_XCD) -- documents of one RANGE of `range` consecutive documents first, longest first inside a range:
+// key = (number of ranges - 1 - d / range) << 22 | min(length, 2^22 - 1), also sorted descending
 __global__ void k_row_lengths(const int *__restrict__ indptr, int n, int *__restrict__ len,
-                              int *__restrict__ ids) {
+                              int *__restrict__ ids, int range) {
     const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) { len[r] = indptr[r + 1] - indptr[r]; ids[r] = (int)r; }
+    if (r < n) {
+        const int l = indptr[r + 1] - indptr[r];
+        len[r] = range > 0 ? (int)((unsigned)((n - 1) / range - (int)(r / range)) << 22 | (unsigned)min(l, (1 << 22) - 1)) : l;
+        ids[r] = (int)r;
+    }
 }
 
 // V [k,m] (reference layout) -> Vt [m,kp] (device layout), 32x32 tiles through LDS

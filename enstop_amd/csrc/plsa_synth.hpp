@@ -80,6 +80,25 @@ __device__ __forceinline__ double gamma_mt(double shape, uint64_t key) {
     return dd;      // (never reached in practice: acceptance > 95 % per round)
 }
 
+// un-normalised weight of latent topic t in document d: gamma(alpha + 1) * u^(1/alpha) (= a gamma(alpha) variate)
+__device__ __forceinline__ double doc_topic_weight(uint64_t seed, long long d, int t, double alpha) {
+    const uint64_t key = mix64(seed ^ 0x7091C5ull ^ mix64((uint64_t)d * 1024ull + (uint64_t)t));
+    return gamma_mt(alpha + 1.0, key) * pow(u01(mix64(key ^ 0xA5A5A5A5ull)), 1.0 / alpha);
+}
+
+// ground truth of the topical corpus: the latent topic with the largest share of each document's mixture
+__global__ void k_synth_dominant_topic(int n, int k0, double alpha, uint64_t seed, int *__restrict__ out) {
+    const long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n) return;
+    double best = -1.0;
+    int arg = 0;
+    for (int t = 0; t < k0; ++t) {
+        const double g = doc_topic_weight(seed, d, t, alpha);
+        if (g > best) { best = g; arg = t; }
+    }
+    out[d] = arg;
+}
+
 // one wave per document, four documents per workgroup.  Topic mixture: g_t = gamma(alpha + 1) * u^(1/alpha)
 // (= gamma(alpha) for any alpha > 0), normalised -> cumulative theta in LDS; tokens as described in the header.
 // perm[2*t], perm[2*t+1]: the affine ranking (a * rank + b) mod m of topic t; t == k0 is the shared ranking.
@@ -92,11 +111,7 @@ __global__ void k_synth_draw_topics(int n, int m, const long long *__restrict__ 
     for (long long base = (long long)blockIdx.x * 4; base < n; base += (long long)gridDim.x * 4) {
         const long long d = base + w;
         if (d < n) {
-            for (int t = lane; t < k0; t += 64) {
-                const uint64_t key = mix64(seed ^ 0x7091C5ull ^ mix64((uint64_t)d * 1024ull + (uint64_t)t));
-                const double g = gamma_mt(alpha + 1.0, key) * pow(u01(mix64(key ^ 0xA5A5A5A5ull)), 1.0 / alpha);
-                tcdf[w][t] = g;
-            }
+            for (int t = lane; t < k0; t += 64) tcdf[w][t] = doc_topic_weight(seed, d, t, alpha);
         }
         __syncthreads();
         if (d < n && lane == 0) {

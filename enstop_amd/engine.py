@@ -118,6 +118,12 @@ class Engine:
         self.base_rows = n
         return out.value
 
+    def synthetic_dominant_topics(self):
+        """Ground truth of the topical synthetic corpus held as the base matrix: the dominant latent topic of every document."""
+        out = np.empty(self.base_rows, np.int32)
+        self._ok(self._L.plsa_synthetic_dominant_topics(self._h, out))
+        return out
+
     def bootstrap(self, idx):
         """active := base[idx] on the device (enstop_.py:87-88); idx=None restores the base."""
         if idx is None:

@@ -288,6 +288,9 @@ int plsa_generate_synthetic(plsa_ctx *ctx, int64_t n, int64_t m, int64_t nnz_tar
  * generative model pLSA assumes.  1 <= k0 <= 256, alpha > 0, 0 <= background <= 1; deterministic in all arguments. */
 int plsa_generate_synthetic_topics(plsa_ctx *ctx, int64_t n, int64_t m, int64_t nnz_target, double zipf_s,
                                    uint64_t seed, int32_t k0, double alpha, double background, int64_t *nnz_out);
+/* ground truth of the topical corpus currently held as the base matrix: out[d] = the latent topic with the largest share
+ * of document d's mixture theta_d (tests: does a fit recover the planted structure; experiments: document orderings). */
+int plsa_synthetic_dominant_topics(plsa_ctx *ctx, int32_t *out /* [n], host */);
 
 #ifdef __cplusplus
 }
