@@ -609,6 +609,18 @@ def test_topical_generator_is_deterministic_and_has_cooccurrence_structure(amd):
         I = eng.download_active_csr()
         with pytest.raises(amd.DeviceError):
             eng.generate_synthetic(n, m, target, seed=11, topics=300)
+        # edge mixtures: one topic; a concentration so small that every gamma draw underflows (the document falls back to
+        # one hashed topic); background = 1 (every token from the shared ranking); the labels follow the mixtures
+        for edge in (dict(topics=1, alpha=0.1, background=0.0), dict(topics=40, alpha=1e-4, background=0.0),
+                     dict(topics=5, alpha=0.1, background=1.0)):
+            nz = eng.generate_synthetic(500, 400, 20_000, seed=2, **edge)
+            E = eng.download_active_csr()
+            assert E.nnz == nz and np.all(np.isfinite(E.data)) and E.indices.max() < 400 and np.diff(E.indptr).min() >= 1
+            lab = eng.synthetic_dominant_topics()
+            assert lab.shape == (500,) and lab.min() >= 0 and lab.max() < edge["topics"]
+        eng.generate_synthetic(500, 400, 20_000, seed=2)
+        with pytest.raises(amd.DeviceError, match="topical"):
+            eng.synthetic_dominant_topics()
 
     def overlap_cv(X):
         Xb = (X[:600] > 0).astype(np.float64)
