@@ -1571,6 +1571,16 @@ def test_schedule_knobs_do_not_change_results(amd):
                 np.testing.assert_array_equal(U, U0, err_msg="%s=%s" % (knob, val))
                 np.testing.assert_array_equal(V, V0, err_msg="%s=%s" % (knob, val))
             del os.environ[knob]
+        # PLSA_ROW_XCD (round-5 experiment knob): XCD x walks the x-th eighth of the documents.  Rows are owned by one
+        # group whatever the schedule -> factors bit-identical; the likelihood's per-workgroup partials are added in
+        # another order -> equal to float64 rounding
+        os.environ["PLSA_ROW_XCD"] = "1"
+        reset_engines()
+        for (X, k, kw), (U0, V0, i0) in zip(cases, ref):
+            U, V, info = amd.plsa_fit(X, k, np.ones(X.shape[0], np.float32), return_info=True, **kw)
+            assert info["n_iter"] == i0["n_iter"]
+            np.testing.assert_allclose(info["log_likelihood_trace"], i0["log_likelihood_trace"], rtol=1e-6)
+            np.testing.assert_array_equal(U, U0); np.testing.assert_array_equal(V, V0)
     finally:
         os.environ.clear(); os.environ.update(saved)
         reset_engines()
