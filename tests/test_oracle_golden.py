@@ -280,3 +280,24 @@ def test_cfg1_shape_reference_run_is_reproduced_bit_for_bit(oracle):
     assert 1e-4 < gap_v < 2e-2, gap_v
     assert gap_u < 1e-3, gap_u               # measured 1.6e-3 (P(w|z)), 1.1e-4 (P(z|d))
     assert 1e-4 < gap_ll < 1e-2, gap_ll      # measured 3.4e-3: the float32 running sum of 2.9 M log terms
+
+
+@pytest.mark.parametrize("case", ["fit_k8_tol0", "fit_k20_50it", "fit_k16_mid", "fit_k4_weighted", "fit_k5_earlystop"])
+def test_numba_compiled_fixtures_belong_to_these_inputs(oracle, case):
+    """tests/golden/numba_small.npz holds what the reference computes when COMPILED by numba (fastmath, parallel;
+    tests/golden/numba_reference.py, build container).  The strict oracle, run from the same initial factors, must sit at
+    exactly the recorded distance from it (the oracle IS the sequential source semantics, bit for bit) and stop at the same
+    iteration: the fixture belongs to these inputs, and compilation moves the reference by 2e-7 ... 2e-5 here."""
+    g = load_golden(case)
+    nb = load_golden("numba_small")
+    X = golden_csr(g)
+    r, c, v = coo_arrays(X)
+    sw = g["sw"].astype(np.float32)
+    U, V = g["U0"].copy(), g["V0"].copy()
+    _, _, trace, iters = oracle.plsa_fit_inner(r, c, v, V, U, sw, n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]),
+                                               tolerance=float(g["tol"]), e_step_thresh=float(g["thresh"]),
+                                               use_sample_weights=bool(np.any(sw != 1.0)), return_trace=True)
+    assert iters == int(nb[case + "__iters"]) == int(g["iters"])
+    assert abs(peak_rel(nb[case + "__U"], U) - float(nb[case + "__dev_from_sequential_U"])) < 1e-12
+    assert abs(peak_rel(nb[case + "__V"], V) - float(nb[case + "__dev_from_sequential_V"])) < 1e-12
+    assert float(nb[case + "__dev_from_sequential_U"]) < 5e-5 and float(nb[case + "__dev_from_sequential_V"]) < 5e-5

@@ -7,6 +7,8 @@ states (needs a real MI355X: -m gpu).  What is compared with what (round 5):
               schedules) == n64 == wide [asserted]; strict on 1 thread and on N threads [recorded: the reference's float32
               log-likelihood carries an error larger than the tolerance there]
             * the reference's OWN output, 2 iterations (tests/golden/fit_cfg1_shape.npz)                        [asserted]
+            * the reference COMPILED BY NUMBA (tests/golden/numba_cfg1.npz): 50 iterations, and its default-tolerance
+              stop iteration on 1 / 2 / 4 / 8 threads (61 on all) == HIP's                                      [asserted]
   config 2  synthetic CSR 100 k x 50 k, 10 M nnz, k = 32       3 iterations, both schedules vs strict / n64 / wide
   config 3  1 M x 100 k, 100 M nnz, k = 64: the WHOLE corpus, 2 iterations, both schedules vs n64               [asserted]
             (the first 150 000 documents vs strict / wide stay as the quick check)
@@ -282,6 +284,53 @@ def test_cfg1_reference_run(amd, oracles):
         for f in ("U", "V"):
             assert vs_ref[f] <= 1.5 * ref_vs_exact[f] + 2e-5, (sched, f, vs_ref, ref_vs_exact)
         assert vs_ref["ll_rel"] <= 1.5 * ref_vs_exact["ll_rel"] + 1e-5, (sched, vs_ref, ref_vs_exact)
+
+
+def test_cfg1_numba_compiled_reference(amd, oracles):
+    """The reference AS COMPILED BY NUMBA (fastmath, parallel prange; tests/golden/numba_reference.py runs it in the build
+    container) at BASELINE config 1's exact corpus: 50 EM iterations from RandomState(42), and the iteration a
+    default-tolerance fit stops at on 1 / 2 / 4 / 8 threads.  Asserted: (i) HIP stops at the iteration the compiled
+    reference stops at, whatever its thread count (61: numba's SIMD-vectorised float32 likelihood is accurate enough there;
+    the strictly sequential float32 sum of the reference's SOURCE semantics stops at 71, see
+    test_config1_default_tolerance_stops_where_the_oracle_stops); (ii) after 50 iterations HIP is no further from the
+    compiled reference than the compiled reference is from exact arithmetic (its float32 norm_pwz running sum), and the
+    compiled reference sits where the strict oracle sits (2e-5: compilation moves it that little at this size)."""
+    from conftest import load_golden, peak_rel
+    g = load_golden("numba_cfg1")
+    X = corpus(amd, CONFIG1)
+    n, m = X.shape
+    k = int(g["k"])
+    cols = g["V_cols"]
+    r, c, v = coo_arrays(X)
+    U0, V0 = host_init(n, m, k, int(g["fit_seed"]))
+    ones = np.ones(n, np.float32)
+    Uw, Vw = U0.copy(), V0.copy()
+    _, _, tw, _ = oracles["wide"].plsa_fit_inner(r, c, v, Vw, Uw, ones, n_iter=50, n_iter_per_test=10, tolerance=0.0,
+                                                 e_step_thresh=1e-32, return_trace=True)
+    ref_vs_exact = {"U": peak_rel(g["U50"], Uw), "V": peak_rel(g["V50_sample"], Vw[:, cols]), "ll_rel": ll_rel(g["ll50"], tw)}
+    stops_ref = {int(t): int(s) for t, s in zip(g["stop_iteration_threads"], g["stop_iteration"])}
+    rec = REPORT.setdefault("config1_numba_compiled_reference", {
+        "numba_version": str(g["numba_version"]), "reference_vs_exact_after_50_iterations": ref_vs_exact,
+        "reference_default_tolerance_stop_iteration_by_threads": stops_ref})
+    assert len(set(stops_ref.values())) == 1
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
+            eng.set_factors(U0, V0)
+            iters, trace = eng.fit(None, n_iter=50, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=flags, trace=True)
+            U, V = eng.get_factors()
+            assert iters == 50
+            vs_ref = {"U": peak_rel(U, g["U50"]), "V": peak_rel(V[:, cols], g["V50_sample"]),
+                      "V_rowsum": float(np.abs(V.astype(np.float64).sum(axis=1) - g["V50_rowsum64"]).max()),
+                      "ll_rel": ll_rel(trace, g["ll50"])}
+            eng.set_factors(U0, V0)
+            stop, _ = eng.fit(None, n_iter=100, n_iter_per_test=10, tolerance=1e-3, e_step_thresh=1e-32, flags=flags)
+            rec[sched] = {"vs_compiled_reference_after_50_iterations": vs_ref, "default_tolerance_stop_iteration": int(stop)}
+            _flush_report()
+            assert stop == stops_ref[1], (sched, stop, stops_ref)
+            for f in ("U", "V"):
+                assert vs_ref[f] <= 1.5 * ref_vs_exact[f] + 2e-5, (sched, f, vs_ref, ref_vs_exact)
+            assert vs_ref["ll_rel"] <= 1.5 * ref_vs_exact["ll_rel"] + 1e-5, (sched, vs_ref, ref_vs_exact)
 
 
 def test_config2_fit_vs_oracle(amd, oracles):
