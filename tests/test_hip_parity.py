@@ -265,13 +265,16 @@ def test_kernels_vs_oracle_midsize(amd, oracle, k):
              np.array([oracle.log_likelihood(r, c, v, Vo, Uo, ones)]))
 
 
-@pytest.mark.parametrize("traversal", ["flat", "documents", "document_items", "document_items_auto"])
+@pytest.mark.parametrize("traversal", ["flat", "flat_unpacked", "documents", "document_items", "document_items_auto"])
 def test_e_step_traversals_agree_with_reference_and_oracle(amd, oracle, monkeypatch, traversal):
     """The E-step has two traversals, picked by corpus size (one group per non-zero; one group per
     document or document piece).  Both are forced here on the reference goldens and on seeded
-    shapes with empty, single-entry and very long documents; the two must agree bit for bit."""
-    monkeypatch.setenv("PLSA_E_ROWS", "0" if traversal == "flat" else "1")
-    monkeypatch.setenv("PLSA_E_SEG", {"flat": "0", "documents": "0", "document_items": "16",
+    shapes with empty, single-entry and very long documents; the two must agree bit for bit.  The flat
+    traversal deals (entry, chunk) slots to the lanes row-major when the topic count leaves lanes of a
+    group idle (k = 10, 20, 23, 27: 3 / 5 / 6 / 7 chunks; `flat_unpacked` switches that off): same bits."""
+    monkeypatch.setenv("PLSA_E_ROWS", "0" if traversal.startswith("flat") else "1")
+    monkeypatch.setenv("PLSA_E_PACKED", "0" if traversal == "flat_unpacked" else "1")
+    monkeypatch.setenv("PLSA_E_SEG", {"flat": "0", "flat_unpacked": "0", "documents": "0", "document_items": "16",
                                       "document_items_auto": "-1"}[traversal])
     results = []
     with amd.Engine() as eng:
@@ -284,7 +287,8 @@ def test_e_step_traversals_agree_with_reference_and_oracle(amd, oracle, monkeypa
             np.testing.assert_allclose(P, g["P"], rtol=2e-6, atol=1e-9)
         rs = np.random.RandomState(11)
         for n, m, k, thresh in ((700, 900, 64, 1e-32), (300, 500, 20, 1e-6), (1200, 300, 33, 1e-32),
-                                (50, 4000, 128, 1e-32), (2000, 100, 3, 1e-4), (400, 600, 200, 1e-32)):
+                                (50, 4000, 128, 1e-32), (2000, 100, 3, 1e-4), (400, 600, 200, 1e-32),
+                                (500, 700, 10, 1e-32), (350, 450, 23, 1e-5), (260, 640, 27, 1e-32), (333, 777, 20, 0.0)):
             X = _corpus(n, m, 0.03, seed=n + k, empty_rows=min(5, n // 10)).tolil()
             X[1, :] = 1.0                                  # a document holding the whole vocabulary
             X[2, :] = 0.0; X[2, m // 2] = 3.0              # a single-entry document

@@ -20,10 +20,14 @@ ap.add_argument("--flags", default="fused")
 ap.add_argument("--events", action="store_true")
 ap.add_argument("--estep", action="store_true", help="time the materialising E-step kernel instead of fits")
 ap.add_argument("--tag", default="")
+ap.add_argument("--shape", default="", help="n,m,nnz,k of a synthetic corpus instead of a BASELINE config")
 ap.add_argument("--per-test", type=int, default=10, help="n_iter_per_test of the timed fit (a likelihood test = one host round trip)")
 ap.add_argument("--no-zero-arm", action="store_true", help="stop test without the `change == 0` arm (timing experiments)")
 a = ap.parse_args()
 cfg = bench.CONFIGS[a.config]
+if a.shape:
+    n_, m_, nnz_, k_ = (int(float(x)) for x in a.shape.split(","))
+    cfg = dict(n=n_, m=m_, nnz=nnz_, k=k_)
 eng = Engine(0)
 nnz = eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], seed=0)
 U0, V0 = bench.init_factors(cfg["n"], cfg["m"], cfg["k"], 42)
