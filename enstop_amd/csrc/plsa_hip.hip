@@ -92,7 +92,6 @@ struct plsa_ctx {
     int row_lpn = 1, row_ch = 1;     // lane shape of the DOCUMENT pass (may differ from lpn / ch: see set_shape)
     bool row_shape_8x2 = true;       // PLSA_ROW_SHAPE=0: document pass in the common shape
     int e_rows = -1;               // E-step traversal: 1 document-owned, 0 one group per non-zero, -1 by size (PLSA_E_ROWS)
-    bool e_packed = true;          // flat E-step of a topic count that leaves lanes idle (k = 20: 5 chunks in 8 lanes): packed slots (PLSA_E_PACKED)
     int mt_streams = 256;          // pieces the MT19937 init stream is cut into (PLSA_MT_STREAMS; 1 = sequential)
     i64 mt_min_blocks = 4096;      // ... once it is at least this many 624-word blocks long (PLSA_MT_MIN_BLOCKS)
     int heavy_items = 32, n_heavy = 0;
@@ -772,20 +771,6 @@ int run_e_step(plsa_ctx *c, float thresh) {
         CHK(ensure_rowidx(c));
         const i64 tiles = (c->nnz + 63) / 64;
         const int grid = grid_for(c, tiles, 4);
-        // topic counts that leave lanes of the group idle (k = 20: 5 of 8, k = 10: 3 of 4) deal the tile's
-        // (entry, chunk) slots to the lanes row-major instead: plsa_kernels.hpp, k_e_step_packed (same bits)
-        const int chunks = c->kp / 4;
-        const bool packed = c->e_packed && c->ch == 1 && chunks != c->lpn && thresh >= plsa::TINY_THRESH &&
-                            (chunks == 3 || (chunks >= 5 && chunks <= 7));
-        if (packed) {
-            Scope s(c, "k_e_step");
-#define PLSA_PACKED(C, L)                                                                                            \
-            if (chunks == C)                                                                                         \
-                hipLaunchKernelGGL((plsa::k_e_step_packed<C, L>), dim3(grid), dim3(256), 0, c->stream, c->rowidx.as<int>(),  \
-                                   c->col, c->nnz, c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(), p_base(c), thresh);
-            PLSA_PACKED(3, 4) PLSA_PACKED(5, 8) PLSA_PACKED(6, 8) PLSA_PACKED(7, 8)
-#undef PLSA_PACKED
-        } else
         CHK(dispatch_shape(c, [&](auto S) {
             Scope s(c, "k_e_step");
             auto go = [&](auto TN) {
@@ -1232,7 +1217,6 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_CHUNKS_PER_LANE")) c->chunks_per_lane = atoi(s);
     if (const char *s = getenv("PLSA_E_ROWS")) c->e_rows = atoi(s);
     if (const char *s = getenv("PLSA_E_SEG")) c->eseg_override = atoi(s);
-    if (const char *s = getenv("PLSA_E_PACKED")) c->e_packed = atoi(s) != 0;
     if (const char *s = getenv("PLSA_MT_STREAMS")) c->mt_streams = std::max(1, std::min(4096, atoi(s)));
     if (const char *s = getenv("PLSA_MT_MIN_BLOCKS")) c->mt_min_blocks = std::max(1, atoi(s));
     if (const char *s = getenv("PLSA_SMALL_GRID")) c->small_grid = std::max(0, atoi(s));

@@ -257,81 +257,6 @@ __global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step(const int *__restric
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_e_step_packed: the flat E-step for topic counts whose C = kp/4 chunks do not fill a power-of-two
-// lane group (k = 20: 5 chunks in an 8-lane group, 3 of 8 lanes idle in every gather, product and
-// store of k_e_step; k = 10: 3 in 4).  A wave still takes a tile of 64 consecutive non-zeros, but
-// the tile's 64*C (entry, chunk) slots are dealt to the lanes in ROW-MAJOR order, slot s = lane + 64 i
-// <-> entry s / C, chunk s % C: no idle lane, and slot s of the tile is float4 number s of the tile's
-// P rows, so every store instruction of the wave writes 1024 contiguous, line-aligned bytes (k = 20:
-// k_e_step writes 8 rows of 80 bytes with holes in the lane mask).  The C partial sums of an entry
-// meet through LDS; the norm is added in the SAME order as group_sum's butterfly over the LPN-lane
-// group (tree_sum: the pad lanes' exact zeros drop out), so P is bit-identical to k_e_step's.
-// Thresholds below TINY_THRESH keep k_e_step (no rescue here).
-// ------------------------------------------------------------------------------------------------
-template <int C, int LO, int LEN>
-__device__ __forceinline__ float tree_sum(const float (&p)[C]) {
-    if constexpr (LEN == 1) {
-        return p[LO];
-    } else {
-        constexpr int H = LEN / 2;
-        if constexpr (LO + H >= C) return tree_sum<C, LO, H>(p);
-        else return tree_sum<C, LO, H>(p) + tree_sum<C, LO + H, H>(p);
-    }
-}
-
-template <int C, int LPN>
-__global__ __launch_bounds__(256, PLSA_WAVES) void k_e_step_packed(const int *__restrict__ rowidx,
-                                                       const int *__restrict__ colidx, i64 nnz,
-                                                       const float *__restrict__ U,
-                                                       const float *__restrict__ Vt, float *__restrict__ P,
-                                                       float thresh) {
-    constexpr int KP = 4 * C;
-    __shared__ float part[4][64 * C];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    float *mypart = part[wave];
-    const i64 tiles = (nnz + 63) >> 6;
-    for (i64 t = (i64)blockIdx.x * 4 + wave; t < tiles; t += (i64)gridDim.x * 4) {
-        const i64 base = t << 6;
-        const i64 mine = base + lane;
-        const int d_l = mine < nnz ? __builtin_nontemporal_load(rowidx + mine) : 0;
-        const int w_l = mine < nnz ? __builtin_nontemporal_load(colidx + mine) : 0;
-        float4 u[C][1], vt[C][1], keep[C][1];
-#pragma unroll
-        for (int i = 0; i < C; ++i) {
-            const unsigned s = (unsigned)lane + 64u * i;
-            const unsigned e = s / (unsigned)C, c = s - e * (unsigned)C;
-            const int d = __shfl(d_l, (int)e, 64);
-            const int w = __shfl(w_l, (int)e, 64);
-            u[i][0] = ld4(U + (i64)d * KP + 4 * c);
-            vt[i][0] = ld4(Vt + (i64)w * KP + 4 * c);
-        }
-#pragma unroll
-        for (int i = 0; i < C; ++i) {
-            float unth;
-            mypart[lane + 64 * i] = products<1, false>(u[i], vt[i], thresh, keep[i], unth);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float p[C];
-#pragma unroll
-        for (int j = 0; j < C; ++j) p[j] = mypart[lane * C + j];     // lane = entry of the tile
-        const float inv = inv_norm(tree_sum<C, 0, LPN>(p));
-        float *prow = P + base * KP;
-#pragma unroll
-        for (int i = 0; i < C; ++i) {
-            const unsigned s = (unsigned)lane + 64u * i;
-            const float iv = __shfl(inv, (int)(s / (unsigned)C), 64);
-            float4 q;
-            q.x = keep[i][0].x * iv; q.y = keep[i][0].y * iv; q.z = keep[i][0].z * iv; q.w = keep[i][0].w * iv;
-            st4_nt(prow + 4 * s, q);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // Document-owned E-step: a group keeps its document's P(z|d) row in registers and walks the
 // document's non-zeros (same traversal as k_row_pass: rows in descending-length order, or row items
 // for corpora with few long documents), so the only gathers are the P(w|z) rows and the (doc) index

@@ -265,16 +265,14 @@ def test_kernels_vs_oracle_midsize(amd, oracle, k):
              np.array([oracle.log_likelihood(r, c, v, Vo, Uo, ones)]))
 
 
-@pytest.mark.parametrize("traversal", ["flat", "flat_unpacked", "documents", "document_items", "document_items_auto"])
+@pytest.mark.parametrize("traversal", ["flat", "documents", "document_items", "document_items_auto"])
 def test_e_step_traversals_agree_with_reference_and_oracle(amd, oracle, monkeypatch, traversal):
     """The E-step has two traversals, picked by corpus size (one group per non-zero; one group per
     document or document piece).  Both are forced here on the reference goldens and on seeded
-    shapes with empty, single-entry and very long documents; the two must agree bit for bit.  The flat
-    traversal deals (entry, chunk) slots to the lanes row-major when the topic count leaves lanes of a
-    group idle (k = 10, 20, 23, 27: 3 / 5 / 6 / 7 chunks; `flat_unpacked` switches that off): same bits."""
-    monkeypatch.setenv("PLSA_E_ROWS", "0" if traversal.startswith("flat") else "1")
-    monkeypatch.setenv("PLSA_E_PACKED", "0" if traversal == "flat_unpacked" else "1")
-    monkeypatch.setenv("PLSA_E_SEG", {"flat": "0", "flat_unpacked": "0", "documents": "0", "document_items": "16",
+    shapes with empty, single-entry and very long documents; the two must agree bit for bit.  Topic
+    counts that leave lanes of a group idle (k = 10, 20, 23, 27: 3 / 5 / 6 / 7 chunks in 4 / 8 lanes) are among the shapes."""
+    monkeypatch.setenv("PLSA_E_ROWS", "0" if traversal == "flat" else "1")
+    monkeypatch.setenv("PLSA_E_SEG", {"flat": "0", "documents": "0", "document_items": "16",
                                       "document_items_auto": "-1"}[traversal])
     results = []
     with amd.Engine() as eng:

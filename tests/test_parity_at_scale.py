@@ -9,6 +9,8 @@ states (needs a real MI355X: -m gpu).  What is compared with what (round 5):
             * the reference's OWN output, 2 iterations (tests/golden/fit_cfg1_shape.npz)                        [asserted]
             * the reference COMPILED BY NUMBA (tests/golden/numba_cfg1.npz): 50 iterations, and its default-tolerance
               stop iteration on 1 / 2 / 4 / 8 threads (61 on all) == HIP's                                      [asserted]
+            * refit (PLSA.transform's loop: 50 iterations, test every 5, tolerance 0.005, never stops early) of
+              P(z|d) against fixed topics, both schedules vs strict / n64 / wide                                [asserted]
   config 2  synthetic CSR 100 k x 50 k, 10 M nnz, k = 32       3 iterations, both schedules vs strict / n64 / wide
   config 3  1 M x 100 k, 100 M nnz, k = 64: the WHOLE corpus, 2 iterations, both schedules vs n64               [asserted]
             (the first 150 000 documents vs strict / wide stay as the quick check)
@@ -331,6 +333,55 @@ def test_cfg1_numba_compiled_reference(amd, oracles):
             for f in ("U", "V"):
                 assert vs_ref[f] <= 1.5 * ref_vs_exact[f] + 2e-5, (sched, f, vs_ref, ref_vs_exact)
             assert vs_ref["ll_rel"] <= 1.5 * ref_vs_exact["ll_rel"] + 1e-5, (sched, vs_ref, ref_vs_exact)
+
+
+def test_config1_refit_vs_oracle(amd, oracles):
+    """SURVEY.md 8f-1 at a BASELINE size: `PLSA.transform` / the refit step of `ensemble_fit` (plsa.py:923-997,
+    1184-1220; enstop_.py:567) on config 1's corpus -- topics fixed (taken from a 20-iteration fit), P(z|d) re-estimated from
+    the transform's own start (RandomState(42), plsa.py:1214) with ITS loop parameters: 50 iterations, a likelihood test
+    every 5, tolerance 0.005 -- and the loop that never stops early (plsa.py:913).  Both schedules vs strict / n64 / wide."""
+    X = corpus(amd, CONFIG1)
+    n, m = X.shape
+    k = CONFIG1["k"]
+    r, c, v = coo_arrays(X)
+    U0, V0 = host_init(n, m, k, 42)
+    ones = np.ones(n, np.float32)
+    kw = dict(n_iter=50, n_iter_per_test=5, tolerance=0.005, e_step_thresh=1e-32)
+    rec = REPORT.setdefault("config1_refit", {"shape": [n, m], "nnz": int(X.nnz), "k": k, **kw})
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        eng.set_factors(U0, V0)
+        eng.fit(None, n_iter=20, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=amd.PLSA_FUSED)
+        _, topics = eng.get_factors()
+        topics = np.ascontiguousarray(topics, np.float32)
+        rs = np.random.RandomState(42)                                   # plsa.py:978-981: rand(n, k), rows normalised
+        Ut = rs.rand(n, k)
+        Ut /= Ut.sum(axis=1, keepdims=True)
+        Ut = Ut.astype(np.float32)
+        ref = {}
+        for variant in ("strict", "n64", "wide"):
+            t0 = time.time()
+            U = Ut.copy()
+            _, trace, iters = oracles[variant].plsa_refit_inner(r, c, v, topics, U, ones, return_trace=True, **kw)
+            ref[variant] = (U, trace, iters)
+            rec.setdefault("oracle_seconds", {})[variant] = round(time.time() - t0, 2)
+        rec["strict_vs_wide"] = {"U": errs(ref["strict"][0], ref["wide"][0]), "ll_rel": ll_rel(ref["strict"][1], ref["wide"][1])}
+        for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
+            eng.set_factors(Ut, topics)
+            iters, trace = eng.refit(None, flags=flags, trace=True, **kw)
+            U, V = eng.get_factors()
+            np.testing.assert_array_equal(V, topics)                     # the topics are not touched
+            out = rec.setdefault(sched, {})
+            for variant in ("strict", "n64", "wide"):
+                Uo, tr_o, it_o = ref[variant]
+                assert iters == it_o == 50, (iters, it_o)                # never stops early (plsa.py:913)
+                out["vs_" + variant] = {"U": errs(U, Uo), "ll_rel": ll_rel(trace, tr_o)}
+            _flush_report()
+            e = out["vs_wide"]
+            assert e["U"]["peak_rel"] <= 1e-4 and e["ll_rel"] <= 1e-5, (sched, e)
+            s_, w = out["vs_strict"], rec["strict_vs_wide"]
+            assert s_["U"]["peak_rel"] <= 1.5 * w["U"]["peak_rel"] + 2e-5, (sched, s_, w)
+            assert s_["ll_rel"] <= 1.5 * w["ll_rel"] + 1e-5, (sched, s_, w)
 
 
 def test_config2_fit_vs_oracle(amd, oracles):
