@@ -11,7 +11,10 @@ states (needs a real MI355X: -m gpu).  What is compared with what (round 5):
               stop iteration on 1 / 2 / 4 / 8 threads (61 on all) == HIP's                                      [asserted]
             * refit (PLSA.transform's loop: 50 iterations, test every 5, tolerance 0.005, never stops early) of
               P(z|d) against fixed topics, both schedules vs strict / n64 / wide                                [asserted]
+            * a fit with document weights (plsa_m_step_w_sample_weight), 10 iterations, both schedules             [asserted]
   config 2  synthetic CSR 100 k x 50 k, 10 M nnz, k = 32       3 iterations, both schedules vs strict / n64 / wide
+            * one E-step over all 10 M non-zeros with a threshold inside the products' range: zero pattern of
+              P(z|w,d) identical to the oracle's, entry for entry                                                [asserted]
   config 3  1 M x 100 k, 100 M nnz, k = 64: the WHOLE corpus, 2 iterations, both schedules vs n64               [asserted]
             (the first 150 000 documents vs strict / wide stay as the quick check)
   config 4  ensemble_of_topics(n_runs = 32) on the config-1 corpus: stack == serial members (bitwise), one member vs oracle
@@ -382,6 +385,87 @@ def test_config1_refit_vs_oracle(amd, oracles):
             s_, w = out["vs_strict"], rec["strict_vs_wide"]
             assert s_["U"]["peak_rel"] <= 1.5 * w["U"]["peak_rel"] + 2e-5, (sched, s_, w)
             assert s_["ll_rel"] <= 1.5 * w["ll_rel"] + 1e-5, (sched, s_, w)
+
+
+def test_config1_weighted_fit_vs_oracle(amd, oracles):
+    """SURVEY.md 8a-3 at a BASELINE size: `plsa_m_step_w_sample_weight` (plsa.py:207-310) through the fit loop on config 1's
+    corpus -- document weights in [0.25, 4], a tenth of them exactly 1 and fifty exactly 0 (a weight of zero removes the document
+    from P(w|z) and from the likelihood but not from its own P(z|d), plsa.py:292-300; words that occur in such documents only
+    then make the reference's likelihood NaN, reproduced) -- 10 iterations, both schedules."""
+    X = corpus(amd, CONFIG1)
+    n, m = X.shape
+    k = CONFIG1["k"]
+    r, c, v = coo_arrays(X)
+    U0, V0 = host_init(n, m, k, 42)
+    rs = np.random.RandomState(9)
+    sw = np.exp(rs.uniform(np.log(0.25), np.log(4.0), n)).astype(np.float32)
+    sw[rs.rand(n) < 0.1] = 1.0
+    sw[rs.choice(n, 50, replace=False)] = 0.0
+    kw = dict(n_iter=10, n_iter_per_test=5, tolerance=0.0, e_step_thresh=1e-32)
+    rec = REPORT.setdefault("config1_weighted_fit", {"shape": [n, m], "nnz": int(X.nnz), "k": k, **kw})
+    ref = {}
+    for variant in ("strict", "wide"):
+        U, V = U0.copy(), V0.copy()
+        _, _, trace, iters = oracles[variant].plsa_fit_inner(r, c, v, V, U, sw, use_sample_weights=True, return_trace=True, **kw)
+        ref[variant] = (U, V, trace, iters)
+    fin = ~np.isnan(ref["wide"][2])
+    rec["strict_vs_wide"] = {"U": errs(ref["strict"][0], ref["wide"][0]), "V": errs(ref["strict"][1], ref["wide"][1]),
+                             "ll_rel": ll_rel(ref["strict"][2][fin], ref["wide"][2][fin])}
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
+            eng.set_factors(U0, V0)
+            iters, trace = eng.fit(sw, flags=flags, trace=True, **kw)
+            U, V = eng.get_factors()
+            out = rec.setdefault(sched, {})
+            for variant in ("strict", "wide"):
+                Uo, Vo, tr_o, it_o = ref[variant]
+                assert iters == it_o == 10
+                # a word that occurs in zero-weight documents only loses its whole P(w|z) column in the first M-step; its
+                # entries then contribute x * log(0) * 0 = NaN to the likelihood (plsa.py:380-383) -- in the reference, in the
+                # oracle and here alike: the tests after the first M-step are NaN on every side, the initial one is finite
+                nan_o = np.isnan(tr_o)
+                np.testing.assert_array_equal(np.isnan(trace), nan_o)
+                assert not nan_o[0] and nan_o[1:].all(), tr_o
+                out["vs_" + variant] = {"U": errs(U, Uo), "V": errs(V, Vo), "ll_rel": ll_rel(trace[~nan_o], tr_o[~nan_o]),
+                                        "nan_tests": int(nan_o.sum())}
+            _flush_report()
+            e = out["vs_wide"]
+            assert e["U"]["peak_rel"] <= 1e-4 and e["V"]["peak_rel"] <= 1e-4 and e["ll_rel"] <= 1e-5, (sched, e)
+            s_, w = out["vs_strict"], rec["strict_vs_wide"]
+            for f in ("U", "V"):
+                assert s_[f]["peak_rel"] <= 1.5 * w[f]["peak_rel"] + 2e-5, (sched, f, s_[f], w[f])
+            assert s_["ll_rel"] <= 1.5 * w["ll_rel"] + 1e-5, (sched, s_["ll_rel"], w["ll_rel"])
+
+
+def test_config2_e_step_threshold_pattern(amd, oracles):
+    """SURVEY.md 8a-1 at a BASELINE size: one materialising E-step over ALL of config 2 (10 M non-zeros x 32 topics) with a
+    threshold INSIDE the range of the products (1e-7: about a sixth of them fall below it) -- the strict `>` of plsa.py:98 decided on the
+    float32 product exactly as the reference forms it, so the zero pattern of P(z|w,d) must equal the oracle's entry for entry,
+    rows whose products all fail stay all-zero (plsa.py:103-105), and the kept entries agree to rounding."""
+    X = corpus(amd, CONFIG2)
+    n, m = X.shape
+    k = CONFIG2["k"]
+    r, c, v = coo_arrays(X)
+    U0, V0 = host_init(n, m, k, 42)
+    U0[::1000] = 0.0                                         # documents with an all-zero P(z|d): norm == 0
+    thresh = np.float32(1e-7)
+    Po = np.zeros((X.nnz, k), np.float32)
+    oracles["strict"].plsa_e_step(r, c, v, V0, U0, Po, thresh)
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        eng.set_factors(U0, V0)
+        P = eng.e_step(thresh)
+    zero_o = Po == 0.0
+    mism = int(np.count_nonzero((P == 0.0) != zero_o))
+    rec = REPORT.setdefault("config2_e_step_threshold_pattern", {"shape": [n, m], "nnz": int(X.nnz), "k": k, "thresh": float(thresh)})
+    rec.update(zero_fraction=float(zero_o.mean()), pattern_mismatches=mism,
+               all_zero_rows=int(np.count_nonzero(~(~zero_o).any(axis=1))),
+               max_rel_on_kept=float(np.max(np.abs(P[~zero_o] - Po[~zero_o]) / Po[~zero_o])))
+    _flush_report()
+    assert 0.05 < rec["zero_fraction"] < 0.95, rec           # the threshold really sits inside the products' range
+    assert mism == 0, rec
+    assert rec["all_zero_rows"] > 0 and rec["max_rel_on_kept"] <= 3e-6, rec
 
 
 def test_config2_fit_vs_oracle(amd, oracles):
