@@ -12,6 +12,9 @@ states (needs a real MI355X: -m gpu).  What is compared with what (round 5):
             * refit (PLSA.transform's loop: 50 iterations, test every 5, tolerance 0.005, never stops early) of
               P(z|d) against fixed topics, both schedules vs strict / n64 / wide                                [asserted]
             * a fit with document weights (plsa_m_step_w_sample_weight), 10 iterations, both schedules             [asserted]
+            * the estimator as a user types it: PLSA(n_components=20, random_state=7).fit(X) with every default, then
+              transform of 2 000 documents: stop iteration, components_, embedding_, transformed rows vs the oracle's
+              restatement of the drivers                                                                         [asserted]
   config 2  synthetic CSR 100 k x 50 k, 10 M nnz, k = 32       3 iterations, both schedules vs strict / n64 / wide
             * one E-step over all 10 M non-zeros with a threshold inside the products' range: zero pattern of
               P(z|w,d) identical to the oracle's, entry for entry                                                [asserted]
@@ -436,6 +439,39 @@ def test_config1_weighted_fit_vs_oracle(amd, oracles):
             for f in ("U", "V"):
                 assert s_[f]["peak_rel"] <= 1.5 * w[f]["peak_rel"] + 2e-5, (sched, f, s_[f], w[f])
             assert s_["ll_rel"] <= 1.5 * w["ll_rel"] + 1e-5, (sched, s_["ll_rel"], w["ll_rel"])
+
+
+def test_config1_estimator_with_its_defaults(amd, oracles):
+    """BASELINE configs[0] as a user types it -- `PLSA(n_components=20, random_state=7).fit(X)` on the count matrix (integer
+    counts: `standardize_input` leaves them alone, utils.py:276-280), every default in force (100 iterations, test every 10,
+    tolerance 1e-3, NumPy's MT19937 stream for the initial factors -- drawn on the DEVICE here, bit-identical) -- and then
+    `transform` of 2 000 of the documents with ITS defaults (seed 42, 50 iterations, never stops early).  Against the oracle's
+    restatement of the same drivers (plsa.py:643-730, 923-997, 1117-1220) in n64 / wide arithmetic: same stop iteration,
+    `components_` / `embedding_` / transformed rows within the north-star tolerances."""
+    X = corpus(amd, CONFIG1)
+    n, m = X.shape
+    k = CONFIG1["k"]
+    Xi = X.astype(np.int64)
+    model = amd.PLSA(n_components=k, random_state=7)
+    emb = model.fit_transform(Xi)
+    held = Xi[::9][:2000]
+    emb_t = model.transform(held)
+    rec = REPORT.setdefault("config1_estimator_defaults", {"shape": [n, m], "nnz": int(X.nnz), "k": k})
+    ones = np.ones(n, np.float32)
+    for variant in ("n64", "wide"):
+        o = oracles[variant]
+        U, V, trace, iters = o.plsa_fit(X, k, ones, random_state=7, return_trace=True)
+        Ut, tr_t, it_t = o.plsa_refit(held.astype(np.float32), V, np.ones(held.shape[0], np.float32), n_iter=50,
+                                      n_iter_per_test=5, tolerance=0.001, e_step_thresh=1e-32, random_state=42, return_trace=True)
+        rec["vs_" + variant] = {"stop_iteration": [int(model.n_iter_), int(iters)], "components": errs(model.components_, V),
+                                "embedding": errs(emb, U), "transform": errs(emb_t, Ut)}
+        _flush_report()
+        assert model.n_iter_ == iters, (variant, model.n_iter_, iters)
+        if variant == "wide":
+            e = rec["vs_wide"]
+            assert e["components"]["peak_rel"] <= 1e-4 and e["embedding"]["peak_rel"] <= 1e-4, e
+            assert e["transform"]["peak_rel"] <= 1e-4, e
+    assert emb.dtype == np.float32 and emb.shape == (n, k) and model.components_.shape == (k, m)
 
 
 def test_config2_e_step_threshold_pattern(amd, oracles):
