@@ -16,6 +16,8 @@ states (needs a real MI355X: -m gpu).  What is compared with what (round 5):
               transform of 2 000 documents: stop iteration, components_, embedding_, transformed rows vs the oracle's
               restatement of the drivers                                                                         [asserted]
   config 2  synthetic CSR 100 k x 50 k, 10 M nnz, k = 32       3 iterations, both schedules vs strict / n64 / wide
+            * the document-sharded fit (4 row shards as 4 engines, accumulate / sum / finish per iteration), 6 iterations,
+              vs the oracle's plsa_fit and vs the unsharded fit                                                  [asserted]
             * one E-step over all 10 M non-zeros with a threshold inside the products' range: zero pattern of
               P(z|w,d) identical to the oracle's, entry for entry                                                [asserted]
   config 3  1 M x 100 k, 100 M nnz, k = 64: the WHOLE corpus, 2 iterations, both schedules vs n64               [asserted]
@@ -502,6 +504,32 @@ def test_config2_e_step_threshold_pattern(amd, oracles):
     assert 0.05 < rec["zero_fraction"] < 0.95, rec           # the threshold really sits inside the products' range
     assert mism == 0, rec
     assert rec["all_zero_rows"] > 0 and rec["max_rel_on_kept"] <= 3e-6, rec
+
+
+def test_config2_doc_sharded_fit(amd, oracles):
+    """SURVEY.md 8f-4 at a BASELINE size: the document-sharded single fit (the counterpart of distributed_plsa.py:99-131 --
+    every shard's un-normalised P(w|z) summed, then normalised identically everywhere) on config 2, four row shards of equal
+    nnz as four engines of this process (the exchange goes through the same three ABI calls per iteration the RCCL ranks
+    use; a 1-GPU box cannot host four ranks), 6 iterations with a likelihood test every 2.  Against the oracle's `plsa_fit`
+    (same seed, same NumPy stream) in wide arithmetic, and against the unsharded fit of the same engine."""
+    from enstop_amd.sharded import sharded_plsa_fit
+    X = corpus(amd, CONFIG2)
+    n, m = X.shape
+    k = CONFIG2["k"]
+    kw = dict(n_iter=6, n_iter_per_test=2, tolerance=0.0, e_step_thresh=1e-32)
+    U, V, info = sharded_plsa_fit(X, k, random_state=3, local_shards=4, return_info=True, **kw)
+    Uo, Vo, tr_o, it_o = oracles["wide"].plsa_fit(X, k, np.ones(n, np.float32), random_state=3, return_trace=True, **kw)
+    U1, V1 = amd.plsa_fit(X, k, np.ones(n, np.float32), random_state=3, **kw)
+    nl = min(len(tr_o), len(info["log_likelihood_trace"]))
+    rec = REPORT.setdefault("config2_doc_sharded_fit", {"shape": [n, m], "nnz": int(X.nnz), "k": k, "shards": 4, **kw})
+    rec.update(iterations=[int(info["n_iter"]), int(it_o)],
+               vs_wide={"U": errs(U, Uo), "V": errs(V, Vo), "ll_rel": ll_rel(info["log_likelihood_trace"][:nl], tr_o[:nl])},
+               vs_unsharded={"U": errs(U, U1), "V": errs(V, V1)})
+    _flush_report()
+    assert info["n_iter"] == it_o == 6
+    e = rec["vs_wide"]
+    assert e["U"]["peak_rel"] <= 1e-4 and e["V"]["peak_rel"] <= 1e-4 and e["ll_rel"] <= 1e-5, e
+    assert rec["vs_unsharded"]["U"]["peak_rel"] <= 1e-5 and rec["vs_unsharded"]["V"]["peak_rel"] <= 1e-5, rec["vs_unsharded"]
 
 
 def test_config2_fit_vs_oracle(amd, oracles):
