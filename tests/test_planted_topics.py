@@ -75,3 +75,28 @@ def test_ensemble_topics_finds_the_planted_topics(amd, planted, combination):
     assert K0 <= m_found <= K0 + 3, m_found
     acc, match = matched_accuracy(emb.argmax(axis=1), labels, m_found)
     assert len(set(match.values())) == K0 and acc > 0.8, (acc, match)
+
+
+@pytest.mark.parametrize("combination", ["hellinger", "kl_divergence"])
+def test_baseline_ensemble_configuration_on_a_20ng_shaped_corpus(amd, combination):
+    """BASELINE.json configs[3] through the estimator itself: `EnsembleTopics(n_components=20, n_starts=32)` on a corpus of
+    20-Newsgroups' shape (18 846 x 173 762, 2.9 M non-zeros) -- here with 20 PLANTED topics instead of newsgroups, so there
+    is an answer to check: 32 bootstrapped 50-iteration fits, the 640 x 640 divergence matrix over 173 762 words, the
+    HDBSCAN* leaf clusters, their representatives, the refit of all documents (enstop_.py:417-584).  Exactly the 20 planted
+    topics come back, none split or merged, and > 90 % of the documents sit on their planted topic."""
+    K = 20
+    with amd.Engine() as eng:
+        eng.generate_synthetic(18846, 173762, 2_950_000, seed=5, topics=K, alpha=0.05, background=0.1)
+        X = eng.download_active_csr().astype(np.int64)
+        labels = eng.synthetic_dominant_topics()
+    et = amd.EnsembleTopics(n_components=K, n_starts=32, topic_combination=combination, n_iter=50, n_jobs=4, random_state=1)
+    emb = et.fit_transform(X)
+    found = et.n_components_
+    assert et.components_.shape == (found, X.shape[1]) and emb.shape == (X.shape[0], found)
+    np.testing.assert_allclose(et.components_.sum(axis=1), 1.0, atol=1e-3)
+    from scipy.optimize import linear_sum_assignment
+    C = np.zeros((found, K), np.int64)
+    np.add.at(C, (emb.argmax(axis=1), labels), 1)
+    r, c = linear_sum_assignment(-C)
+    acc = C[r, c].sum() / float(len(labels))
+    assert found == K and len(set(c.tolist())) == K and acc > 0.9, (found, acc)
