@@ -45,6 +45,7 @@ Extra objects in the JSON line:
   other_configs (N = 1, --config 3) every other BASELINE.json configuration in compact form, each with steps /
                 ms_per_step: config1, config2, config5 (EM iterations/s + k_e_step roofline fraction),
                 ensemble_20ng_shape (configs[3]: 32 members through enstop_amd.ensemble_of_topics, fits/min),
+                ensemble_topics_estimator_20ng_shape (configs[3] through EnsembleTopics itself, planted topics: wall + outcome),
                 config3_topical (config 3's shape on a corpus WITH co-occurrence structure)
   hot_kernels   per hot kernel: VGPRs / waves per SIMD / LDS (hipcc's own remarks, captured when the library was
                 built: enstop_amd/kernel_resources.json) and traffic_ratio = counter bytes / algorithmic bytes
@@ -246,6 +247,39 @@ def ensemble_20ng_shape(eng, seed, n_runs=32, n_jobs=4):
             "path": "enstop_amd.ensemble_of_topics(X_host, 20, n_runs=32, n_iter=50, tolerance=0, n_jobs=4): upload + per member "
                     "(device bootstrap gather, CSC / item build, MT19937 init on the device, fit, D2D into the stack) + one copy "
                     "of the stack to the host; median of three calls"}
+
+
+def ensemble_topics_estimator_20ng_shape(eng, seed, n_starts=32):
+    """BASELINE configs[3] through the ESTIMATOR: EnsembleTopics(n_components=20, n_starts=32).fit_transform on a corpus of the
+    20NG shape with 20 planted topics (so the outcome can be checked, not only timed): the 32 bootstrapped 50-iteration fits,
+    the all-pairs Hellinger matrix of the 640 topics, the HDBSCAN* leaf clusters, their representatives, the refit of every
+    document (enstop_.py:417-584).  Wall clock of the whole call; median of three."""
+    import enstop_amd
+    from scipy.optimize import linear_sum_assignment
+    cfg = CONFIGS[4]
+    eng.release_scratch()
+    eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], seed=seed + 5, topics=cfg["k"], alpha=0.05, background=0.1)
+    X = eng.download_active_csr().astype(np.int64)
+    labels = eng.synthetic_dominant_topics()
+    walls, found, acc = [], None, None
+    for _ in range(4):                                       # the first call warms the member contexts up
+        et = enstop_amd.EnsembleTopics(n_components=cfg["k"], n_starts=n_starts, topic_combination="hellinger",
+                                       n_iter=FITS_ITERS, n_jobs=4, random_state=seed + 1)
+        t0 = time.perf_counter()
+        emb = et.fit_transform(X)
+        walls.append(time.perf_counter() - t0)
+        found = int(et.n_components_)
+        C = np.zeros((found, cfg["k"]), np.int64)
+        np.add.at(C, (emb.argmax(axis=1), labels), 1)
+        r_, c_ = linear_sum_assignment(-C)
+        acc = float(C[r_, c_].sum()) / len(labels)
+    wall = sorted(walls[1:])[1]
+    return {"workload": "EnsembleTopics(n_components=20, n_starts=32, topic_combination='hellinger', n_iter=50) on a 20NG-shaped "
+                        "corpus with 20 planted topics (%d x %d, %d nnz)" % (X.shape[0], X.shape[1], X.nnz),
+            "fits": n_starts, "steps": n_starts * FITS_ITERS, "wall_s": round(wall, 4), "walls_s": [round(w, 4) for w in walls[1:]],
+            "ms_per_step": round(wall / (n_starts * FITS_ITERS) * 1e3, 5), "value": round(n_starts / wall * 60.0, 1),
+            "unit": "member fits/min, topic combination and refit of all documents included",
+            "topics_found": found, "topics_planted": cfg["k"], "documents_on_their_planted_topic": round(acc, 4)}
 
 
 def ensemble_leg(eng, comm, k, world, rank, args, rccl_init_s):
@@ -750,6 +784,7 @@ def main():
             out["cpu_baseline"]["whole_config2"] = c2["cpu_baseline"]
         leg("config1", lambda: quick_config(eng, 1, args.steps, args.warmup, args.seed, min_steps=1000))
         leg("ensemble_20ng_shape", lambda: ensemble_20ng_shape(eng, args.seed))
+        leg("ensemble_topics_estimator_20ng_shape", lambda: ensemble_topics_estimator_20ng_shape(eng, args.seed))
         leg("config3_topical", lambda: quick_config(eng, 3, args.steps, args.warmup, args.seed, e_step=False, min_steps=50,
                                                     corpus_kw=dict(TOPICAL), pass_times=True))
         from enstop_amd.engine import reset_engines as _reset
