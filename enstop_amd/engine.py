@@ -96,6 +96,12 @@ class Engine:
         """X: scipy CSR (any dtype; values are cast to float32 like plsa.py:714)."""
         X = X.tocsr()
         n, m = X.shape
+        # the device layout is the reference's: int32 row pointers / indices (plsa.py:26 `i4[::1]`, its loop counters are
+        # uint32).  scipy switches to int64 index arrays on its own for large matrices: refuse what does not fit
+        # instead of letting the cast below wrap around
+        if X.nnz > 2**31 - 64 or max(n, m) >= 2**31 - 1:
+            raise ValueError("matrix too large for 32-bit indices: %d x %d with %d stored entries (limit 2^31 - 64 entries)"
+                             % (n, m, X.nnz))
         indptr = np.ascontiguousarray(X.indptr, dtype=np.int32)
         indices = np.ascontiguousarray(X.indices, dtype=np.int32)
         data = _f32(X.data)

@@ -423,6 +423,41 @@ def test_duplicate_coo_entries_are_separate_nonzeros(amd, oracle):
     np.testing.assert_allclose(Uh, Uo, rtol=1e-5, atol=1e-9)
 
 
+def test_stored_zeros_and_unsorted_rows(amd, oracle):
+    """Input formats either side of the path.  `X.tocoo()` (plsa.py:714) hands the reference whatever the CSR stores, in
+    the stored order: explicitly stored zero counts stay entries (their responsibilities are computed, they add exactly
+    nothing to either factor or to the likelihood), and rows whose column indices are not sorted are walked as stored.
+    Both schedules and the estimator follow the oracle on such a matrix; a CSC or dense copy of the same data gives
+    the result of its own CSR conversion (sorted rows: same factors to rounding)."""
+    rs = np.random.RandomState(12)
+    X = sp.random(260, 180, density=0.08, format="csr", random_state=rs, dtype=np.float32)
+    X.data = np.ceil(X.data * 4).astype(np.float32)
+    X = X[np.diff(X.indptr) > 0].tocsr()
+    X.data[rs.rand(X.nnz) < 0.15] = 0.0                     # stored zeros (kept: no eliminate_zeros())
+    X.data[X.indptr[:-1]] = np.maximum(X.data[X.indptr[:-1]], 1.0)   # ... but no document of zeros only (the estimator drops those)
+    for d in range(0, X.shape[0], 3):                       # every third row in a shuffled stored order
+        a, b = X.indptr[d], X.indptr[d + 1]
+        p = rs.permutation(b - a)
+        X.indices[a:b] = X.indices[a:b][p]; X.data[a:b] = X.data[a:b][p]
+    X.has_sorted_indices = False
+    assert (X.data == 0).sum() > 100 and X.nnz == X.tocoo().nnz
+    n, m = X.shape
+    k = 9
+    ones = np.ones(n, np.float32)
+    kw = dict(n_iter=12, n_iter_per_test=4, tolerance=0.0, e_step_thresh=1e-32, random_state=5)
+    Uo, Vo, trace, iters = oracle.plsa_fit(X, k, ones, return_trace=True, **kw)
+    for mode in MODES.values():
+        U, V, info = amd.plsa_fit(X, k, ones, flags=mode, return_info=True, **kw)
+        assert info["n_iter"] == iters == 12
+        close_factors(U, Uo); close_factors(V, Vo)
+        close_ll(info["log_likelihood_trace"], trace)
+    Xs = X.copy(); Xs.sort_indices()
+    for other in (Xs.tocsc(), Xs.toarray()):                # formats the estimator accepts (check_array, plsa.py:1138)
+        model = amd.PLSA(n_components=k, n_iter=12, n_iter_per_test=4, tolerance=0.0, random_state=5)
+        emb = model.fit_transform(other.astype(np.int64) if not sp.issparse(other) else other.astype(np.int64))
+        close_factors(model.components_, Vo, tol=2e-4); close_factors(emb, Uo, tol=2e-4)
+
+
 @pytest.mark.parametrize("k", [384, 500, 512, 1000, 1024])
 def test_largest_topic_counts_vs_oracle(amd, oracle, k):
     """The widest lane shapes (64 lanes x 2 / 4 chunks; k = 512 and 1024 are FULL shapes, 500 and 1000 are not): both
@@ -1233,6 +1268,15 @@ def test_upload_contract_is_checked_on_the_device(amd):
         assert "corpus" in L.plsa_last_error(h).decode()
         with pytest.raises(ValueError):                        # the Python layer answers the same input before any copy
             eng.upload_csr(sp.csr_matrix((dt, bad, ip), shape=(n, m)))
+        # more stored entries than 32-bit row pointers can address (scipy switches to int64 index arrays by itself there):
+        # refused by name before any cast could wrap around; through the C ABI directly: a status code
+        class Huge:
+            shape, nnz = (n, m), 2**31 + 5
+            def tocsr(self):
+                return self
+        with pytest.raises(ValueError, match="32-bit"):
+            eng.upload_csr(Huge())
+        assert L.plsa_upload_csr(h, ip, ix, dt, n, m, 2**31 + 5) != 0 and "2^31" in L.plsa_last_error(h).decode()
         eng.upload_csr(X)                                      # ... and the context is fine
         eng.set_factors(np.ones((n, 4), np.float32) / 4, np.ones((4, m), np.float32) / m)
         iters, _ = eng.fit(None, n_iter=2, n_iter_per_test=1, tolerance=0.0)
