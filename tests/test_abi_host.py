@@ -183,6 +183,26 @@ def test_estimator_validation_like_reference():
         assert params[key] == val
 
 
+def test_estimators_follow_the_scikit_learn_protocol():
+    """What pipelines, grid searches and joblib do to an estimator of the reference (BaseEstimator + TransformerMixin,
+    plsa.py:1000, enstop_.py:587): `clone` rebuilds it from `get_params`, and it pickles -- unfitted and with fitted
+    attributes; no device handle lives on the object."""
+    import pickle
+    from sklearn.base import clone
+    import enstop_amd
+    for cls in (enstop_amd.PLSA, enstop_amd.EnsembleTopics, enstop_amd.StreamedPLSA, enstop_amd.BlockParallelPLSA,
+                enstop_amd.GPUPLSA):
+        est = cls(n_components=7)
+        assert clone(est).get_params() == est.get_params()
+        assert pickle.loads(pickle.dumps(est)).get_params() == est.get_params()
+        assert hasattr(est, "fit_transform") and hasattr(est, "transform")
+    fitted = enstop_amd.PLSA(n_components=3)
+    fitted.components_ = np.full((3, 5), 0.2, np.float32)
+    fitted.embedding_ = np.full((4, 3), 1 / 3, np.float32)
+    back = pickle.loads(pickle.dumps(fitted))
+    np.testing.assert_array_equal(back.components_, fitted.components_)
+
+
 def test_standardize_input():
     from enstop_amd.utils import standardize_input
     Xi = sp.csr_matrix(np.arange(12).reshape(3, 4))
