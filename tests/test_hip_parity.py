@@ -477,6 +477,32 @@ def test_largest_topic_counts_vs_oracle(amd, oracle, k):
         close_factors(U, Uo); close_factors(V, Vo)
 
 
+@pytest.mark.parametrize("mode", list(MODES))
+def test_loop_parameter_corners_vs_oracle(amd, oracle, mode):
+    """Corners of plsa_fit_inner's loop (plsa.py:591-640) the estimator's own validation lets through: no iteration at all,
+    one, two; a test interval longer than the run (the only test is the one after iteration 0, `0 % n == 0`); a tolerance
+    that stops at the first test; and a threshold ABOVE every product -- every responsibility row stays zero
+    (plsa.py:103-105), the M-step then leaves both factors all-zero (norms are 0: plsa.py:196-202) and the likelihood is
+    log(0) = -inf from there on.  Iteration counts, traces (inf included) and factors as the oracle has them."""
+    X = _corpus(150, 120, 0.06, seed=41)
+    ones = np.ones(150, np.float32)
+    for kw in (dict(n_iter=0, n_iter_per_test=10, tolerance=0.001), dict(n_iter=1, n_iter_per_test=10, tolerance=0.0),
+               dict(n_iter=2, n_iter_per_test=1, tolerance=0.0), dict(n_iter=7, n_iter_per_test=50, tolerance=0.0),
+               dict(n_iter=30, n_iter_per_test=3, tolerance=np.inf), dict(n_iter=30, n_iter_per_test=3, tolerance=0.5),
+               dict(n_iter=6, n_iter_per_test=2, tolerance=0.0, e_step_thresh=1.0)):
+        kw = dict(dict(e_step_thresh=1e-32, random_state=8), **kw)
+        Uo, Vo, trace, iters = oracle.plsa_fit(X, 6, ones, return_trace=True, **kw)
+        U, V, info = amd.plsa_fit(X, 6, ones, flags=MODES[mode], return_info=True, **kw)
+        assert info["n_iter"] == iters, (kw, info["n_iter"], iters)
+        got = info["log_likelihood_trace"]
+        q = min(len(got), len(trace))           # the trace may carry the result-neutral test of the last iteration
+        assert q >= len(trace) - 1 and q >= 1, (kw, len(got), len(trace))
+        close_ll(got[:q], trace[:q])
+        close_factors(U, Uo); close_factors(V, Vo)
+        if kw["e_step_thresh"] == 1.0:
+            assert not U.any() and not V.any() and np.isneginf(trace[-1])
+
+
 def test_limits_and_errors(amd):
     X = sp.random(50, 40, density=0.2, format="csr", random_state=0, dtype=np.float32)
     ones = np.ones(50, np.float32)
