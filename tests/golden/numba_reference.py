@@ -10,6 +10,7 @@ is data: inputs are the committed corpus of fit_cfg1_shape.npz, outputs are what
 
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py fixture     -> tests/golden/numba_cfg1.npz
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py small       -> tests/golden/numba_small.npz
+    /opt/conda/bin/python3.9 tests/golden/numba_reference.py blocks      -> tests/golden/numba_block_streamed.npz
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py fuzz [N]    -> compiled reference vs oracle/plsa_oracle.c
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py time        -> compiled reference vs the C port, same cores
 """
@@ -303,6 +304,65 @@ def cmd_time():
     json.dump(rows, open(os.path.join(ROOT, "profiles", "r05_numba_reference_vs_c_port_timing.json"), "w"), indent=1)
 
 
+def blocks_corpus():
+    """Mid-size corpus for the block-parallel / streamed modules: 12 000 documents x 6 000 words, ~60 distinct words per
+    document drawn from a Zipf-like law, counts 1..4.  Built from NumPy's legacy RandomState only (stable across versions)."""
+    import numpy as np
+    import scipy.sparse as sp
+    rs = np.random.RandomState(2026)
+    n, m, per = 12000, 6000, 64
+    w = (m * rs.rand(n * per) ** 3.0).astype(np.int64)                   # heavy head, long tail
+    perm = rs.permutation(m)
+    rows = np.repeat(np.arange(n), per)
+    vals = rs.randint(1, 5, n * per).astype(np.float32)
+    X = sp.csr_matrix((np.ones_like(vals), (rows, perm[w])), shape=(n, m))
+    X.sum_duplicates()                                                   # distinct words per document
+    X.sort_indices()
+    X.data = vals[:X.nnz].copy()
+    return X
+
+
+def cmd_blocks():
+    """enstop/block_parallel_plsa.py and enstop/streamed_plsa.py COMPILED BY NUMBA on a corpus large enough for their own
+    tilings to matter (8 x 8 tiles of 1 500 x 750; 11 blocks of 65 536 non-zeros) -> tests/golden/numba_block_streamed.npz."""
+    import numpy as np
+    numba, ref = numba_env()
+    import enstop.block_parallel_plsa as bp
+    import enstop.streamed_plsa as st
+    X = blocks_corpus()
+    n = X.shape[0]
+    k = 16
+    kw = dict(n_iter=30, n_iter_per_test=10, tolerance=0.0, random_state=17)
+    numba.set_num_threads(min(8, numba.config.NUMBA_NUM_THREADS))
+    t0 = time.time()
+    Ub, Vb = bp.plsa_fit(X, k, n_row_blocks=8, n_col_blocks=8, **kw)
+    t_b = time.time() - t0
+    sw = np.ones(n, np.float32)
+    t0 = time.time()
+    Us, Vs = st.plsa_fit(X, k, sw, block_size=65536, **kw)
+    t_s = time.time() - t0
+    sww = np.exp(np.random.RandomState(4).uniform(-1, 1, n)).astype(np.float32)
+    Usw, Vsw = st.plsa_fit(X, k, sww, block_size=65536, **kw)
+    Up, Vp = ref.plsa_fit(X, k, sw, **kw)
+    held = X[::7]
+    Ut = st.plsa_refit(held, Vs, np.ones(held.shape[0], np.float32), block_size=65536, n_iter=20, n_iter_per_test=5,
+                       tolerance=0.0, random_state=42)
+    out = os.path.join(HERE, "numba_block_streamed.npz")
+    np.savez_compressed(out, indptr=X.indptr.astype(np.int32), indices=X.indices.astype(np.int32), data_u8=X.data.astype(np.uint8),
+                        shape=np.array(X.shape), k=k, n_iter=30, n_iter_per_test=10, fit_seed=17,
+                        U_block=Ub[::4], V_block=Vb, U_streamed=Us[::4], V_streamed=Vs, U_streamed_weighted=Usw[::4],
+                        V_streamed_weighted=Vsw, sample_weight_seed=4, u_stride=4, held_stride=7, U_streamed_refit=Ut[::2],
+                        streamed_equals_plsa_bitwise=bool(np.array_equal(Us, Up) and np.array_equal(Vs, Vp)),
+                        block_vs_plsa=np.array([peak_rel(Ub, Up), peak_rel(Vb, Vp)]))
+    rep = {"shape": [int(v) for v in X.shape], "nnz": int(X.nnz), "k": k, "threads": int(numba.get_num_threads()),
+           "block_parallel_fit_s": round(t_b, 2), "streamed_fit_s": round(t_s, 2),
+           "block_vs_plsa": [peak_rel(Ub, Up), peak_rel(Vb, Vp)], "streamed_vs_plsa": [peak_rel(Us, Up), peak_rel(Vs, Vp)],
+           "fixture_bytes": os.path.getsize(out)}
+    print(json.dumps(rep))
+    with open(os.path.join(ROOT, "profiles", "r05_numba_reference_block_streamed.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "fixture"
     if what == "fixture":
@@ -313,3 +373,5 @@ if __name__ == "__main__":
         cmd_time()
     elif what == "small":
         cmd_small()
+    elif what == "blocks":
+        cmd_blocks()

@@ -1268,6 +1268,43 @@ def test_fit_vs_the_numba_compiled_reference(amd, case):
             assert peak_rel(U, Uc) <= 1e-4 and peak_rel(V, Vc) <= 1e-4, (case, flags, peak_rel(U, Uc), peak_rel(V, Vc))
 
 
+def test_compiled_block_parallel_and_streamed_reference_midsize(amd):
+    """The reference's block-parallel and streamed MODULES as their users run them -- compiled by numba -- on a corpus large
+    enough for their own tilings to matter (12 000 x 6 000, 717 k non-zeros, k = 16, 30 iterations; 8 x 8 tiles, 11 blocks of
+    65 536 non-zeros: tests/golden/numba_block_streamed.npz).  The drop-in functions of the same names sit within 1e-5 of
+    EXACT arithmetic (the oracle's streamed loop, every accumulator float64) and no further from the compiled fits than those
+    are from exact arithmetic themselves: 1.3e-4 for the streamed fit after 30 iterations (its float32 running sums at this
+    size; it equals the compiled plsa.py fit bit for bit), 1.4e-4 / 5.9e-4 more for the block-parallel one (float32 tile sums)."""
+    from oracle.plsa_oracle import Oracle
+    from enstop_amd.block_parallel_plsa import plsa_fit as block_fit
+    from enstop_amd.streamed_plsa import plsa_fit as streamed_fit, plsa_refit as streamed_refit
+    g = load_golden("numba_block_streamed")
+    X = sp.csr_matrix((g["data_u8"].astype(np.float32), g["indices"], g["indptr"]), shape=tuple(int(v) for v in g["shape"]))
+    n, k, st = X.shape[0], int(g["k"]), int(g["u_stride"])
+    kw = dict(n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]), tolerance=0.0, random_state=int(g["fit_seed"]))
+    wide = Oracle(variant="wide")
+    wide.set_threads(8)
+    sww = np.exp(np.random.RandomState(int(g["sample_weight_seed"])).uniform(-1, 1, n)).astype(np.float32)
+    for sw, tag in ((np.ones(n, np.float32), "streamed"), (sww, "streamed_weighted")):
+        Uw, Vw = wide.streamed_plsa_fit(X, k, sw, block_size=65536, **kw)
+        U, V, info = streamed_fit(X, k, sw, block_size=65536, return_info=True, **kw)
+        assert info["n_iter"] == 30
+        assert peak_rel(U, Uw) <= 1e-5 and peak_rel(V, Vw) <= 1e-5, (tag, peak_rel(U, Uw), peak_rel(V, Vw))
+        ref_u, ref_v = peak_rel(g["U_" + tag], Uw[::st]), peak_rel(g["V_" + tag], Vw)      # the compiled fit vs exact arithmetic
+        assert peak_rel(U[::st], g["U_" + tag]) <= 1.5 * ref_u + 2e-5, (tag, peak_rel(U[::st], g["U_" + tag]), ref_u)
+        assert peak_rel(V, g["V_" + tag]) <= 1.5 * ref_v + 2e-5, (tag, peak_rel(V, g["V_" + tag]), ref_v)
+        if tag == "streamed":
+            held = X[::int(g["held_stride"])]
+            Ut = streamed_refit(held, g["V_streamed"], np.ones(held.shape[0], np.float32), block_size=65536, n_iter=20,
+                                n_iter_per_test=5, tolerance=0.0, random_state=42)
+            close_factors(Ut[::2], g["U_streamed_refit"])            # fixed topics: no corpus-long float32 sum in a refit
+            for mode in MODES.values():
+                Ub, Vb = block_fit(X, k, n_row_blocks=8, n_col_blocks=8, flags=mode, **kw)
+                assert peak_rel(Ub, Uw) <= 1e-5 and peak_rel(Vb, Vw) <= 1e-5
+                for a, b, w in ((Ub[::st], g["U_block"], Uw[::st]), (Vb, g["V_block"], Vw)):
+                    assert peak_rel(a, b) <= 1.5 * peak_rel(b, w) + 2e-5, (peak_rel(a, b), peak_rel(b, w))
+
+
 def test_upload_contract_is_checked_on_the_device(amd):
     """include/plsa_hip.h: "indices must be in [0, m), indptr non-decreasing from 0 to nnz".  Straight through the C ABI
     (the Python layer's own ValueError check bypassed): a violation is a non-zero status with a message, nothing stays

@@ -2,6 +2,7 @@
 (tests/golden/make_golden.py).  CPU-only; runs in the build container and on the GPU box."""
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 from conftest import load_golden, golden_csr, coo_arrays, peak_rel
 
@@ -301,3 +302,27 @@ def test_numba_compiled_fixtures_belong_to_these_inputs(oracle, case):
     assert abs(peak_rel(nb[case + "__U"], U) - float(nb[case + "__dev_from_sequential_U"])) < 1e-12
     assert abs(peak_rel(nb[case + "__V"], V) - float(nb[case + "__dev_from_sequential_V"])) < 1e-12
     assert float(nb[case + "__dev_from_sequential_U"]) < 5e-5 and float(nb[case + "__dev_from_sequential_V"]) < 5e-5
+
+
+def _block_streamed_fixture():
+    g = load_golden("numba_block_streamed")
+    X = sp.csr_matrix((g["data_u8"].astype(np.float32), g["indices"], g["indptr"]), shape=tuple(int(v) for v in g["shape"]))
+    return g, X
+
+
+def test_numba_compiled_block_and_streamed_modules_midsize(oracle):
+    """tests/golden/numba_block_streamed.npz: enstop/block_parallel_plsa.py (8 x 8 tiles) and enstop/streamed_plsa.py
+    (11 blocks of 65 536 non-zeros) COMPILED BY NUMBA on a 12 000 x 6 000 corpus (717 k non-zeros, k = 16, 30 iterations;
+    tests/golden/numba_reference.py blocks, build container).  The compiled streamed fit equals the compiled plsa.py fit bit
+    for bit (recorded there); the oracle's block-streamed restatement of the same loop sits within compile-level rounding of
+    it, weights included; the compiled block-parallel fit is itself 1.4e-4 / 5.9e-4 from plsa.py (float32 tile sums)."""
+    g, X = _block_streamed_fixture()
+    assert bool(g["streamed_equals_plsa_bitwise"])
+    n, k, st = X.shape[0], int(g["k"]), int(g["u_stride"])
+    kw = dict(n_iter=int(g["n_iter"]), n_iter_per_test=int(g["n_iter_per_test"]), tolerance=0.0, random_state=int(g["fit_seed"]))
+    U, V = oracle.streamed_plsa_fit(X, k, np.ones(n, np.float32), block_size=65536, **kw)
+    assert peak_rel(U[::st], g["U_streamed"]) < 1e-4 and peak_rel(V, g["V_streamed"]) < 1e-4
+    sww = np.exp(np.random.RandomState(int(g["sample_weight_seed"])).uniform(-1, 1, n)).astype(np.float32)
+    U, V = oracle.streamed_plsa_fit(X, k, sww, block_size=65536, **kw)
+    assert peak_rel(U[::st], g["U_streamed_weighted"]) < 1e-4 and peak_rel(V, g["V_streamed_weighted"]) < 1e-4
+    assert 5e-5 < float(g["block_vs_plsa"][1]) < 2e-3
