@@ -57,6 +57,9 @@ SIGNATURES = {
     "plsa_refit": (C.c_int, [_ctx, _vp, _i32, _i32, C.c_double, C.c_float, _i32, C.POINTER(_i32), _vp,
                              C.POINTER(_i32)]),
     "plsa_em_accumulate": (C.c_int, [_ctx, _vp, C.c_float, _vp]),
+    "plsa_em_accumulate_materialised": (C.c_int, [_ctx, _vp, C.c_float, _vp]),
+    "plsa_p_reserve": (C.c_int, [_ctx, C.c_int64, C.POINTER(C.c_void_p)]),
+    "plsa_p_borrow": (C.c_int, [_ctx, C.c_void_p, C.c_int64]),
     "plsa_em_finish": (C.c_int, [_ctx]),
     "plsa_set_sample_weight": (C.c_int, [_ctx, _vp]),
     "plsa_comm_last_error": (C.c_int, [_ctx, C.c_char_p, _i64]),

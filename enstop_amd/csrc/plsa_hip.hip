@@ -91,6 +91,7 @@ struct plsa_ctx {
     int chunks_per_lane = 2;
     int row_lpn = 1, row_ch = 1;     // lane shape of the DOCUMENT pass (may differ from lpn / ch: see set_shape)
     bool row_shape_8x2 = true;       // PLSA_ROW_SHAPE=0: document pass in the common shape
+    bool p_borrowed = false;       // P(z|w,d) lives in memory lent by plsa_p_borrow (never freed, never re-allocated here)
     int e_rows = -1;               // E-step traversal: 1 document-owned, 0 one group per non-zero, -1 by size (PLSA_E_ROWS)
     int mt_streams = 256;          // pieces the MT19937 init stream is cut into (PLSA_MT_STREAMS; 1 = sequential)
     i64 mt_min_blocks = 4096;      // ... once it is at least this many 624-word blocks long (PLSA_MT_MIN_BLOCKS)
@@ -729,10 +730,15 @@ int run_e_step(plsa_ctx *c, float thresh) {
     {   // the materialised schedule needs the whole nnz x kp array: say so instead of a bare OOM
         const size_t need = sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp;
         size_t free_b = 0, total_b = 0;
-        if (c->P.cap < need && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + c->P.cap < need)
+        if (!c->p_borrowed && c->P.cap < need && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + c->P.cap < need)
             return fail(c, "materialising P(z|w,d) needs %.1f GB but only %.1f GB of HBM are free; use the fused "
-                           "schedule (PLSA_FUSED), which never stores it", need / 1e9, (free_b + c->P.cap) / 1e9);
+                           "schedule (PLSA_FUSED), which never stores it, or tile the documents (plsa_em_accumulate_materialised)", need / 1e9, (free_b + c->P.cap) / 1e9);
     }
+    if (c->p_borrowed) {
+        const size_t need = sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp;
+        if (c->P.cap < need)
+            return fail(c, "the borrowed P(z|w,d) buffer holds %.2f GB, this matrix needs %.2f GB (plsa_p_borrow)", c->P.cap / 1e9, need / 1e9);
+    } else
     // one tile (64 rows) of slack: the last tile is stored without a predicate
     {   // placement experiment knobs: PLSA_P_SLACK_MB over-allocates, PLSA_P_OFFSET_KB shifts the start
         const char *s1 = getenv("PLSA_P_SLACK_MB"), *s2 = getenv("PLSA_P_OFFSET_KB");
@@ -1243,6 +1249,7 @@ void plsa_destroy(plsa_ctx *c) {
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->U[2], &c->Vt[0], &c->Vt[1], &c->Vt[2], &c->Vacc,
                      &c->P, &c->sw, &c->sw_res, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
                      &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp};
+    if (c->p_borrowed) { c->P.p = nullptr; c->P.cap = 0; }      // lent memory is the lender's to free
     for (DevBuf *b : all) release(*b);
     for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
@@ -1612,6 +1619,9 @@ int plsa_e_step(plsa_ctx *c, float thresh, float *P_out) {
 int plsa_set_p(plsa_ctx *c, const float *P) {
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
+    if (c->p_borrowed) {
+        if (c->P.cap < sizeof(float) * (size_t)(c->nnz + 64) * c->kp) return fail(c, "plsa_set_p: the borrowed P(z|w,d) buffer is too small");
+    } else
     CHK(ensure(c, c->P, sizeof(float) * (size_t)(c->nnz + 64) * c->kp + c->p_shift));
     if (c->kp != c->k) HIPCHK(c, hipMemsetAsync(p_base(c), 0, sizeof(float) * (size_t)c->nnz * c->kp, c->stream));
     if (c->nnz)
@@ -2004,6 +2014,52 @@ int plsa_em_accumulate(plsa_ctx *c, const float *sw, float thresh, double *ll_pa
     return 0;
 }
 
+// The reference's kernel SEQUENCE over the local rows (E-step into P(z|w,d), M-step from it) with the accumulate / finish
+// split of the doc-sharded fit: what a doc-block TILE of block_parallel_plsa.py:373-403 does -- responsibilities of the block,
+// partial factors of the block (:182-185) -- with the block's P(z|w,d) alive only inside this call.
+int plsa_em_accumulate_materialised(plsa_ctx *c, const float *sw, float thresh, double *ll_partial) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(need_factors(c));
+    const float *d_sw = nullptr;
+    CHK(upload_sw(c, sw, &d_sw));
+    if (ll_partial) CHK(run_loglik(c, d_sw, ll_partial));       // log-likelihood of the CURRENT factors, local rows
+    CHK(run_e_step(c, thresh));
+    CHK(run_row_pass(c, true, false, nullptr, 0.f, nullptr, nullptr));
+    CHK(run_col_pass(c, true, d_sw, 0.f));                      // partial sums + per-column sums into the accumulator
+    // P(z|w,d) may be another context's by the next call (plsa_p_borrow): its last reader has finished when this returns
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    c->p_valid = false;
+    return 0;
+}
+
+// P(z|w,d) capacity of this context: at least `bytes` (own allocation); *device_ptr = its address.
+int plsa_p_reserve(plsa_ctx *c, int64_t bytes, void **device_ptr) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (bytes <= 0 || !device_ptr) return fail(c, "plsa_p_reserve: bad arguments");
+    if (c->p_borrowed) return fail(c, "plsa_p_reserve: this context borrows its P(z|w,d) buffer");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(ensure(c, c->P, (size_t)bytes));
+    c->p_valid = false;
+    *device_ptr = c->P.p;
+    return 0;
+}
+
+// Use `device_ptr` (memory of the same device that outlives every later call on this context; e.g. another context's
+// plsa_p_reserve) for P(z|w,d) instead of an allocation of one's own; NULL returns to own allocations.  Contexts that
+// share a buffer must not run materialising calls concurrently.
+int plsa_p_borrow(plsa_ctx *c, void *device_ptr, int64_t bytes) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->p_borrowed) release(c->P);
+    c->P.p = device_ptr;
+    c->P.cap = device_ptr ? (size_t)std::max<int64_t>(bytes, 0) : 0;
+    c->p_borrowed = device_ptr != nullptr;
+    c->p_valid = false;
+    c->p_shift = 0;
+    return 0;
+}
+
 int plsa_set_sample_weight(plsa_ctx *c, const float *sw) {
     HIPCHK(c, hipSetDevice(c->device));
     c->sw_resident = false;
@@ -2234,6 +2290,7 @@ int plsa_schedule_info(plsa_ctx *c, int32_t *xcd_lo, double *xcd_end_us, int32_t
 int plsa_release_scratch(plsa_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->p_borrowed) { c->P.p = nullptr; c->P.cap = 0; c->p_borrowed = false; c->p_valid = false; }
     release(c->P); release(c->partial); release(c->tmp0); release(c->tmp1); release(c->tmp2); release(c->cubtmp);
     release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly); release(c->mt_seq);
     // member stack + gather buffers of the ensemble exchange (16 runs x 64 topics x 100 k words = 0.4 GB): re-created

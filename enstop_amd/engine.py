@@ -261,12 +261,29 @@ class Engine:
                            e_step_thresh, flags, trace)
 
     # -- doc-sharded fit building blocks ---------------------------------------------------------------
-    def em_accumulate(self, sample_weight=None, e_step_thresh=1e-32, want_ll=False):
+    def em_accumulate(self, sample_weight=None, e_step_thresh=1e-32, want_ll=False, materialised=False):
+        """materialised: the reference's kernel sequence over this context's rows (E-step into P(z|w,d), M-step from it)
+        instead of the fused passes -- one doc block of a tiled materialised iteration (plsa_em_accumulate_materialised)."""
         sw = None if sample_weight is None else _f32(sample_weight)
         ll = C.c_double(0.0)
-        self._ok(self._L.plsa_em_accumulate(self._h, ptr(sw), np.float32(e_step_thresh),
-                                            C.addressof(ll) if want_ll else None))
+        fn = self._L.plsa_em_accumulate_materialised if materialised else self._L.plsa_em_accumulate
+        self._ok(fn(self._h, ptr(sw), np.float32(e_step_thresh), C.addressof(ll) if want_ll else None))
         return ll.value if want_ll else None
+
+    def p_bytes(self):
+        """bytes of P(z|w,d) for the active matrix and the factors in force (one tile of slack included)"""
+        n, m, nnz = self.shape
+        return 4 * (nnz + 64) * ((self.k + 3) // 4 * 4)
+
+    def p_reserve(self, nbytes):
+        """own P(z|w,d) capacity of at least nbytes; returns its device address (for p_borrow on other contexts)"""
+        out = C.c_void_p()
+        self._ok(self._L.plsa_p_reserve(self._h, int(nbytes), C.byref(out)))
+        return out.value
+
+    def p_borrow(self, device_ptr, nbytes=0):
+        """use another context's P(z|w,d) buffer (None: back to own allocations); sharers run one after the other"""
+        self._ok(self._L.plsa_p_borrow(self._h, device_ptr, int(nbytes)))
 
     def em_finish(self):
         self._ok(self._L.plsa_em_finish(self._h))

@@ -79,7 +79,7 @@ class RankComm:
 
 
 def sharded_em(engines, comm, sample_weights=None, n_iter=100, n_iter_per_test=10, tolerance=0.001,
-               e_step_thresh=1e-32, trace_last=False, zero_arm=True):
+               e_step_thresh=1e-32, trace_last=False, zero_arm=True, materialised=False):
     """plsa_fit_inner (plsa.py:583-640) over row shards.  `engines`: the shards local to this process,
     each with its rows uploaded and factors set (same P(w|z) everywhere).  Returns (iterations,
     float32 log-likelihood trace)."""
@@ -87,20 +87,22 @@ def sharded_em(engines, comm, sample_weights=None, n_iter=100, n_iter_per_test=1
     for e, sw in zip(engines, sws):          # one upload per fit, not one copy + host wait per iteration
         e.set_sample_weight(sw)
     try:
-        return _sharded_em_loop(engines, comm, n_iter, n_iter_per_test, tolerance, e_step_thresh, trace_last, zero_arm)
+        return _sharded_em_loop(engines, comm, n_iter, n_iter_per_test, tolerance, e_step_thresh, trace_last, zero_arm,
+                                materialised)
     finally:
         for e in engines:
             e.set_sample_weight(None)
 
 
-def _sharded_em_loop(engines, comm, n_iter, n_iter_per_test, tolerance, e_step_thresh, trace_last, zero_arm):
+def _sharded_em_loop(engines, comm, n_iter, n_iter_per_test, tolerance, e_step_thresh, trace_last, zero_arm,
+                     materialised=False):
     sws = [None] * len(engines)              # the resident weights apply
     trace = []
     prev = np.float32(comm.allreduce_scalar([e.log_likelihood(sw) for e, sw in zip(engines, sws)]))
     trace.append(prev)                                             # plsa.py:591
     pending, iters, stopped = False, 0, False
     for i in range(n_iter):
-        parts = [e.em_accumulate(sw, e_step_thresh, want_ll=pending) for e, sw in zip(engines, sws)]
+        parts = [e.em_accumulate(sw, e_step_thresh, want_ll=pending, materialised=materialised) for e, sw in zip(engines, sws)]
         comm.allreduce_accumulators(engines)
         if pending:
             cur = np.float32(comm.allreduce_scalar(parts))
@@ -131,6 +133,9 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
     that many engines of this process (single-GPU emulation used by the tests).  Every rank passes the
     same X and arguments; returns the full (P(z|d), P(w|z)) on every rank.  Same initial factors as
     `plsa_fit` for the same seed.
+
+    `local_shards=R` with `flags` that do not contain PLSA_FUSED runs the MATERIALISED schedule tiled by doc blocks
+    (block_parallel_plsa.py:373-403): R contexts on one device, one shared P(z|w,d) buffer of the largest block's size.
 
     Every communicator drives the accumulate / all-reduce / finish split; with the RCCL communicator and
     ENSTOP_AMD_SHARDED_INLOOP=1 the whole loop runs inside the C ABI instead (`plsa_fit` with PLSA_SHARDED)."""
@@ -165,6 +170,11 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
         mine = [c.rank]
     if any(b <= a for a, b in ranges):
         raise ValueError("sharded_plsa_fit: %d documents cannot be split over %d shards" % (n, len(ranges)))
+    # local shards with the MATERIALISED schedule (flags without PLSA_FUSED): the doc-block tiling of
+    # block_parallel_plsa.py:373-403 -- every block's P(z|w,d) is computed and consumed inside its own step, and the blocks
+    # share ONE buffer sized for the largest of them (config 5: 8 blocks of 32 GB instead of 256 GB)
+    tiled = bool(local_shards) and flags is not None and not (flags & PLSA_FUSED)
+    lender = -1
     try:
         sws = []
         for e, r in zip(engines, mine):
@@ -172,13 +182,20 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
             e.upload_csr(X[a:b])
             e.set_factors(U0[a:b], V0)
             sws.append(None if sw_all is None else sw_all[a:b])
+        if tiled:
+            need = [e.p_bytes() for e in engines]
+            lender = int(np.argmax(need))
+            shared = engines[lender].p_reserve(max(need))
+            for i, e in enumerate(engines):
+                if i != lender:
+                    e.p_borrow(shared, max(need))
         if native:
             fl = (PLSA_FUSED if flags is None else flags) | PLSA_SHARDED | (0 if zero_arm else PLSA_STOP_NO_ZERO_ARM)
             iters, trace = engines[0].fit(sws[0], n_iter, n_iter_per_test, tolerance, e_step_thresh, fl,
                                           trace=return_info)
         else:
             iters, trace = sharded_em(engines, comm, sws, n_iter, n_iter_per_test, tolerance, e_step_thresh,
-                                      trace_last=return_info, zero_arm=zero_arm)
+                                      trace_last=return_info, zero_arm=zero_arm, materialised=tiled)
         U = np.zeros((n, k), np.float32)
         V = None
         for e, r in zip(engines, mine):
@@ -191,6 +208,10 @@ def sharded_plsa_fit(X, k, sample_weight=None, init="random", n_iter=100, n_iter
             for r, (a, b) in enumerate(ranges):
                 U[a:b] = parts[r, :b - a]
     finally:
+        if tiled and lender >= 0:
+            for i, e in enumerate(engines):
+                if i != lender:
+                    e.p_borrow(None)                   # the loan ends before the lender's buffer goes
         for e in engines:
             if local_shards or not on_comm_engine:
                 e.close()

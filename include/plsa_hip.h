@@ -160,6 +160,23 @@ int plsa_refit(plsa_ctx *ctx, const float *sw, int32_t n_iter, int32_t n_iter_pe
  * plsa_accumulator_get/set are ordered behind them on that stream; a caller that touches plsa_accumulator_device's
  * buffer from a stream of its own calls plsa_synchronize first (ll_partial != NULL implies that synchronisation). */
 int plsa_em_accumulate(plsa_ctx *ctx, const float *sw, float thresh, double *ll_partial);
+
+/* Doc-block tiling of the MATERIALISED schedule (enstop/block_parallel_plsa.py:373-403: X cut into row blocks, the
+ * responsibilities of a block computed and consumed block by block, the blocks' partial P(w|z) summed, :182-185).  One
+ * context per doc block; per EM iteration every block calls
+ *   plsa_em_accumulate_materialised   the reference's kernel sequence over the block's rows -- plsa_e_step into P(z|w,d),
+ *                                     the M-step from it (plsa.py:39-107, 124-204) -- leaving the block's rows of P(z|d) final
+ *                                     and its un-normalised P(w|z) sums in the accumulator, exactly like plsa_em_accumulate;
+ *                                     P(z|w,d) is dead when the call returns (the call waits for its own kernels: the
+ *                                     buffer may be lent to the next block at once)
+ * followed by the same sum over blocks and plsa_em_finish as the doc-sharded fit.  The blocks of ONE device may share one
+ * P(z|w,d) buffer sized for the largest block: plsa_p_reserve on one context (own allocation of at least `bytes`, address
+ * in *device_ptr), plsa_p_borrow on the others (the context then never allocates or frees P itself; NULL ends the loan; the
+ * lender outlives the loan; sharers do not run materialising calls concurrently).  Config 5 (500 M non-zeros, k = 128:
+ * 256 GB of P(z|w,d) untiled) runs this schedule in 8 blocks of 32 GB. */
+int plsa_em_accumulate_materialised(plsa_ctx *ctx, const float *sw, float thresh, double *ll_partial);
+int plsa_p_reserve(plsa_ctx *ctx, int64_t bytes, void **device_ptr);
+int plsa_p_borrow(plsa_ctx *ctx, void *device_ptr, int64_t bytes);
 int plsa_em_finish(plsa_ctx *ctx);
 /* Makes the per-document weights (`sample_weight`, enstop/plsa.py:208, :314) resident in HBM: one copy + one host
  * wait here, after which every call that passes sw = NULL (plsa_em_accumulate in a per-iteration loop, plsa_fit,

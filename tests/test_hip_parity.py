@@ -756,6 +756,44 @@ def test_sharded_fit_matches_reference_golden(amd, shards):
         close_factors(U, g["U"]); close_factors(V, g["V"])
 
 
+def test_materialised_schedule_tiled_by_doc_blocks(amd, oracle):
+    """block_parallel_plsa.py:373-403 on the device: the MATERIALISED schedule (E-step into P(z|w,d), M-step from it) run doc
+    block by doc block, every block's responsibilities alive only inside its own step, all blocks writing through ONE
+    borrowed P(z|w,d) buffer of the largest block's size.  Same factors, iteration count and likelihood trace as the
+    untiled materialised fit and as the oracle; a borrowed buffer that is too small is refused by name."""
+    from enstop_amd.sharded import sharded_plsa_fit
+    X = _corpus(900, 700, 0.04, seed=23, empty_rows=4)
+    n = X.shape[0]
+    k = 12
+    rs = np.random.RandomState(2)
+    sw = (0.5 + rs.rand(n)).astype(np.float32)
+    kw = dict(n_iter=9, n_iter_per_test=3, tolerance=0.0, e_step_thresh=1e-32, random_state=6)
+    for weights in (None, sw):
+        w = np.ones(n, np.float32) if weights is None else weights
+        Uo, Vo, trace, iters = oracle.plsa_fit(X, k, w, return_trace=True, **kw)
+        U1, V1 = amd.plsa_fit(X, k, w, flags=0, **kw)
+        for shards in (2, 5):
+            U, V, info = sharded_plsa_fit(X, k, sample_weight=weights, local_shards=shards, flags=0, return_info=True, **kw)
+            assert info["n_iter"] == iters == 9
+            close_factors(U, Uo); close_factors(V, Vo)
+            close_factors(U, U1, tol=1e-5); close_factors(V, V1, tol=1e-5)
+            q = min(len(info["log_likelihood_trace"]), len(trace))
+            close_ll(info["log_likelihood_trace"][:q], trace[:q])
+    with amd.Engine() as a, amd.Engine() as b:
+        a.upload_csr(X[:300]); b.upload_csr(X[300:])
+        V0 = np.full((k, X.shape[1]), 1.0 / X.shape[1], np.float32)
+        a.set_factors(np.full((300, k), 1.0 / k, np.float32), V0)
+        b.set_factors(np.full((n - 300, k), 1.0 / k, np.float32), V0)
+        ptr = a.p_reserve(a.p_bytes())                          # sized for the SMALLER block
+        assert b.p_bytes() > a.p_bytes()
+        b.p_borrow(ptr, a.p_bytes())
+        with pytest.raises(amd.DeviceError, match="borrowed"):
+            b.em_accumulate(None, 1e-32, materialised=True)
+        b.p_borrow(None)
+        b.em_accumulate(None, 1e-32, materialised=True)         # own allocation again
+        b.em_finish()
+
+
 def test_sharded_fit_with_more_shards_than_documents_raises(amd):
     """No rank may end up without rows (it would leave the others waiting in the all-reduce): the same
     ValueError on every rank, before any exchange."""
