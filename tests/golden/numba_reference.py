@@ -11,6 +11,7 @@ is data: inputs are the committed corpus of fit_cfg1_shape.npz, outputs are what
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py fixture     -> tests/golden/numba_cfg1.npz
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py small       -> tests/golden/numba_small.npz
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py blocks      -> tests/golden/numba_block_streamed.npz
+    /opt/conda/bin/python3.9 tests/golden/numba_reference.py refit       -> tests/golden/numba_cfg1_refit.npz
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py fuzz [N]    -> compiled reference vs oracle/plsa_oracle.c
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py time        -> compiled reference vs the C port, same cores
 """
@@ -363,6 +364,40 @@ def cmd_blocks():
         json.dump(rep, f, indent=1)
 
 
+def refit_topics(k, m):
+    """A topic matrix both sides can rebuild bit for bit (no stored array): small integers, rows divided by their exact sums."""
+    import numpy as np
+    w = np.arange(m, dtype=np.int64)[None, :]
+    z = np.arange(k, dtype=np.int64)[:, None]
+    T = ((w * 7 + z * 131) % 97 + 1).astype(np.float64)
+    return (T / T.sum(axis=1, keepdims=True)).astype(np.float32)      # integer sums: exact in float64 in any order
+
+
+def cmd_refit():
+    """`plsa_refit` of the reference COMPILED BY NUMBA at BASELINE config 1's exact shape -- PLSA.transform's own call
+    (plsa.py:1210-1218: 50 iterations, a test every 5, tolerance 0.001, RandomState(42)) against fixed topics
+    -> tests/golden/numba_cfg1_refit.npz (every second row of P(z|d))."""
+    import numpy as np
+    numba, ref = numba_env()
+    X, g = load_cfg1()
+    n, m = X.shape
+    k = 20
+    topics = refit_topics(k, m)
+    sw = np.ones(n, np.float32)
+    t0 = time.time()
+    U = ref.plsa_refit(X, topics, sw, n_iter=50, n_iter_per_test=5, tolerance=0.001, e_step_thresh=1e-32, random_state=42)
+    dt = time.time() - t0
+    rep = {"seconds": round(dt, 2), "threads": int(numba.get_num_threads())}
+    for variant in ("strict", "wide"):
+        o = oracle(variant, 8)
+        Uo = o.plsa_refit(X, topics, sw, n_iter=50, n_iter_per_test=5, tolerance=0.001, e_step_thresh=1e-32, random_state=42)
+        rep["compiled_vs_oracle_" + variant] = peak_rel(U, Uo)
+    np.savez_compressed(os.path.join(HERE, "numba_cfg1_refit.npz"), U_every_second_row=U[::2], k=np.int64(k),
+                        topics_checksum=np.float64(topics.astype(np.float64).sum()), compiled_vs_strict=np.float64(rep["compiled_vs_oracle_strict"]))
+    print(json.dumps(rep))
+    json.dump(rep, open(os.path.join(ROOT, "profiles", "r05_numba_reference_cfg1_refit.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "fixture"
     if what == "fixture":
@@ -375,3 +410,5 @@ if __name__ == "__main__":
         cmd_small()
     elif what == "blocks":
         cmd_blocks()
+    elif what == "refit":
+        cmd_refit()

@@ -326,3 +326,25 @@ def test_numba_compiled_block_and_streamed_modules_midsize(oracle):
     U, V = oracle.streamed_plsa_fit(X, k, sww, block_size=65536, **kw)
     assert peak_rel(U[::st], g["U_streamed_weighted"]) < 1e-4 and peak_rel(V, g["V_streamed_weighted"]) < 1e-4
     assert 5e-5 < float(g["block_vs_plsa"][1]) < 2e-3
+
+
+def test_numba_compiled_refit_at_cfg1_shape(oracle):
+    """tests/golden/numba_cfg1_refit.npz: `plsa_refit` of the reference COMPILED BY NUMBA on config 1's exact corpus (the
+    call PLSA.transform makes: 50 iterations, a test every 5, tolerance 0.001, RandomState(42); fixed topics both sides
+    rebuild bit for bit).  The strict oracle sits at the recorded distance from it (1e-6: compilation moves the
+    reference that little where no corpus-long float32 sum is involved)."""
+    g = load_golden("numba_cfg1_refit")
+    X = golden_csr(load_golden("fit_cfg1_shape"))
+    n, m = X.shape
+    k = int(g["k"])
+    w = np.arange(m, dtype=np.int64)[None, :]
+    z = np.arange(k, dtype=np.int64)[:, None]
+    T = ((w * 7 + z * 131) % 97 + 1).astype(np.float64)
+    topics = (T / T.sum(axis=1, keepdims=True)).astype(np.float32)
+    assert float(topics.astype(np.float64).sum()) == float(g["topics_checksum"])
+    oracle.set_threads(8)
+    U = oracle.plsa_refit(X, topics, np.ones(n, np.float32), n_iter=50, n_iter_per_test=5, tolerance=0.001,
+                          e_step_thresh=1e-32, random_state=42)
+    d = peak_rel(g["U_every_second_row"], U[::2])
+    # the recorded figure is over all rows, this one over the stored half of them
+    assert d < 1e-5 and 0.5 * float(g["compiled_vs_strict"]) < d < 2.0 * float(g["compiled_vs_strict"]), (d, float(g["compiled_vs_strict"]))

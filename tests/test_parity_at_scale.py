@@ -9,6 +9,8 @@ states (needs a real MI355X: -m gpu).  What is compared with what (round 5):
             * the reference's OWN output, 2 iterations (tests/golden/fit_cfg1_shape.npz)                        [asserted]
             * the reference COMPILED BY NUMBA (tests/golden/numba_cfg1.npz): 50 iterations, and its default-tolerance
               stop iteration on 1 / 2 / 4 / 8 threads (61 on all) == HIP's                                      [asserted]
+            * plsa_refit of the reference COMPILED BY NUMBA (tests/golden/numba_cfg1_refit.npz): P(z|d) within the literal
+              north-star tolerance 1e-4                                                                          [asserted]
             * refit (PLSA.transform's loop: 50 iterations, test every 5, tolerance 0.005, never stops early) of
               P(z|d) against fixed topics, both schedules vs strict / n64 / wide                                [asserted]
             * a fit with document weights (plsa_m_step_w_sample_weight), 10 iterations, both schedules             [asserted]
@@ -341,6 +343,32 @@ def test_cfg1_numba_compiled_reference(amd, oracles):
             for f in ("U", "V"):
                 assert vs_ref[f] <= 1.5 * ref_vs_exact[f] + 2e-5, (sched, f, vs_ref, ref_vs_exact)
             assert vs_ref["ll_rel"] <= 1.5 * ref_vs_exact["ll_rel"] + 1e-5, (sched, vs_ref, ref_vs_exact)
+
+
+def test_cfg1_numba_compiled_refit(amd, oracles):
+    """`plsa_refit` of the reference COMPILED BY NUMBA at config 1's exact corpus (tests/golden/numba_cfg1_refit.npz: the call
+    PLSA.transform makes, plsa.py:1210-1218 -- 50 iterations, a test every 5, tolerance 0.001, RandomState(42) -- against a
+    fixed topic matrix both sides rebuild bit for bit).  The refit has no corpus-long float32 sum, so here the north-star
+    tolerance holds LITERALLY against the reference as its users run it: P(z|d) within 1e-4 (measured ~5e-6)."""
+    from conftest import load_golden, peak_rel
+    g = load_golden("numba_cfg1_refit")
+    X = corpus(amd, CONFIG1)
+    n, m = X.shape
+    k = int(g["k"])
+    w = np.arange(m, dtype=np.int64)[None, :]
+    z = np.arange(k, dtype=np.int64)[:, None]
+    T = ((w * 7 + z * 131) % 97 + 1).astype(np.float64)
+    topics = (T / T.sum(axis=1, keepdims=True)).astype(np.float32)
+    assert float(topics.astype(np.float64).sum()) == float(g["topics_checksum"])
+    rec = REPORT.setdefault("config1_numba_compiled_refit", {"shape": [n, m], "k": k})
+    for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
+        U = amd.plsa_refit(X, topics, np.ones(n, np.float32), n_iter=50, n_iter_per_test=5, tolerance=0.001,
+                           e_step_thresh=1e-32, random_state=42, flags=flags)
+        rec[sched] = {"vs_compiled_reference": peak_rel(U[::2], g["U_every_second_row"])}
+        _flush_report()
+        assert rec[sched]["vs_compiled_reference"] <= 1e-4, rec
+    rec["compiled_reference_vs_strict_oracle"] = float(g["compiled_vs_strict"])
+    _flush_report()
 
 
 def test_config1_refit_vs_oracle(amd, oracles):
