@@ -81,6 +81,17 @@ CONFIGS = {
     5: dict(n=5_000_000, m=200_000, nnz=500_000_000, k=128, name="synthetic CSR 5M docs x 200k vocab, 500M nnz, k=128"),
 }
 TOPICAL = dict(topics=64, alpha=0.1, background=0.25)      # --topics: documents as Dirichlet mixtures of latent topics
+# the 20-Newsgroups stand-in of configs 1 / 4 (round 6): the dataset cannot be obtained here, and real text has co-occurrence
+# structure that independent Zipf tokens lack (their gathers hit the L2 1.6x more often) -- twenty latent topics, like the
+# twenty newsgroups.  Config 3's headline stays on SURVEY.md 8d's generator (independent tokens) with `config3_topical` beside it.
+TOPICAL_20NG = dict(topics=20, alpha=0.1, background=0.25)
+
+
+def corpus_kind(kw):
+    if not kw or not kw.get("topics"):
+        return "independent Zipf(1.07) tokens (SURVEY.md 8d generator)"
+    return "topical: Dirichlet(%g) mixtures of %d latent topics, %g background (plsa_generate_synthetic_topics)" % (
+        kw.get("alpha", 0.1), kw["topics"], kw.get("background", 0.25))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 FITS_ITERS = 50                # EM iterations per ensemble member when quoting fits/min
 # How the timed C port relates to the reference itself (measured once, in the build container, where the numba-compiled
@@ -190,7 +201,8 @@ def quick_config(eng, cfg_id, steps, warmup, seed, with_cpu=False, e_step=True, 
     it, _ = eng.fit(None, n_iter=steps, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=PLSA_FUSED)
     eng.synchronize()
     dt = time.perf_counter() - t0
-    out = {"workload": cfg["name"] + ("" if not corpus_kw else " -- TOPICAL corpus %r" % (corpus_kw,)), "nnz": nnz, "k": k,
+    out = {"workload": cfg["name"] + ("" if not corpus_kw else " -- TOPICAL corpus %r" % (corpus_kw,)), "corpus": corpus_kind(corpus_kw),
+           "nnz": nnz, "k": k,
            "steps": it, "value": round(it / dt, 2), "unit": "iter/s", "ms_per_step": round(dt / it * 1e3, 4),
            "gcell_per_s": round(nnz * k * it / dt / 1e9, 2)}
     if pass_times:
@@ -228,7 +240,7 @@ def ensemble_20ng_shape(eng, seed, n_runs=32, n_jobs=4):
     import enstop_amd
     cfg = CONFIGS[4]
     eng.release_scratch()
-    eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], zipf_s=1.07, seed=seed)
+    eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], zipf_s=1.07, seed=seed, **TOPICAL_20NG)
     X = eng.download_active_csr()
     kw = dict(n_iter=FITS_ITERS, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, random_state=seed + 7, n_jobs=n_jobs)
     enstop_amd.ensemble_of_topics(X, cfg["k"], n_runs=n_jobs, **kw)          # warm-up: member contexts and their buffers
@@ -240,7 +252,8 @@ def ensemble_20ng_shape(eng, seed, n_runs=32, n_jobs=4):
     assert stack.shape == (n_runs * cfg["k"], cfg["m"]) and np.all(np.isfinite(stack))
     assert np.abs(stack.sum(axis=1, dtype=np.float64) - 1.0).max() < 1e-3
     wall = sorted(walls)[1]
-    return {"workload": cfg["name"], "nnz": int(X.nnz), "k": cfg["k"], "fits": n_runs, "iters_per_member": FITS_ITERS,
+    return {"workload": cfg["name"], "corpus": corpus_kind(TOPICAL_20NG), "nnz": int(X.nnz), "k": cfg["k"], "fits": n_runs,
+            "iters_per_member": FITS_ITERS,
             "n_jobs": n_jobs, "steps": n_runs * FITS_ITERS, "wall_s": round(wall, 4), "walls_s": [round(w, 4) for w in walls],
             "ms_per_step": round(wall / (n_runs * FITS_ITERS) * 1e3, 5), "ms_per_fit": round(wall / n_runs * 1e3, 3),
             "value": round(n_runs / wall * 60.0, 1), "unit": "fits/min",
@@ -357,7 +370,13 @@ def spawn_ranks(args):
 
 
 def corpus_options(args):
-    return dict(TOPICAL, topics=args.topics) if args.topics > 0 else {}
+    """--topics N > 0: topical corpus with N latent topics; 0: independent tokens; -1 (default): the 20-topic stand-in for the
+    20-Newsgroups configurations (1, 4), independent tokens -- SURVEY.md 8d's generator -- for the others."""
+    if args.topics > 0:
+        return dict(TOPICAL, topics=args.topics)
+    if args.topics < 0 and args.config in (1, 4):
+        return dict(TOPICAL_20NG)
+    return {}
 
 
 def pmc_child(args):
@@ -410,7 +429,7 @@ def measure_traffic(args):
             out = os.path.join(tmpdir, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "b", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(args.config),
-                   "--seed", str(args.seed), "--topics", str(args.topics)]
+                   "--seed", str(args.seed), "--topics", str(args.topics), "--no-pmc"]
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            timeout=float(os.environ.get("PLSA_BENCH_PMC_TIMEOUT", "150")), check=True)
@@ -478,6 +497,67 @@ def hot_kernel_table(k, kernels, traffic, source):
         out[name] = row
     return out
 
+def _pick(d, *keys):
+    return {k_: d[k_] for k_ in keys if isinstance(d, dict) and k_ in d}
+
+
+def compact_line(out, full_path=None):
+    """The ONE JSON line of a default run: the contract keys, `roofline` (north-star kernel + `timed_loop` = the dominant
+    kernel of the loop `value` times), `cpu_baseline`, every other BASELINE configuration and the ensemble legs as one
+    short object each -- sized to fit the 2000-character tail the driver keeps.  Everything else (per-kernel tables,
+    register counts, counter traffic, schedules) is in the full object (`full`, --full-json / --full)."""
+    line = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data")
+    c = out.get("config", {})
+    line["config"] = {"workload": CONFIG_SHORT.get((c.get("n_docs"), c.get("k")), c.get("workload")),
+                      "corpus": "topical" if str(c.get("corpus", "")).startswith("topical") else "independent Zipf tokens (SURVEY 8d)",
+                      "nnz": c.get("nnz"), "k": c.get("k"), "schedule": c.get("schedule"),
+                      "parallelism": str(c.get("parallelism", ""))[:60]}
+    r = out.get("roofline") or {}
+    line["roofline"] = _pick(r, "kernel", "leg", "bound", "achieved", "peak", "unit", "frac", "traffic")
+    line["roofline"]["avg_ms"] = r.get("avg_launch_ms")
+    if "timed_loop" in r:
+        line["roofline"]["timed_loop"] = r["timed_loop"]
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "sampled")
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:90]
+    line["timed_regions"] = [t.get("value") for t in out.get("timed_regions", [])]
+    line["rccl_ranks"] = out.get("rccl_ranks", 0)
+    line["exchange"] = str(out.get("exchange", ""))[:60]
+    oc = out.get("other_configs")
+    if isinstance(oc, dict):
+        short = line["other_configs"] = {}
+        for name, v in oc.items():
+            if not isinstance(v, dict):
+                short[name] = str(v)[:60]
+                continue
+            e = _pick(v, "value", "steps", "ms_per_step")
+            if "iter/s" not in str(v.get("unit", "iter/s")):
+                e["unit"] = str(v.get("unit"))[:24]
+            if isinstance(v.get("e_step"), dict):
+                e["e_step_frac"] = v["e_step"].get("frac")
+            if isinstance(v.get("cpu_baseline"), dict):
+                e["cpu_port_iter_s"] = v["cpu_baseline"].get("value")
+            if str(v.get("corpus", "")).startswith("topical"):
+                e["corpus"] = "topical"
+            for extra in ("wall_s", "topics_found", "documents_on_their_planted_topic"):
+                if extra in v:
+                    e[extra] = v[extra]
+            short[name] = e
+    en = out.get("ensemble")
+    if isinstance(en, dict):
+        line["ensemble"] = _pick(en, "fits", "iters_per_member", "wall_s", "fits_per_min")
+    elif en is not None:
+        line["ensemble"] = str(en)[:80]
+    if full_path:
+        line["full"] = full_path
+    return line
+
+
+CONFIG_SHORT = {(18_846, 20): "20NG-shaped 18846x173762, 2.95M nnz", (100_000, 32): "100k x 50k, 10M nnz",
+                (1_000_000, 64): "1M x 100k, 100M nnz", (5_000_000, 128): "5M x 200k, 500M nnz"}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -493,9 +573,14 @@ def main():
     ap.add_argument("--no-ensemble", action="store_true", help="skip the measured ensemble leg")
     ap.add_argument("--members-per-rank", type=int, default=0,
                     help="members each rank fits in the measured ensemble leg (0 = 2, or 32 / N with --config 4)")
-    ap.add_argument("--topics", type=int, default=0,
+    ap.add_argument("--topics", type=int, default=-1,
                     help="generate a TOPICAL corpus of the config's shape (documents as Dirichlet mixtures of this many latent "
-                         "topics; plsa_generate_synthetic_topics) instead of independent Zipf tokens; labelled in `config`")
+                         "topics; plsa_generate_synthetic_topics) instead of independent Zipf tokens; labelled in `config`.  "
+                         "Default -1: 20 topics for the 20-Newsgroups configurations (1, 4), independent tokens (0) otherwise")
+    ap.add_argument("--full", action="store_true",
+                    help="print the FULL result object as the JSON line (tools); default: the compact line (the driver keeps a "
+                         "2000-character tail) and the full object in --full-json")
+    ap.add_argument("--full-json", default="", help="where the full result object goes (default gpurun_out/bench_full_cfgC_nN.json)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact legs of the other BASELINE configs")
     ap.add_argument("--cpu-baseline-sampled", action="store_true",
                     help="time the CPU port on a bounded row sample (~15 s) instead of the whole corpus (config 3: ~45 s, 26 GB)")
@@ -716,7 +801,8 @@ def main():
         "timed_regions": [{"value": round(n_gpus * args.steps / r[0], 4), "ms_per_step": round(r[0] / args.steps * 1e3, 4)}
                           for r in regions],
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["name"] + ("" if not args.topics else " -- TOPICAL corpus %r" % (corpus_options(args),)),
+        "config": {"workload": cfg["name"] + ("" if not corpus_options(args) else " -- TOPICAL corpus %r" % (corpus_options(args),)),
+                   "corpus": corpus_kind(corpus_options(args)),
                    "n_docs": n, "n_vocab": m, "nnz": nnz, "k": k,
                    "schedule": args.schedule,
                    "parallelism": "single fit" if n_gpus == 1 else
@@ -762,7 +848,7 @@ def main():
                 plsa_comm.report_failure(e, rank, world, eng)
                 raise                                     # a rank that fails here would leave the others in a collective
             out["ensemble"] = "failed: %r" % (e,)
-    if rank == 0 and n_gpus == 1 and args.config == 3 and not args.topics and not args.no_other_configs:
+    if rank == 0 and n_gpus == 1 and args.config == 3 and not corpus_options(args) and not args.no_other_configs:
         # every other BASELINE.json configuration on the same device in compact form (same method as the main legs), so
         # that each is a number the driver's own run observes: configs[0] / [1] / [4] as EM iterations/s + the
         # materialising E-step's roofline fraction, configs[3] (the 32-member ensemble on the 20NG shape) as fits/min
@@ -782,7 +868,7 @@ def main():
         c2 = other["config2"]
         if isinstance(out.get("cpu_baseline"), dict) and isinstance(c2, dict) and isinstance(c2.get("cpu_baseline"), dict):
             out["cpu_baseline"]["whole_config2"] = c2["cpu_baseline"]
-        leg("config1", lambda: quick_config(eng, 1, args.steps, args.warmup, args.seed, min_steps=1000))
+        leg("config1", lambda: quick_config(eng, 1, args.steps, args.warmup, args.seed, min_steps=1000, corpus_kw=dict(TOPICAL_20NG)))
         leg("ensemble_20ng_shape", lambda: ensemble_20ng_shape(eng, args.seed))
         leg("ensemble_topics_estimator_20ng_shape", lambda: ensemble_topics_estimator_20ng_shape(eng, args.seed))
         leg("config3_topical", lambda: quick_config(eng, 3, args.steps, args.warmup, args.seed, e_step=False, min_steps=50,
@@ -817,11 +903,32 @@ def main():
                 out[key]["traffic"] = rec["hbm_bytes_per_launch"]
                 out[key]["traffic_source"] = source if source != "from_committed_profile" else \
                     "from_committed_profile: " + rec.get("source", "profiles/pmc_traffic.json")
+        # the driver-visible roofline object names BOTH kernels: the north-star one (k_e_step: not launched by the loop `value`
+        # times -- a separate, materialised leg) and, as `timed_loop`, the dominant kernel of the loop that IS timed
+        out["roofline"]["leg"] = "materialised (separate from value)" if mat is not None else "the timed loop itself (--schedule materialised)"
+        d_ = out["roofline_dominant_fused"]
+        tl = {"kernel": d_["kernel"], "avg_ms": d_["avg_launch_ms"], "algorithmic_GB": d_["algorithmic_GB_per_launch"],
+              "frac": d_["frac"], "traffic_GB": None, "traffic_ratio": None, "frac_on_traffic": None,
+              "share_of_ms_per_step": round(d_["avg_launch_ms"] / out["ms_per_step"], 3)}
+        if d_.get("traffic"):
+            tl["traffic_GB"] = round(d_["traffic"] / 1e9, 3)
+            tl["traffic_ratio"] = round(d_["traffic"] / 1e9 / d_["algorithmic_GB_per_launch"], 2)
+            tl["frac_on_traffic"] = round(d_["traffic"] / 1e9 / (d_["avg_launch_ms"] / 1e3) / HBM_PEAK_GBS, 4)
+        out["roofline"]["timed_loop"] = tl
         if table and source != "from_committed_profile":
             out["pmc_traffic"] = table
         out["hot_kernels"] = hot_kernel_table(k, dict(kernels, **((mat or {}).get("kernels", {}))), table or {}, source)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        full_path = args.full_json or os.path.join(ROOT, "gpurun_out", "bench_full_cfg%d_n%d.json" % (args.config, n_gpus))
+        try:
+            os.makedirs(os.path.dirname(full_path) or ".", exist_ok=True)
+            with open(full_path, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:
+            print("bench.py: full result object not written (%r)" % (e,), file=sys.stderr)
+            full_path = None
+        line = out if args.full else compact_line(out, full_path and os.path.relpath(full_path, ROOT))
+        os.write(json_fd, (json.dumps(line, separators=(",", ":")) + "\n").encode())
     os.close(json_fd)
 
 

@@ -17,6 +17,8 @@ PLSA_TRACE_LL = 4
 PLSA_SW_LL_ONLY = 8
 PLSA_STOP_NO_ZERO_ARM = 16
 PLSA_SHARDED = 64
+PLSA_REFERENCE_SUMS = 256   # the reference's float32 sums, rounding for rounding (include/plsa_hip.h)
+PLSA_REFERENCE_LL = 512     # + the log-likelihood as one sequential float32 sum (plsa.py:322 read literally)
 
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
@@ -48,6 +50,7 @@ SIGNATURES = {
     "plsa_refit_init_mt19937": (C.c_int, [_ctx, C.c_void_p, _i64, _i32,
                                           np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]),
     "plsa_copy_components_to_device": (C.c_int, [_ctx, _vp]),
+    "plsa_set_arithmetic": (C.c_int, [_ctx, _i32]),
     "plsa_e_step": (C.c_int, [_ctx, C.c_float, _vp]),
     "plsa_set_p": (C.c_int, [_ctx, _f32p]),
     "plsa_m_step": (C.c_int, [_ctx, _vp, _i32, _vp, _vp]),
@@ -110,19 +113,25 @@ def _default_hw_queues():
     HERE, visibly, before the library is loaded -- never by the library itself -- unless the user set it or opted out
     with ENSTOP_AMD_HW_QUEUES=0 (any other value of that variable is the number to use).  It cannot take effect when the
     process initialised HIP earlier (e.g. torch.cuda): `hw_queues()` says whether the runtime was already mapped."""
+    want = os.environ.get("ENSTOP_AMD_HW_QUEUES", "8").strip()
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        HW_QUEUES["set_by"] = "user"
+        return
+    try:
+        n_queues = int(want)
+    except ValueError:
+        raise ValueError("ENSTOP_AMD_HW_QUEUES=%r: expected a positive integer (hardware queues to ask the HIP runtime for) "
+                         "or 0 to leave the runtime's default" % (want,)) from None
+    if n_queues <= 0:                     # 0 (documented) or a negative number: opt out -- nothing is exported, nothing probed
+        HW_QUEUES["set_by"] = "opt-out"
+        return
     try:
         with open("/proc/self/maps") as f:
             HW_QUEUES["hip_mapped_before_load"] = "libamdhip64" in f.read()
     except OSError:
         pass
-    want = os.environ.get("ENSTOP_AMD_HW_QUEUES", "8")
-    if "GPU_MAX_HW_QUEUES" in os.environ:
-        HW_QUEUES["set_by"] = "user"
-    elif want == "0":
-        HW_QUEUES["set_by"] = "opt-out"
-    else:
-        os.environ["GPU_MAX_HW_QUEUES"] = want
-        HW_QUEUES["set_by"] = "enstop_amd"
+    os.environ["GPU_MAX_HW_QUEUES"] = str(n_queues)
+    HW_QUEUES["set_by"] = "enstop_amd"
 
 
 def hw_queues():

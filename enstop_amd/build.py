@@ -5,8 +5,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "plsa_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "plsa_kernels.hpp"), os.path.join(HERE, "csrc", "plsa_synth.hpp"),
-        os.path.join(HERE, "csrc", "mt_jump.hpp"), os.path.join(os.path.dirname(HERE), "include", "plsa_hip.h")]
+DEPS = [SRC, os.path.join(HERE, "csrc", "plsa_kernels.hpp"), os.path.join(HERE, "csrc", "plsa_ref_kernels.hpp"),
+        os.path.join(HERE, "csrc", "plsa_synth.hpp"), os.path.join(HERE, "csrc", "mt_jump.hpp"),
+        os.path.join(os.path.dirname(HERE), "include", "plsa_hip.h"), os.path.join(os.path.dirname(HERE), "include", "plsa_hip_diag.h")]
 OUT = os.path.join(HERE, "libplsa_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))

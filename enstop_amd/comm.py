@@ -283,9 +283,31 @@ def install(comm):
     return comm
 
 
+_warned_unsharded = False
+
+
 def current():
-    """The installed communicator, else the single-process identity -- no detection of anything else in the process."""
-    return _installed if _installed is not None else SingleComm()
+    """The installed communicator, else the single-process identity -- no detection of anything else in the process.
+    A process that was evidently started as one rank of several (WORLD_SIZE > 1 in the environment: torchrun, mpirun
+    wrappers) and never installed a communicator gets ONE warning: every rank would otherwise fit the whole ensemble /
+    corpus redundantly -- correct results, no scaling, no sign of it (rounds 1-4 picked up an initialised
+    torch.distributed group silently; that dispatch is gone on purpose)."""
+    global _warned_unsharded
+    if _installed is not None:
+        return _installed
+    if not _warned_unsharded:
+        try:
+            world = int(os.environ.get("WORLD_SIZE", "1"))
+        except ValueError:
+            world = 1
+        if world > 1:
+            _warned_unsharded = True
+            import warnings
+            warnings.warn("enstop_amd: WORLD_SIZE=%d but no communicator is installed -- this rank works alone (every rank "
+                          "repeats the whole job).  Call enstop_amd.distributed.init() (RCCL, one process per GPU) or "
+                          "enstop_amd.comm.install(...) once per process to shard ensembles and doc-sharded fits." % world,
+                          RuntimeWarning, stacklevel=2)
+    return SingleComm()
 
 
 def _launcher_nonce():
@@ -371,6 +393,14 @@ def rendezvous_id(rank, path=None, timeout=600.0):
     want = len(ID_MAGIC) + TOKEN_BYTES + ID_BYTES
     seen = "no file"
     hinted = False
+    # An EXPLICIT id file without a launcher nonce is compared by the parent-based launch token: ranks with different
+    # parents (static multi-node torchrun, whose TORCHELASTIC_RUN_ID is the constant 'none'; ssh-started ranks sharing a
+    # path) can then never match.  They fail after `foreign_grace` seconds of looking at a well-formed foreign token with
+    # the remedy in the message, instead of spinning until the rendezvous timeout.
+    explicit_without_nonce = bool(os.environ.get("PLSA_COMM_ID_FILE")) and path == os.environ.get("PLSA_COMM_ID_FILE") \
+        and not _launcher_nonce()
+    foreign_grace = float(os.environ.get("PLSA_RENDEZVOUS_FOREIGN_GRACE", "30"))
+    foreign_since = None
     while True:
         try:
             with open(path, "rb") as f:
@@ -380,14 +410,23 @@ def rendezvous_id(rank, path=None, timeout=600.0):
                     return data[-ID_BYTES:]
                 seen = ("a file of another launch (token mismatch: a stale file rank 0 has not replaced yet, or ranks "
                         "started by different launchers -- those must share PLSA_LAUNCH_NONCE)")
+                foreign_since = foreign_since or time.time()
+                if explicit_without_nonce and time.time() - foreign_since > foreign_grace:
+                    raise RuntimeError(
+                        "rank %d: the RCCL id file %s has carried another launcher's token for %.0f s.  PLSA_COMM_ID_FILE is set "
+                        "explicitly and no launch nonce is exported, so ranks are matched by their PARENT process -- ranks "
+                        "started by different launchers (multi-node torchrun with a static rendezvous, ssh sessions) never "
+                        "match that way: export the same PLSA_LAUNCH_NONCE=<any string> on every rank (or remove a stale "
+                        "file of a crashed launch)." % (rank, path, time.time() - foreign_since))
                 if not hinted and time.time() - t0 > 10.0:
                     hinted = True
                     sys.stderr.write("[enstop_amd rank %d] still waiting for this launch's RCCL id at %s; saw %s\n"
                                      % (rank, path, seen))
             else:
                 seen = "a malformed / half-written file (%d bytes)" % len(data)
+                foreign_since = None
         except FileNotFoundError:
-            pass
+            foreign_since = None
         if time.time() - t0 > timeout:
             raise TimeoutError("rank %d: no RCCL id for this launch at %s after %.0f s (last seen: %s)"
                                % (rank, path, timeout, seen))

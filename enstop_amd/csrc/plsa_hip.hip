@@ -1,5 +1,6 @@
 // plsa_hip.hip -- host side of libplsa_hip.so: context, HBM layout, kernel dispatch, EM drivers and
-// the C ABI declared in include/plsa_hip.h.  gfx950 only; no other back-end exists.
+// the C ABI declared in include/plsa_hip.h (the drop-in) and include/plsa_hip_diag.h (diagnostics, measurement, test
+// plumbing).  gfx950 only; no other back-end exists.
 //
 // HBM layout per context (n docs, m words, k topics, kp = 4*ceil(k/4)):
 //   base CSR     indptr i32[n+1], col i32[nnz], val f32[nnz]      the uploaded corpus
@@ -26,8 +27,10 @@
 #include <vector>
 
 #include "../../include/plsa_hip.h"
+#include "../../include/plsa_hip_diag.h"
 #include "mt_jump.hpp"
 #include "plsa_kernels.hpp"
+#include "plsa_ref_kernels.hpp"
 #include "plsa_synth.hpp"
 
 using plsa::i64;
@@ -92,6 +95,7 @@ struct plsa_ctx {
     int row_lpn = 1, row_ch = 1;     // lane shape of the DOCUMENT pass (may differ from lpn / ch: see set_shape)
     bool row_shape_8x2 = true;       // PLSA_ROW_SHAPE=0: document pass in the common shape
     bool p_borrowed = false;       // P(z|w,d) lives in memory lent by plsa_p_borrow (never freed, never re-allocated here)
+    bool p_lent = false;           // plsa_p_reserve handed this context's P(z|w,d) address out: it must not move (no regrowth) until plsa_release_scratch
     int e_rows = -1;               // E-step traversal: 1 document-owned, 0 one group per non-zero, -1 by size (PLSA_E_ROWS)
     int mt_streams = 256;          // pieces the MT19937 init stream is cut into (PLSA_MT_STREAMS; 1 = sequential)
     i64 mt_min_blocks = 4096;      // ... once it is at least this many 624-word blocks long (PLSA_MT_MIN_BLOCKS)
@@ -128,6 +132,11 @@ struct plsa_ctx {
     int cu = 0, cv = 0;
     i64 fac_n = 0, fac_m = 0;
     DevBuf P;
+    // arithmetic of the kernel-level operators and drivers (plsa_set_arithmetic; PLSA_REFERENCE_SUMS / PLSA_REFERENCE_LL of plsa_fit):
+    // ref_sums: every factor sum one float32 accumulator in the reference's loop order (plsa_ref_kernels.hpp)
+    // ref_ll:   the log-likelihood one float32 running sum over the non-zeros (plsa.py:322 read literally)
+    bool ref_sums = false, ref_ll = false;
+    DevBuf ref_terms;              // float32 [nnz]: per-entry log-likelihood terms of the sequential sum
     int placement_candidates = 4, placement_tried = 0;
     double placement_gbps[2] = {0.0, 0.0};
     size_t p_shift = 0;   // experiment knob: byte offset of P inside its allocation (PLSA_P_OFFSET_KB)
@@ -726,6 +735,10 @@ int need_factors(plsa_ctx *c) {
 // ---------------------------------------------------------------------------------------------
 // kernel wrappers
 // ---------------------------------------------------------------------------------------------
+int run_ref_e_step(plsa_ctx *c, float thresh);
+int run_ref_m_step(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_pdz);
+int run_ref_loglik(plsa_ctx *c, const float *d_sw, double *out);
+
 int run_e_step(plsa_ctx *c, float thresh) {
     {   // the materialised schedule needs the whole nnz x kp array: say so instead of a bare OOM
         const size_t need = sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp;
@@ -734,10 +747,14 @@ int run_e_step(plsa_ctx *c, float thresh) {
             return fail(c, "materialising P(z|w,d) needs %.1f GB but only %.1f GB of HBM are free; use the fused "
                            "schedule (PLSA_FUSED), which never stores it, or tile the documents (plsa_em_accumulate_materialised)", need / 1e9, (free_b + c->P.cap) / 1e9);
     }
-    if (c->p_borrowed) {
+    if (c->p_borrowed || c->p_lent) {
         const size_t need = sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp;
         if (c->P.cap < need)
-            return fail(c, "the borrowed P(z|w,d) buffer holds %.2f GB, this matrix needs %.2f GB (plsa_p_borrow)", c->P.cap / 1e9, need / 1e9);
+            return fail(c, c->p_borrowed ? "the borrowed P(z|w,d) buffer holds %.2f GB, this matrix needs %.2f GB (plsa_p_borrow)"
+                                         : "the P(z|w,d) buffer lent out by plsa_p_reserve holds %.2f GB, this matrix needs %.2f GB: it cannot "
+                                           "grow while other contexts hold its address (end the loans, then plsa_release_scratch)",
+                        c->P.cap / 1e9, need / 1e9);
+        c->p_shift = 0;
     } else
     // one tile (64 rows) of slack: the last tile is stored without a predicate
     {   // placement experiment knobs: PLSA_P_SLACK_MB over-allocates, PLSA_P_OFFSET_KB shifts the start
@@ -752,6 +769,7 @@ int run_e_step(plsa_ctx *c, float thresh) {
     // into pieces of 4 index batches every group of a wave runs the same number of gather/store bursts
     // (config 3 5.27 -> 4.62 ms = 71 % of the HBM peak; config 2 0.357 -> 0.235 ms = 71 %).  Tiny corpora
     // (config 1: 84 us in all) keep the flat kernel: one group per non-zero, perfectly balanced, no setup.
+    if (c->ref_sums) return run_ref_e_step(c, thresh);
     bool e_rows = c->e_rows < 0 ? (double)c->nnz * c->kp >= 1e8 : c->e_rows != 0;
     if (e_rows) {
         // piece length: measured optimum 64 entries at k = 64 (48: 4.86, 64: 4.61, 80: 5.03, whole documents:
@@ -1112,6 +1130,7 @@ int wait_ll(plsa_ctx *c, double *out) {
 }
 
 int run_loglik(plsa_ctx *c, const float *d_sw, double *out) {
+    if (c->ref_ll) return run_ref_loglik(c, d_sw, out);
     const int grid = grid_for(c, c->n, 256 / c->lpn);
     const int *order = nullptr;
     CHK(ensure_roworder(c, &order));
@@ -1129,6 +1148,7 @@ int run_loglik(plsa_ctx *c, const float *d_sw, double *out) {
 // one M-step from the materialised P: U[1-cu], and (update_v) Vt[1-cv]; swaps the buffers in
 int run_m_step_from_p(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_pdz) {
     if (!c->p_valid) return fail(c, "plsa_m_step: no P(z|w,d) on the device (run plsa_e_step or plsa_set_p)");
+    if (c->ref_sums) return run_ref_m_step(c, d_sw, update_v, d_norm_pdz);
     CHK(run_row_pass(c, true, false, nullptr, 0.f, d_norm_pdz, nullptr));
     if (update_v) {
         CHK(run_col_pass(c, true, d_sw, 0.f, 1));
@@ -1138,6 +1158,138 @@ int run_m_step_from_p(plsa_ctx *c, const float *d_sw, bool update_v, float *d_no
     if (update_v) c->cv ^= 1;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// reference arithmetic (plsa_ref_kernels.hpp): the reference's statements with the reference's roundings
+// ---------------------------------------------------------------------------------------------
+// lanes per document / column (G) and topics per lane (NZ) of the reference-arithmetic passes: z = lane + G t
+template <class Fn>
+int dispatch_ref_group(plsa_ctx *c, Fn &&fn) {
+    using std::integral_constant;
+    const int kp = c->kp;
+    if (kp <= 8) fn(integral_constant<int, 8>{}, integral_constant<int, 1>{});
+    else if (kp <= 16) fn(integral_constant<int, 16>{}, integral_constant<int, 1>{});
+    else if (kp <= 32) fn(integral_constant<int, 32>{}, integral_constant<int, 1>{});
+    else if (kp <= 64) fn(integral_constant<int, 64>{}, integral_constant<int, 1>{});
+    else if (kp <= 128) fn(integral_constant<int, 64>{}, integral_constant<int, 2>{});
+    else if (kp <= 256) fn(integral_constant<int, 64>{}, integral_constant<int, 4>{});
+    else if (kp <= 512) fn(integral_constant<int, 64>{}, integral_constant<int, 8>{});
+    else if (kp <= 1024) fn(integral_constant<int, 64>{}, integral_constant<int, 16>{});
+    else return fail(c, "unsupported topic count k=%d (max 1024)", c->k);
+    return 0;
+}
+
+// plsa.py:91-105 with one float32 norm per entry, topics in order (P allocated by run_e_step)
+int run_ref_e_step(plsa_ctx *c, float thresh) {
+    CHK(ensure_rowidx(c));
+    {
+        Scope s(c, "k_ref_e_step");
+        hipLaunchKernelGGL(plsa::ref::k_ref_e_step, dim3(grid_for(c, c->nnz, 256)), dim3(256), 0, c->stream,
+                           c->rowidx.as<int>(), c->col, c->nnz, c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
+                           p_base(c), c->kp, thresh);
+    }
+    CHK(launch_check(c, "k_ref_e_step"));
+    c->p_valid = true;
+    return 0;
+}
+
+// plsa.py:172-204 / 277-310 / 795-816 from the materialised P: U[out], (update_v) Vt[out]; swaps the buffers in.
+// The norm_pwz chain (one workgroup, nnz dependent additions per topic) runs on the second stream beside the document
+// and column passes.
+int run_ref_m_step(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_pdz) {
+    if (c->sharded) return fail(c, "the reference arithmetic has no doc-sharded form (norm_pwz is ONE chain over all non-zeros)");
+    const int *order = nullptr;
+    CHK(ensure_roworder(c, &order));
+    if (update_v) {
+        CHK(ensure_csc(c));
+        CHK(ensure_rowidx(c));
+        CHK(ensure(c, c->norm_pwz, sizeof(float) * (size_t)c->kp));
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        c->ls = c->stream2;
+        {
+            Scope s(c, "k_ref_norm_chain");
+            const int kp = c->kp;
+            const int *ri = c->rowidx.as<int>();
+            float *out = c->norm_pwz.as<float>();
+            auto go = [&](auto NZ) {
+                hipLaunchKernelGGL((plsa::ref::k_ref_norm_chain<decltype(NZ)::value>), dim3(1), dim3(plsa::ref::CHAIN_THREADS), 0,
+                                   c->ls, ri, c->val, c->nnz, p_base(c), d_sw, kp, out);
+            };
+            using std::integral_constant;
+            if (kp <= 64) go(integral_constant<int, 1>{});
+            else if (kp <= 128) go(integral_constant<int, 2>{});
+            else if (kp <= 256) go(integral_constant<int, 4>{});
+            else if (kp <= 512) go(integral_constant<int, 8>{});
+            else go(integral_constant<int, 16>{});
+        }
+        c->ls = c->stream;
+        CHK(launch_check(c, "k_ref_norm_chain"));
+        HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+    }
+    CHK(dispatch_ref_group(c, [&](auto G, auto NZ) {
+        constexpr int g = decltype(G)::value, nz = decltype(NZ)::value;
+        {
+            Scope s(c, "k_ref_row_pass");
+            hipLaunchKernelGGL((plsa::ref::k_ref_row_pass<g, nz>), dim3(grid_for(c, c->n, 256 / g)), dim3(256),
+                               sizeof(float) * (size_t)(256 / g) * c->kp, c->stream, c->indptr, c->val, (int)c->n, order,
+                               p_base(c), c->U[out_u(c)].as<float>(), d_norm_pdz, c->kp);
+        }
+        if (update_v) {
+            Scope s(c, "k_ref_col_pass");
+            hipLaunchKernelGGL((plsa::ref::k_ref_col_pass<g, nz>), dim3(grid_for(c, c->m, 256 / g)), dim3(256), 0, c->stream,
+                               c->colptr.as<int>(), c->csc_row.as<int>(), c->csc_val.as<float>(), c->csc_pos.as<int>(),
+                               (int)c->m, p_base(c), d_sw, c->Vacc.as<float>(), c->kp);
+        }
+    }));
+    CHK(launch_check(c, "k_ref_row_pass / k_ref_col_pass"));
+    if (update_v) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        Scope s(c, "k_v_normalise");
+        const i64 total4 = c->m * c->kp / 4;
+        hipLaunchKernelGGL(plsa::k_v_normalise, dim3(grid_for(c, total4, 256)), dim3(256), c->kp * sizeof(float), c->stream,
+                           c->Vacc.as<float>(), c->Vt[out_v(c)].as<float>(), (int)c->m, c->kp, c->norm_pwz.as<float>());
+        CHK(launch_check(c, "k_v_normalise"));
+    }
+    c->cu ^= 1;
+    if (update_v) c->cv ^= 1;
+    return 0;
+}
+
+// plsa.py:372-386 as ONE float32 running sum over the non-zeros (PLSA_REFERENCE_LL)
+int run_ref_loglik(plsa_ctx *c, const float *d_sw, double *out) {
+    if (c->sharded) return fail(c, "the reference arithmetic has no doc-sharded form");
+    CHK(ensure_rowidx(c));
+    CHK(ensure(c, c->ref_terms, sizeof(float) * (size_t)std::max<i64>(c->nnz, 1)));
+    CHK(ensure(c, c->ll_out, sizeof(double)));
+    {
+        Scope s(c, "k_ref_ll_terms");
+        hipLaunchKernelGGL(plsa::ref::k_ref_ll_terms, dim3(grid_for(c, c->nnz, 256)), dim3(256), 0, c->stream,
+                           c->rowidx.as<int>(), c->col, c->val, c->nnz, c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
+                           d_sw, c->kp, c->ref_terms.as<float>());
+    }
+    {
+        Scope s(c, "k_ref_ll_chain");
+        hipLaunchKernelGGL(plsa::ref::k_ref_ll_chain, dim3(1), dim3(64), 0, c->stream, c->ref_terms.as<float>(), c->nnz,
+                           c->ll_out.as<double>());
+    }
+    CHK(launch_check(c, "k_ref_ll_chain"));
+    HIPCHK(c, hipMemcpyAsync(c->h_ll, c->ll_out.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out = *c->h_ll;
+    return 0;
+}
+
+// PLSA_REFERENCE_SUMS / PLSA_REFERENCE_LL of a driver call: in force for that call on top of plsa_set_arithmetic's setting
+struct ArithmeticScope {
+    plsa_ctx *c;
+    bool sums, ll;
+    ArithmeticScope(plsa_ctx *c_, int flags) : c(c_), sums(c_->ref_sums), ll(c_->ref_ll) {
+        if (flags & PLSA_REFERENCE_SUMS) c->ref_sums = true;
+        if (flags & PLSA_REFERENCE_LL) c->ref_ll = true;
+    }
+    ~ArithmeticScope() { c->ref_sums = sums; c->ref_ll = ll; }
+};
 
 // the reference's stop test, plsa.py:634-638: float32 arithmetic, float64 comparison with tolerance
 // (block_parallel_plsa.py:329-331 has no `change == 0` arm: zero_arm = false)
@@ -1248,7 +1400,7 @@ void plsa_destroy(plsa_ctx *c) {
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->U[2], &c->Vt[0], &c->Vt[1], &c->Vt[2], &c->Vacc,
                      &c->P, &c->sw, &c->sw_res, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
-                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp};
+                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp, &c->ref_terms};
     if (c->p_borrowed) { c->P.p = nullptr; c->P.cap = 0; }      // lent memory is the lender's to free
     for (DevBuf *b : all) release(*b);
     for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -1605,6 +1757,14 @@ int plsa_copy_components_to_device(plsa_ctx *c, void *dst) {
     return 0;
 }
 
+int plsa_set_arithmetic(plsa_ctx *c, int32_t mode) {
+    if (mode & ~(PLSA_REFERENCE_SUMS | PLSA_REFERENCE_LL))
+        return fail(c, "plsa_set_arithmetic: mode %d is not a combination of PLSA_REFERENCE_SUMS and PLSA_REFERENCE_LL", mode);
+    c->ref_sums = (mode & PLSA_REFERENCE_SUMS) != 0;
+    c->ref_ll = (mode & PLSA_REFERENCE_LL) != 0;
+    return 0;
+}
+
 int plsa_e_step(plsa_ctx *c, float thresh, float *P_out) {
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
@@ -1619,8 +1779,9 @@ int plsa_e_step(plsa_ctx *c, float thresh, float *P_out) {
 int plsa_set_p(plsa_ctx *c, const float *P) {
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
-    if (c->p_borrowed) {
-        if (c->P.cap < sizeof(float) * (size_t)(c->nnz + 64) * c->kp) return fail(c, "plsa_set_p: the borrowed P(z|w,d) buffer is too small");
+    if (c->p_borrowed || c->p_lent) {
+        if (c->P.cap < sizeof(float) * (size_t)(c->nnz + 64) * c->kp)
+            return fail(c, "plsa_set_p: the %s P(z|w,d) buffer is too small (it cannot be re-allocated while shared)", c->p_borrowed ? "borrowed" : "lent");
     } else
     CHK(ensure(c, c->P, sizeof(float) * (size_t)(c->nnz + 64) * c->kp + c->p_shift));
     if (c->kp != c->k) HIPCHK(c, hipMemsetAsync(p_base(c), 0, sizeof(float) * (size_t)c->nnz * c->kp, c->stream));
@@ -1670,7 +1831,12 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
     if (n_iter < 0 || n_iter_per_test <= 0) return fail(c, "plsa_fit: bad n_iter / n_iter_per_test");
-    const bool fused = flags & PLSA_FUSED, trace = flags & PLSA_TRACE_LL;
+    ArithmeticScope arithmetic_scope(c, flags);
+    if ((c->ref_sums || c->ref_ll) && (flags & PLSA_SHARDED))
+        return fail(c, "plsa_fit: PLSA_REFERENCE_SUMS / PLSA_REFERENCE_LL have no doc-sharded form (the reference's sums are single chains over all non-zeros)");
+    // the reference arithmetic IS the reference's kernel sequence (E-step into P(z|w,d), M-step from it, likelihood): there is
+    // one such arithmetic, so PLSA_FUSED has nothing to select there and is ignored
+    const bool fused = (flags & PLSA_FUSED) && !c->ref_sums && !c->ref_ll, trace = flags & PLSA_TRACE_LL;
     const bool zero_arm = !(flags & PLSA_STOP_NO_ZERO_ARM);
     struct ShardedScope {           // PLSA_SHARDED: this context's rows are one shard of the corpus
         plsa_ctx *c;
@@ -1929,7 +2095,8 @@ int plsa_refit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
     if (n_iter < 0 || n_iter_per_test <= 0) return fail(c, "plsa_refit: bad n_iter / n_iter_per_test");
-    const bool fused = flags & PLSA_FUSED, trace = flags & PLSA_TRACE_LL;
+    ArithmeticScope arithmetic_scope(c, flags);
+    const bool fused = (flags & PLSA_FUSED) && !c->ref_sums && !c->ref_ll, trace = flags & PLSA_TRACE_LL;
     const float *d_sw = nullptr;
     CHK(upload_sw(c, sw, &d_sw));
     int nll = 0, iters = 0;
@@ -2005,6 +2172,7 @@ int plsa_refit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_
 int plsa_em_accumulate(plsa_ctx *c, const float *sw, float thresh, double *ll_partial) {
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
+    if (c->ref_sums || c->ref_ll) return fail(c, "plsa_em_accumulate: the reference arithmetic (plsa_set_arithmetic) has no doc-sharded form");
     const float *d_sw = nullptr;
     CHK(upload_sw(c, sw, &d_sw));
     int blocks = 0;
@@ -2020,6 +2188,7 @@ int plsa_em_accumulate(plsa_ctx *c, const float *sw, float thresh, double *ll_pa
 int plsa_em_accumulate_materialised(plsa_ctx *c, const float *sw, float thresh, double *ll_partial) {
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
+    if (c->ref_sums || c->ref_ll) return fail(c, "plsa_em_accumulate_materialised: the reference arithmetic (plsa_set_arithmetic) has no doc-block form");
     const float *d_sw = nullptr;
     CHK(upload_sw(c, sw, &d_sw));
     if (ll_partial) CHK(run_loglik(c, d_sw, ll_partial));       // log-likelihood of the CURRENT factors, local rows
@@ -2038,8 +2207,13 @@ int plsa_p_reserve(plsa_ctx *c, int64_t bytes, void **device_ptr) {
     HIPCHK(c, hipSetDevice(c->device));
     if (bytes <= 0 || !device_ptr) return fail(c, "plsa_p_reserve: bad arguments");
     if (c->p_borrowed) return fail(c, "plsa_p_reserve: this context borrows its P(z|w,d) buffer");
+    if (c->p_lent && c->P.cap < (size_t)bytes)
+        return fail(c, "plsa_p_reserve: the buffer handed out earlier (%.2f GB) cannot grow to %.2f GB while other contexts may hold its "
+                       "address: end the loans (plsa_p_borrow(NULL)) and call plsa_release_scratch first", c->P.cap / 1e9, bytes / 1e9);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     CHK(ensure(c, c->P, (size_t)bytes));
+    c->p_lent = true;
+    c->p_shift = 0;
     c->p_valid = false;
     *device_ptr = c->P.p;
     return 0;
@@ -2290,8 +2464,12 @@ int plsa_schedule_info(plsa_ctx *c, int32_t *xcd_lo, double *xcd_end_us, int32_t
 int plsa_release_scratch(plsa_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->p_borrowed) { c->P.p = nullptr; c->P.cap = 0; c->p_borrowed = false; c->p_valid = false; }
-    release(c->P); release(c->partial); release(c->tmp0); release(c->tmp1); release(c->tmp2); release(c->cubtmp);
+    // a BORROWED P(z|w,d) stays borrowed (nothing of this context's own would be freed, and silently dropping the loan made
+    // the next materialising call allocate a private full-size array); a LENT one is freed: the caller ends the loans first
+    if (!c->p_borrowed) release(c->P);
+    c->p_lent = false;
+    release(c->ref_terms);
+    release(c->partial); release(c->tmp0); release(c->tmp1); release(c->tmp2); release(c->cubtmp);
     release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly); release(c->mt_seq);
     // member stack + gather buffers of the ensemble exchange (16 runs x 64 topics x 100 k words = 0.4 GB): re-created
     // by the next plsa_stack_reserve / plsa_comm_allgather_stack

@@ -1,0 +1,378 @@
+// plsa_ref_kernels.hpp -- the REFERENCE'S float32 arithmetic, rounding for rounding (PLSA_REFERENCE_SUMS / PLSA_REFERENCE_LL).
+//
+// The default kernels (plsa_kernels.hpp) add every corpus-long sum in a fixed order of their own, norm_pwz and the
+// log-likelihood in float64: more accurate than the reference, and therefore 1e-2 away from the reference's OWN output
+// from ~1e6 non-zeros on.  The kernels below evaluate the reference's statements with the
+// reference's roundings instead -- every sum one float32 accumulator, added in the order the reference's loops add --
+// so that a fit in this mode returns the bits `enstop/plsa.py` computes when its source is executed statement by
+// statement (the fixtures under tests/golden/*.npz, produced by the reference itself, are met bit for bit):
+//
+//   reference statement (enstop/plsa.py)                       here
+//   :96-105  v = P(w|z) P(z|d); norm += v (z = 0 .. k-1);      k_ref_e_step     one lane per non-zero walks the topics in
+//            P(z|w,d) = v / norm                                                order; true division
+//   :188     s = x * P(z|w,d)          (:294 t = s * sw[d])    every kernel     product rounded BEFORE it is added: the whole
+//                                                                               file is compiled with fp contraction off
+//   :190     p_w_given_z[z, w] += s    over nz = 0 .. nnz-1    k_ref_col_pass   a group owns a whole column; its entries in
+//                                                                               document order (stable CSC) = COO order
+//   :191     p_z_given_d[d, z] += s                            k_ref_row_pass   a group owns a document, entries in order
+//   :194     norm_pdz[d] += s          (entry-major, z-minor)  k_ref_row_pass   the row's k * len products added one by one
+//                                                                               (through LDS, every lane of the group)
+//   :193     norm_pwz[z] += s          over ALL nz             k_ref_norm_chain ONE chain of nnz dependent adds per topic:
+//                                                                               lane = topic, a workgroup streams x * P
+//                                                                               through LDS for its one adding wave
+//   :196-202 division by the norms where positive              k_v_normalise (plsa_kernels.hpp) / k_ref_row_pass
+//   :378-384 dot += P(w|z) P(z|d); result += x log(dot) sw     k_ref_ll_terms + k_ref_ll_chain (PLSA_REFERENCE_LL only): one
+//                                                                               float32 running sum over all non-zeros
+//
+// None of this is fast (the chains are the point); it is a PARITY mode: 10-60 ms per iteration at the BASELINE sizes the
+// tests run it on.  Layouts are the engine's (U [n,kp], Vt [m,kp] word-major, P [nnz,kp], pad entries zero: a zero product
+// adds +0.0, which changes no sum).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)   // s = x * p is rounded, THEN added (plsa.py:188-194): no fused multiply-add in this file
+
+namespace plsa {
+namespace ref {
+
+typedef long long i64;
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS traffic of one wave executes in program order; this only keeps the COMPILER from moving accesses across
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------
+// plsa.py:91-105.  One lane per non-zero: the topics are walked in order z = 0 .. k-1 with ONE float32
+// norm (plsa.py:33 types it float32), kept products divided by it (true division) when it is positive.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ref_e_step(const int *__restrict__ rowidx, const int *__restrict__ colidx,
+                                                    i64 nnz, const float *__restrict__ U, const float *__restrict__ Vt,
+                                                    float *__restrict__ P, int kp, float thresh) {
+    for (i64 nz = (i64)blockIdx.x * 256 + threadIdx.x; nz < nnz; nz += (i64)gridDim.x * 256) {
+        const float4 *u = reinterpret_cast<const float4 *>(U + (i64)rowidx[nz] * kp);
+        const float4 *v = reinterpret_cast<const float4 *>(Vt + (i64)colidx[nz] * kp);
+        float4 *p = reinterpret_cast<float4 *>(P + nz * kp);
+        const int q = kp >> 2;
+        float norm = 0.0f;
+        for (int c = 0; c < q; ++c) {
+            const float4 a = v[c], b = u[c];
+            const float t0 = a.x * b.x, t1 = a.y * b.y, t2 = a.z * b.z, t3 = a.w * b.w;
+            if (t0 > thresh) norm += t0;      // plsa.py:97-100 (a pad product is 0: it adds +0.0 at most)
+            if (t1 > thresh) norm += t1;
+            if (t2 > thresh) norm += t2;
+            if (t3 > thresh) norm += t3;
+        }
+        const bool pos = norm > 0.0f;         // plsa.py:104
+        for (int c = 0; c < q; ++c) {
+            const float4 a = v[c], b = u[c];
+            float4 o;
+            o.x = a.x * b.x; o.y = a.y * b.y; o.z = a.z * b.z; o.w = a.w * b.w;
+            o.x = o.x > thresh ? o.x : 0.0f; o.y = o.y > thresh ? o.y : 0.0f;
+            o.z = o.z > thresh ? o.z : 0.0f; o.w = o.w > thresh ? o.w : 0.0f;
+            if (pos) { o.x = o.x / norm; o.y = o.y / norm; o.z = o.z / norm; o.w = o.w / norm; }
+            p[c] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Document half of the M-step, plsa.py:188, 191, 194, 200-202 (and the refit M-step, :806-814).  A group of G lanes
+// owns a document; lane li holds the topics z = li + G t (t < NZ).  Per entry: s = x * P(z|w,d) (rounded), the
+// lane's own sums p_z_given_d[d, z] += s, and norm_pdz[d] += s for z = 0 .. k-1 IN THAT ORDER: the group's products go
+// through LDS and every lane adds them one by one (all lanes of a group carry the same chain).
+// ------------------------------------------------------------------------------------------------
+template <int G, int NZ>
+__global__ __launch_bounds__(256) void k_ref_row_pass(const int *__restrict__ indptr, const float *__restrict__ vals,
+                                                      int n, const int *__restrict__ row_order,
+                                                      const float *__restrict__ P, float *__restrict__ U_new,
+                                                      float *__restrict__ norm_pdz_out, int kp) {
+    extern __shared__ float s_lds[];          // [256 / G][kp]
+    constexpr int GPB = 256 / G;
+    const int li = threadIdx.x % G, gid = threadIdx.x / G;
+    float *mine = s_lds + gid * kp;
+    const float4 *mine4 = reinterpret_cast<const float4 *>(mine);
+    const int q = kp >> 2;
+    for (i64 r = (i64)blockIdx.x * GPB + gid; r < n; r += (i64)gridDim.x * GPB) {
+        const int d = row_order ? row_order[r] : (int)r;
+        const int j0 = indptr[d], j1 = indptr[d + 1];
+        float acc[NZ];
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) acc[t] = 0.0f;
+        float npdz = 0.0f;
+        // software pipeline: the next entry's count and P(z|w,d) values are requested before the current entry's chain
+        float xn = 0.0f, pn[NZ];
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) pn[t] = 0.0f;
+        if (j0 < j1) {
+            xn = vals[j0];
+#pragma unroll
+            for (int t = 0; t < NZ; ++t) { const int z = li + G * t; if (z < kp) pn[t] = P[(i64)j0 * kp + z]; }
+        }
+        for (int j = j0; j < j1; ++j) {
+            const float x = xn;
+            float pc[NZ];
+#pragma unroll
+            for (int t = 0; t < NZ; ++t) pc[t] = pn[t];
+            if (j + 1 < j1) {
+                xn = vals[j + 1];
+#pragma unroll
+                for (int t = 0; t < NZ; ++t) { const int z = li + G * t; if (z < kp) pn[t] = P[(i64)(j + 1) * kp + z]; }
+            }
+#pragma unroll
+            for (int t = 0; t < NZ; ++t) {
+                const int z = li + G * t;
+                if (z < kp) {
+                    const float s = x * pc[t];        // plsa.py:188
+                    acc[t] += s;                      // plsa.py:191
+                    mine[z] = s;
+                }
+            }
+            wave_lds_fence();
+            for (int c = 0; c < q; ++c) {             // plsa.py:194, z ascending
+                const float4 v = mine4[c];
+                npdz += v.x; npdz += v.y; npdz += v.z; npdz += v.w;
+            }
+            wave_lds_fence();
+        }
+        if (norm_pdz_out && li == 0) norm_pdz_out[d] = npdz;
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) {
+            const int z = li + G * t;
+            if (z < kp) U_new[(i64)d * kp + z] = npdz > 0.0f ? acc[t] / npdz : acc[t];   // plsa.py:200-202
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Vocabulary half, plsa.py:190 (296 with weights): p_w_given_z[z, w] += s over the non-zeros in COO order.  For one
+// word those are its column's entries in document order -- what the stable CSC holds -- so a group that owns the WHOLE
+// column (no items, no partial sums) and adds entry by entry reproduces the reference's accumulator bit for bit.
+// Un-normalised sums -> Vacc [m, kp]; B rows of P are in flight per group.
+// ------------------------------------------------------------------------------------------------
+template <int G, int NZ>
+__global__ __launch_bounds__(256) void k_ref_col_pass(const int *__restrict__ colptr, const int *__restrict__ csc_row,
+                                                      const float *__restrict__ csc_val, const int *__restrict__ csc_pos,
+                                                      int m, const float *__restrict__ P, const float *__restrict__ sw,
+                                                      float *__restrict__ Vacc, int kp) {
+    constexpr int GPB = 256 / G;
+    constexpr int B = 8;
+    const int li = threadIdx.x % G, gid = threadIdx.x / G;
+    for (i64 w = (i64)blockIdx.x * GPB + gid; w < m; w += (i64)gridDim.x * GPB) {
+        const int j0 = colptr[w], j1 = colptr[w + 1];
+        float acc[NZ];
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) acc[t] = 0.0f;
+        for (int jb = j0; jb < j1; jb += B) {
+            float p[B][NZ], x[B], wd[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const int j = min(jb + b, j1 - 1);
+                const i64 pos = csc_pos[j];
+                x[b] = csc_val[j];
+                wd[b] = sw ? sw[csc_row[j]] : 1.0f;
+#pragma unroll
+                for (int t = 0; t < NZ; ++t) {
+                    const int z = li + G * t;
+                    p[b][t] = z < kp ? P[pos * kp + z] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                if (jb + b < j1) {
+#pragma unroll
+                    for (int t = 0; t < NZ; ++t) {
+                        float s = x[b] * p[b][t];          // plsa.py:188
+                        if (sw) s = s * wd[b];             // plsa.py:294
+                        acc[t] += s;                       // plsa.py:190 / :296
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) {
+            const int z = li + G * t;
+            if (z < kp) Vacc[w * kp + z] = acc[t];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// norm_pwz[z] += s over ALL non-zeros, plsa.py:193 (:299 with weights): one float32 accumulator per topic and a chain
+// of nnz dependent additions -- the statement that carries the reference 1e-2 away from exact arithmetic at 3 M
+// non-zeros, and the one a drop-in has to reproduce to land on the reference's own numbers.
+//
+// ONE workgroup of 1024 lanes.  All sixteen waves stream t = (x * P(z|w,d)) [* sw[d]] -- tiles of CHAIN_TILE floats
+// of the P array, DEPTH tiles ahead in registers -- into a double-buffered LDS tile; wave 0 alone walks each tile row by
+// row, lane = topic (z = lane + 64 t), one dependent v_add_f32 per row and chain.  One barrier per tile: the tile being
+// refilled is the one wave 0 finished before it arrived at the previous barrier.
+// ------------------------------------------------------------------------------------------------
+constexpr int CHAIN_THREADS = 1024;
+constexpr int CHAIN_TILE = 8192;                       // floats per LDS tile (32 KB; two tiles)
+constexpr int CHAIN_F4 = CHAIN_TILE / 4 / CHAIN_THREADS;   // float4 per lane and tile (2)
+constexpr int CHAIN_DEPTH = 4;                         // tiles in flight in registers
+
+template <int NZ>
+__global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__restrict__ rowidx,
+                                                                  const float *__restrict__ vals, i64 nnz,
+                                                                  const float *__restrict__ P,
+                                                                  const float *__restrict__ sw, int kp,
+                                                                  float *__restrict__ norm_pwz) {
+    __shared__ float4 tile[2][CHAIN_TILE / 4];
+    const int tid = threadIdx.x;
+    const int rows_per_tile = CHAIN_TILE / kp;                 // whole rows only
+    const int f4_per_tile = rows_per_tile * kp / 4;
+    const i64 n_tiles = (nnz + rows_per_tile - 1) / rows_per_tile;
+    const int kq = kp >> 2;
+    // the lane's float4 slots inside a tile and the tile-relative row each belongs to (the same for every tile)
+    int slot[CHAIN_F4], srow[CHAIN_F4];
+#pragma unroll
+    for (int s = 0; s < CHAIN_F4; ++s) {
+        slot[s] = tid + CHAIN_THREADS * s;
+        srow[s] = slot[s] / kq;
+    }
+    float4 reg[CHAIN_DEPTH][CHAIN_F4];
+    auto fetch = [&](i64 t, float4 (&dst)[CHAIN_F4]) {
+        const i64 row0 = t * rows_per_tile;
+#pragma unroll
+        for (int s = 0; s < CHAIN_F4; ++s) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            const i64 nz = row0 + srow[s];
+            if (t < n_tiles && slot[s] < f4_per_tile && nz < nnz) {
+                const float4 p = *reinterpret_cast<const float4 *>(P + row0 * kp + (i64)slot[s] * 4);
+                const float x = vals[nz];
+                o.x = x * p.x; o.y = x * p.y; o.z = x * p.z; o.w = x * p.w;                 // plsa.py:188
+                if (sw) { const float wd = sw[rowidx[nz]]; o.x = o.x * wd; o.y = o.y * wd; o.z = o.z * wd; o.w = o.w * wd; }   // :294
+            }
+            dst[s] = o;
+        }
+    };
+#pragma unroll
+    for (int dd = 0; dd < CHAIN_DEPTH; ++dd) fetch(dd, reg[dd]);
+    float acc[NZ];
+#pragma unroll
+    for (int t = 0; t < NZ; ++t) acc[t] = 0.0f;
+    for (i64 t0 = 0; t0 < n_tiles; t0 += CHAIN_DEPTH) {
+#pragma unroll
+        for (int dd = 0; dd < CHAIN_DEPTH; ++dd) {           // static register indices; tile t = t0 + dd
+            const i64 t = t0 + dd;
+            if (t >= n_tiles) break;                         // (uniform)
+            float4 *buf = tile[dd & 1];                      // CHAIN_DEPTH is even: buffer parity == parity of t
+#pragma unroll
+            for (int s = 0; s < CHAIN_F4; ++s)
+                if (slot[s] < f4_per_tile) buf[slot[s]] = reg[dd][s];
+            __syncthreads();
+            fetch(t + CHAIN_DEPTH, reg[dd]);
+            if (tid < 64) {
+                const float *rowp = reinterpret_cast<const float *>(buf);
+                const int rows = (int)min((i64)rows_per_tile, nnz - t * rows_per_tile);
+                constexpr int UN = NZ >= 8 ? 2 : (NZ == 4 ? 4 : 8);     // rows whose LDS reads are issued ahead of their adds
+                int r = 0;
+                for (; r + UN <= rows; r += UN) {
+                    float v[UN][NZ];
+#pragma unroll
+                    for (int u = 0; u < UN; ++u)
+#pragma unroll
+                        for (int c = 0; c < NZ; ++c) {
+                            const int z = tid + 64 * c;
+                            v[u][c] = z < kp ? rowp[(r + u) * kp + z] : 0.0f;
+                        }
+#pragma unroll
+                    for (int u = 0; u < UN; ++u)
+#pragma unroll
+                        for (int c = 0; c < NZ; ++c) acc[c] += v[u][c];      // plsa.py:193
+                }
+                for (; r < rows; ++r)
+#pragma unroll
+                    for (int c = 0; c < NZ; ++c) {
+                        const int z = tid + 64 * c;
+                        acc[c] += z < kp ? rowp[r * kp + z] : 0.0f;
+                    }
+            }
+        }
+    }
+    if (tid < 64) {
+#pragma unroll
+        for (int c = 0; c < NZ; ++c) {
+            const int z = tid + 64 * c;
+            if (z < kp) norm_pwz[z] = acc[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PLSA_REFERENCE_LL: the log-likelihood as the reference's SOURCE states it, plsa.py:372-384 -- p_w_given_d one float32
+// sum over the topics in order, result one float32 running sum over the non-zeros in order (plsa.py:322).  (What a numba
+// user sees is something else: the compiled prange reduction is vectorised and lands within 1e-7 of the float64 sum at
+// config 1, where this chain is 3.4e-3 away -- DESIGN.md section 2.)  The logarithm: float64 log of the float32 dot,
+// rounded to float32 -- within an ulp of any libm's logf (NumPy's, glibc's and numba's differ from each other in the
+// last place as well).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ref_ll_terms(const int *__restrict__ rowidx, const int *__restrict__ colidx,
+                                                      const float *__restrict__ vals, i64 nnz,
+                                                      const float *__restrict__ U, const float *__restrict__ Vt,
+                                                      const float *__restrict__ sw, int kp, float *__restrict__ terms) {
+    for (i64 nz = (i64)blockIdx.x * 256 + threadIdx.x; nz < nnz; nz += (i64)gridDim.x * 256) {
+        const int d = rowidx[nz];
+        const float4 *u = reinterpret_cast<const float4 *>(U + (i64)d * kp);
+        const float4 *v = reinterpret_cast<const float4 *>(Vt + (i64)colidx[nz] * kp);
+        float dot = 0.0f;
+        for (int c = 0; c < (kp >> 2); ++c) {       // plsa.py:380-381
+            const float4 a = v[c], b = u[c];
+            dot += a.x * b.x; dot += a.y * b.y; dot += a.z * b.z; dot += a.w * b.w;
+        }
+        const float lg = (float)log((double)dot);
+        float term = vals[nz] * lg;                  // plsa.py:383: x * log(p) * sample_weight[d], left to right
+        term = term * (sw ? sw[d] : 1.0f);
+        terms[nz] = term;
+    }
+}
+
+// one wave: terms are loaded 64 at a time (PF loads in flight), every lane adds them in order (same chain in all lanes)
+__global__ __launch_bounds__(64) void k_ref_ll_chain(const float *__restrict__ terms, i64 nnz, double *__restrict__ out) {
+    constexpr int PF = 16;
+    __shared__ float4 sx[2][16];
+    const int lane = threadIdx.x;
+    float nxt[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const i64 i = (i64)p * 64 + lane;
+        nxt[p] = i < nnz ? terms[i] : 0.0f;
+    }
+    float s = 0.0f;
+    for (i64 base = 0; base < nnz; base += 64 * PF) {
+        float cur[PF];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) cur[p] = nxt[p];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const i64 i = base + 64 * PF + (i64)p * 64 + lane;
+            nxt[p] = i < nnz ? terms[i] : 0.0f;
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const i64 first = base + (i64)p * 64;
+            if (first >= nnz) break;
+            reinterpret_cast<float *>(sx[p & 1])[lane] = cur[p];
+            wave_lds_fence();
+            const int cnt = (int)min((i64)64, nnz - first);
+            if (cnt == 64) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const float4 v = sx[p & 1][c];
+                    s += v.x; s += v.y; s += v.z; s += v.w;          // plsa.py:383
+                }
+            } else {
+                for (int c = 0; c < cnt; ++c) s += reinterpret_cast<const float *>(sx[p & 1])[c];
+            }
+            wave_lds_fence();
+        }
+    }
+    if (lane == 0) out[0] = (double)s;
+}
+
+}  // namespace ref
+}  // namespace plsa
+
+#pragma clang fp contract(fast)   // hipcc's default for the rest of the translation unit

@@ -11,7 +11,8 @@ import threading
 import numpy as np
 
 from . import _lib
-from ._lib import PLSA_FUSED, PLSA_SHARDED, PLSA_STOP_NO_ZERO_ARM, PLSA_SW_LL_ONLY, PLSA_TRACE_LL, ptr
+from ._lib import (PLSA_FUSED, PLSA_REFERENCE_LL, PLSA_REFERENCE_SUMS, PLSA_SHARDED, PLSA_STOP_NO_ZERO_ARM, PLSA_SW_LL_ONLY,
+                   PLSA_TRACE_LL, ptr)
 
 
 class DeviceError(RuntimeError):
@@ -36,10 +37,33 @@ def default_device():
     return dev
 
 
+def arithmetic_flags(arithmetic):
+    """`arithmetic=` of the fit functions -> flag bits.  None / "default": the engine's own summation orders (float64
+    norm_pwz and log-likelihood; more accurate than the reference).  "reference": PLSA_REFERENCE_SUMS -- every sum of the
+    E- and M-step one float32 accumulator in the reference's loop order: the bits of enstop/plsa.py executed statement
+    by statement; the log-likelihood stays float64-accumulated (what the numba-compiled reduction delivers to 1e-7).
+    "reference_source": additionally PLSA_REFERENCE_LL -- the log-likelihood as ONE float32 running sum (plsa.py:322
+    read literally, one thread).  An int passes through."""
+    if arithmetic is None or arithmetic == "default":
+        return 0
+    if isinstance(arithmetic, (int, np.integer)):
+        if int(arithmetic) & ~(PLSA_REFERENCE_SUMS | PLSA_REFERENCE_LL):
+            raise ValueError("arithmetic bits must be PLSA_REFERENCE_SUMS | PLSA_REFERENCE_LL")
+        return int(arithmetic)
+    if arithmetic == "reference":
+        return PLSA_REFERENCE_SUMS
+    if arithmetic == "reference_source":
+        return PLSA_REFERENCE_SUMS | PLSA_REFERENCE_LL
+    raise ValueError('arithmetic must be None, "default", "reference" or "reference_source", not %r' % (arithmetic,))
+
+
 def default_flags():
     """Fit schedule: fused (P(z|w,d) never touches HBM) unless ENSTOP_AMD_MATERIALISE=1, which
-    follows the reference's E-step -> M-step kernel sequence through a materialised nnz x k array."""
-    return 0 if os.environ.get("ENSTOP_AMD_MATERIALISE", "0") == "1" else PLSA_FUSED
+    follows the reference's E-step -> M-step kernel sequence through a materialised nnz x k array.
+    ENSTOP_AMD_ARITHMETIC=reference / reference_source selects the reference's rounding (arithmetic_flags)
+    for every fit that does not say otherwise."""
+    flags = 0 if os.environ.get("ENSTOP_AMD_MATERIALISE", "0") == "1" else PLSA_FUSED
+    return flags | arithmetic_flags(os.environ.get("ENSTOP_AMD_ARITHMETIC") or None)
 
 
 def _f32(a):
@@ -213,6 +237,11 @@ class Engine:
         self._ok(self._L.plsa_copy_components_to_device(self._h, int(device_ptr)))
 
     # -- kernel-level operators --------------------------------------------------------------------
+    def set_arithmetic(self, arithmetic=None):
+        """Arithmetic of e_step / m_step / log_likelihood and of later fits on this engine (arithmetic_flags)."""
+        self._ok(self._L.plsa_set_arithmetic(self._h, arithmetic_flags(arithmetic)))
+        return self
+
     def e_step(self, thresh=1e-32, out=None, want_host_copy=True):
         _, _, nnz = self.shape
         if want_host_copy and out is None:

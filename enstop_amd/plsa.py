@@ -23,7 +23,7 @@ from scipy.sparse import csr_matrix, issparse
 from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_array, check_random_state
 
-from .engine import PLSA_SW_LL_ONLY, PLSA_STOP_NO_ZERO_ARM, default_flags, get_engine
+from .engine import PLSA_SW_LL_ONLY, PLSA_STOP_NO_ZERO_ARM, arithmetic_flags, default_flags, get_engine
 from .utils import (_check_sample_weight, coherence, log_lift, mean_coherence, mean_log_lift, normalize,
                     standardize_input)
 
@@ -66,7 +66,23 @@ def _locked(fn):
     return wrapper
 
 
-def _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device=None):
+class _KernelArithmetic:
+    """Arithmetic of ONE kernel-level call on the shared engine (None = the engine's own or ENSTOP_AMD_ARITHMETIC;
+    "reference": the reference's bits, which presupposes the reference's entry order -- triplets that had to be re-sorted
+    are summed in row-major order); the engine is handed back in its default arithmetic."""
+
+    def __init__(self, eng, arithmetic):
+        self.eng = eng
+        self.arithmetic = arithmetic if arithmetic is not None else (os.environ.get("ENSTOP_AMD_ARITHMETIC") or None)
+
+    def __enter__(self):
+        self.eng.set_arithmetic(self.arithmetic)
+
+    def __exit__(self, *exc):
+        self.eng.set_arithmetic(None)
+
+
+def _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device=None, arithmetic=None):
     k, m = p_w_given_z.shape
     n = p_z_given_d.shape[0]
     csr, order = _coo_to_csr(X_rows, X_cols, X_vals, n, m)
@@ -78,10 +94,11 @@ def _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device=None):
 
 @_locked
 def plsa_e_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd,
-                probability_threshold=1e-32, device=None):
+                probability_threshold=1e-32, device=None, arithmetic=None):
     """P(z|w,d) for every stored (d, w); fills and returns `p_z_given_wd` [nnz, k]."""
-    eng, order = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device)
-    P = eng.e_step(probability_threshold)
+    eng, order = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device, arithmetic)
+    with _KernelArithmetic(eng, arithmetic):
+        P = eng.e_step(probability_threshold)
     if order is None:
         p_z_given_wd[...] = P
     else:
@@ -91,11 +108,12 @@ def plsa_e_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd,
 
 @_locked
 def _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, sample_weight,
-            norm_pwz, norm_pdz, update_v, device):
-    eng, order = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device)
+            norm_pwz, norm_pdz, update_v, device, arithmetic=None):
+    eng, order = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device, arithmetic)
     P = np.asarray(p_z_given_wd, np.float32)
     eng.set_p(P if order is None else P[order])
-    npwz, npdz = eng.m_step(sample_weight, update_v=update_v)
+    with _KernelArithmetic(eng, arithmetic):
+        npwz, npdz = eng.m_step(sample_weight, update_v=update_v)
     U, V = eng.get_factors(want_v=update_v)
     p_z_given_d[...] = U
     if update_v:
@@ -108,32 +126,33 @@ def _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, samp
 
 
 def plsa_m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, norm_pwz, norm_pdz,
-                device=None):
+                device=None, arithmetic=None):
     """New P(w|z), P(z|d) from P(z|w,d); overwrites both factor arrays in place and returns them."""
     return _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, None, norm_pwz,
-                   norm_pdz, True, device)
+                   norm_pdz, True, device, arithmetic)
 
 
 def plsa_m_step_w_sample_weight(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd,
-                                sample_weight, norm_pwz, norm_pdz, device=None):
+                                sample_weight, norm_pwz, norm_pdz, device=None, arithmetic=None):
     """As plsa_m_step with per-document weights entering P(w|z) only (plsa.py:293-300)."""
     return _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, sample_weight,
-                   norm_pwz, norm_pdz, True, device)
+                   norm_pwz, norm_pdz, True, device, arithmetic)
 
 
 def plsa_refit_m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, sample_weight,
-                      norm_pdz, device=None):
+                      norm_pdz, device=None, arithmetic=None):
     """M-step for P(z|d) only, topics frozen; `sample_weight` is accepted and unused exactly like
     the reference (plsa.py:801-814)."""
     return _m_step(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd, None, None,
-                   norm_pdz, False, device)
+                   norm_pdz, False, device, arithmetic)
 
 
 @_locked
-def log_likelihood(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, sample_weight, device=None):
+def log_likelihood(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, sample_weight, device=None, arithmetic=None):
     """sum x * log(sum_z P(w|z) P(z|d)) * sample_weight[d], returned as float32 like the reference."""
-    eng, _ = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device)
-    return np.float32(eng.log_likelihood(sample_weight))
+    eng, _ = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device, arithmetic)
+    with _KernelArithmetic(eng, arithmetic):
+        return np.float32(eng.log_likelihood(sample_weight))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -199,11 +218,11 @@ def plsa_init(X, k, init="random", rng=np.random):
 @_locked
 def plsa_fit_inner(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, sample_weight, n_iter=100,
                    n_iter_per_test=10, tolerance=0.001, e_step_thresh=1e-32,
-                   use_sample_weights=False, device=None, flags=None):
+                   use_sample_weights=False, device=None, flags=None, arithmetic=None):
     """EM loop on COO triplets; factor arrays are updated in place and returned (plsa.py:517-640)."""
     eng, _ = _stage(X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, device)
     sw = np.asarray(sample_weight, np.float32)
-    flags = default_flags() if flags is None else flags
+    flags = (default_flags() if flags is None else flags) | arithmetic_flags(arithmetic)
     # the weighted M-step only when requested (plsa.py:606-628); the log-likelihood always sees the
     # weights (plsa.py:591, 631): non-unit weights with use_sample_weights=False reach the engine
     # with the PLSA_SW_LL_ONLY flag
@@ -264,14 +283,17 @@ def _fit_on_engine(eng, k, sample_weight, init, n_iter, n_iter_per_test, toleran
 
 @_locked
 def plsa_fit(X, k, sample_weight, init="random", n_iter=100, n_iter_per_test=10, tolerance=0.001,
-             e_step_thresh=1e-32, random_state=None, device=None, flags=None, return_info=False):
+             e_step_thresh=1e-32, random_state=None, device=None, flags=None, return_info=False, arithmetic=None):
     """Fit pLSA with k topics to the sparse doc-term matrix X; returns (P(z|d) [n,k], P(w|z) [k,m]),
-    both float32 (plsa.py:643-730).  Extra keyword arguments select the device and the kernel
-    schedule (fused / materialised); positional compatibility is unchanged."""
+    both float32 (plsa.py:643-730).  Extra keyword arguments select the device, the kernel
+    schedule (fused / materialised) and the arithmetic (`arithmetic="reference"`: the reference's float32 sums,
+    rounding for rounding -- engine.arithmetic_flags); positional compatibility is unchanged."""
     if not issparse(X):
         X = csr_matrix(X)
     eng = get_engine(device)
     eng.upload_csr(X)
+    if arithmetic is not None:
+        flags = (default_flags() if flags is None else flags) | arithmetic_flags(arithmetic)
     iters, ll = _fit_on_engine(eng, k, sample_weight, init, n_iter, n_iter_per_test, tolerance,
                                e_step_thresh, random_state, flags, trace=return_info, X_for_init=X)
     p_z_given_d, p_w_given_z = eng.get_factors()
@@ -282,10 +304,12 @@ def plsa_fit(X, k, sample_weight, init="random", n_iter=100, n_iter_per_test=10,
 
 @_locked
 def plsa_refit_inner(X_rows, X_cols, X_vals, topics, p_z_given_d, sample_weight, n_iter=50,
-                     n_iter_per_test=10, tolerance=0.005, e_step_thresh=1e-32, device=None, flags=None):
+                     n_iter_per_test=10, tolerance=0.005, e_step_thresh=1e-32, device=None, flags=None, arithmetic=None):
     """EM on P(z|d) with the topics frozen (plsa.py:820-920); returns P(z|d)."""
     eng, _ = _stage(X_rows, X_cols, X_vals, topics, p_z_given_d, device)
     sw = np.asarray(sample_weight, np.float32)
+    if arithmetic is not None:
+        flags = (default_flags() if flags is None else flags) | arithmetic_flags(arithmetic)
     eng.refit(None if not np.any(sw != 1.0) else sw, n_iter, n_iter_per_test, tolerance, e_step_thresh, flags)
     U, _ = eng.get_factors(want_v=False)
     p_z_given_d[...] = U
@@ -294,8 +318,10 @@ def plsa_refit_inner(X_rows, X_cols, X_vals, topics, p_z_given_d, sample_weight,
 
 @_locked
 def plsa_refit(X, topics, sample_weight, n_iter=50, n_iter_per_test=10, tolerance=0.005,
-               e_step_thresh=1e-32, random_state=None, device=None, flags=None, return_info=False):
+               e_step_thresh=1e-32, random_state=None, device=None, flags=None, return_info=False, arithmetic=None):
     """Document vectors P(z|d) for X against fixed `topics` (plsa.py:923-997)."""
+    if arithmetic is not None:
+        flags = (default_flags() if flags is None else flags) | arithmetic_flags(arithmetic)
     if not issparse(X):
         X = csr_matrix(X)
     topics = np.asarray(topics)
@@ -359,8 +385,9 @@ class PLSA(_TopicMetricsMixin, BaseEstimator, TransformerMixin):
 
     def __init__(self, n_components=10, init="random", n_iter=100, n_iter_per_test=10,
                  tolerance=0.001, e_step_thresh=1e-32, transform_random_seed=42, random_state=None,
-                 device=None):
+                 device=None, arithmetic=None):
         self.n_components = n_components
+        self.arithmetic = arithmetic
         self.init = init
         self.n_iter = n_iter
         self.n_iter_per_test = n_iter_per_test
@@ -373,7 +400,8 @@ class PLSA(_TopicMetricsMixin, BaseEstimator, TransformerMixin):
     _extra_flags = 0      # subclasses: stop-test variant of the reference module they stand in for
 
     def _flags(self):
-        return default_flags() | self._extra_flags
+        # arithmetic="reference": the reference's float32 sums, rounding for rounding (engine.arithmetic_flags)
+        return default_flags() | self._extra_flags | arithmetic_flags(getattr(self, "arithmetic", None))
 
     def _fit_factors(self, X, sample_weight):
         return plsa_fit(X, self.n_components, sample_weight, self.init, self.n_iter, self.n_iter_per_test,
@@ -429,11 +457,11 @@ class StreamedPLSA(PLSA):
 
     def __init__(self, n_components=10, init="random", block_size=65536, n_iter=100, n_iter_per_test=10,
                  tolerance=0.001, e_step_thresh=1e-32, transform_random_seed=42, random_state=None,
-                 device=None):
+                 device=None, arithmetic=None):
         super().__init__(n_components=n_components, init=init, n_iter=n_iter,
                          n_iter_per_test=n_iter_per_test, tolerance=tolerance,
                          e_step_thresh=e_step_thresh, transform_random_seed=transform_random_seed,
-                         random_state=random_state, device=device)
+                         random_state=random_state, device=device, arithmetic=arithmetic)
         self.block_size = block_size
 
     # streamed_plsa.py:596-597: the stop test has no `change == 0` arm
@@ -441,7 +469,7 @@ class StreamedPLSA(PLSA):
 
     def _flags(self):
         from .engine import PLSA_FUSED
-        return PLSA_FUSED | self._extra_flags
+        return PLSA_FUSED | self._extra_flags | arithmetic_flags(getattr(self, "arithmetic", None))
 
     def transform(self, X, y=None, sample_weight=None):
         """streamed_plsa.py:1237: unlike PLSA.transform this one takes `sample_weight` (it only enters
@@ -473,11 +501,11 @@ class BlockParallelPLSA(PLSA):
 
     def __init__(self, n_components=10, init="random", n_row_blocks=8, n_col_blocks=8, n_iter=100,
                  n_iter_per_test=10, tolerance=0.001, e_step_thresh=1e-32, transform_random_seed=42,
-                 random_state=None, device=None):
+                 random_state=None, device=None, arithmetic=None):
         super().__init__(n_components=n_components, init=init, n_iter=n_iter,
                          n_iter_per_test=n_iter_per_test, tolerance=tolerance,
                          e_step_thresh=e_step_thresh, transform_random_seed=transform_random_seed,
-                         random_state=random_state, device=device)
+                         random_state=random_state, device=device, arithmetic=arithmetic)
         self.n_row_blocks = n_row_blocks
         self.n_col_blocks = n_col_blocks
 

@@ -6,6 +6,8 @@
  * below, and its own accelerator plug point is the `plsa_fit` swap at enstop/enstop_.py:52-53,92-114.
  * Each entry point names the reference interface it replaces (paths relative to the reference root).
  * enstop_amd/_lib.py is the ctypes binding; INTEGRATION.md shows the stub a maintainer would add.
+ * Diagnostics, measurement hooks, test plumbing and the synthetic-corpus generators of the same library -- nothing a
+ * maintainer binding the seam needs -- are declared in include/plsa_hip_diag.h.
  *
  * Conventions
  *   - Every function returns 0 on success and a non-zero status on failure; the message is available
@@ -42,6 +44,19 @@ enum {
                            (`change / |cur| < tolerance` only, no `change == 0` arm)               */
     PLSA_GRAPH     = 128, /* plsa_fit (fused): replay the iterations between two likelihood tests from a hipGraph
                            of two iterations captured from the same launch sequence; results identical           */
+    PLSA_REFERENCE_SUMS = 256, /* plsa_fit / plsa_refit: THE REFERENCE'S ROUNDING.  Every sum of the E- and M-step is one float32
+                           accumulator added in the order the reference's loops add: the E-step norm over z = 0 .. k-1
+                           (enstop/plsa.py:96-105, true division), s = x * P(z|w,d) rounded before it is added (:188), P(w|z) columns
+                           and P(z|d) rows entry by entry in COO order (:190-191), norm_pdz entry-major / topic-minor (:194) and
+                           norm_pwz[z] as ONE chain over all non-zeros (:193) -- the sum that puts the reference 1e-2 from exact
+                           arithmetic at 3 M non-zeros.  Results are the bits of the reference's source executed statement by
+                           statement (tests/golden/*.npz; the numba-compiled reference sits 2e-5 from them at config 1).  The
+                           kernel sequence is the reference's (P(z|w,d) materialised; PLSA_FUSED is ignored); a parity mode, 10-60 ms
+                           per iteration at the BASELINE sizes, not available with PLSA_SHARDED.  The log-likelihood stays the
+                           float64-accumulated one (which is what the compiled reference's vectorised reduction delivers to 1e-7) unless: */
+    PLSA_REFERENCE_LL = 512, /* the log-likelihood as ONE float32 running sum over the non-zeros in COO order, its inner product a float32
+                           sum over the topics in order (enstop/plsa.py:322, 378-384 read literally: one thread, no SIMD).  3.4e-3 from
+                           the exact value at config 1 -- enough to move a default-tolerance stop from iteration 61 to 71      */
     PLSA_SHARDED   = 64 /* plsa_fit: the context's rows are ONE SHARD of the corpus; the P(w|z)
                            accumulator and the log-likelihood are all-reduced over the context's RCCL
                            communicator every iteration (plsa_comm_init); every rank passes the same
@@ -56,14 +71,11 @@ enum {
  * concurrently sets GPU_MAX_HW_QUEUES=8 itself before its first HIP call -- enstop_amd/_lib.py does so unless
  * ENSTOP_AMD_HW_QUEUES=0 or the variable is already set; plsa_hw_queues() returns the value this process runs with. */
 int plsa_device_count(int *count);
-int plsa_hw_queues(void);
 int plsa_create(int device, plsa_ctx **out);
 void plsa_destroy(plsa_ctx *ctx);
 /* ctx may be NULL: returns the last error of a failed plsa_create()/plsa_device_count(). */
 const char *plsa_last_error(const plsa_ctx *ctx);
 int plsa_synchronize(plsa_ctx *ctx);
-/* 64-char device name ("AMD Instinct MI355X"), gcnArchName, CU count and HBM bytes. */
-int plsa_device_info(plsa_ctx *ctx, char *name64, char *arch64, int *cus, int64_t *hbm_bytes);
 
 /* ---- corpus ------------------------------------------------------------------------------------
  * plsa_upload_csr: the doc-term matrix X, replaces `A = X.tocoo().astype(np.float32)`
@@ -73,12 +85,11 @@ int plsa_device_info(plsa_ctx *ctx, char *name64, char *arch64, int *cus, int64_
  *   resident (later calls answer "no corpus uploaded").
  * plsa_bootstrap: active := base[idx, :] gathered on the device; replaces
  *   `B = A[bootstrap_sample_indices]` (enstop/enstop_.py:87-88).  idx == NULL restores active := base.
- * plsa_active_shape / plsa_download_active_csr: read back the active matrix (tests).           */
+ * plsa_active_shape: dimensions of the active matrix (plsa_download_active_csr: plsa_hip_diag.h).            */
 int plsa_upload_csr(plsa_ctx *ctx, const int32_t *indptr, const int32_t *indices, const float *data,
                     int64_t n, int64_t m, int64_t nnz);
 int plsa_bootstrap(plsa_ctx *ctx, const int64_t *idx, int64_t n_out);
 int plsa_active_shape(plsa_ctx *ctx, int64_t *n, int64_t *m, int64_t *nnz);
-int plsa_download_active_csr(plsa_ctx *ctx, int32_t *indptr, int32_t *indices, float *data);
 
 /* ---- factors -----------------------------------------------------------------------------------
  * plsa_set_factors: current estimates (p_z_given_d [n,k], p_w_given_z [k,m]) as produced by
@@ -89,10 +100,6 @@ int plsa_download_active_csr(plsa_ctx *ctx, int32_t *indptr, int32_t *indices, f
  *   memory (e.g. a buffer handed to an RCCL all-gather: the np.vstack of enstop/enstop_.py:231).  */
 int plsa_set_factors(plsa_ctx *ctx, const float *U, const float *V, int64_t n, int64_t m, int32_t k);
 int plsa_get_factors(plsa_ctx *ctx, float *U, float *V);
-/* Throughput-mode alternative to plsa_init(random) + plsa_set_factors: uniform draws from a
- * counter-based generator, rows L1-normalised, entirely on the device.  NOT the reference's NumPy
- * MT19937 stream -- use plsa_set_factors for seed-for-seed parity (enstop/plsa.py:455-456).      */
-int plsa_init_factors_device(plsa_ctx *ctx, int32_t k, uint64_t seed);
 /* plsa_init(X, k, init="random", rng) + the float32 casts (enstop/plsa.py:455-456, 510-511, 709-710)
  * evaluated on the device WITH the reference's random stream: state_io holds the 624 MT19937 key
  * words followed by the position, i.e. numpy.random.RandomState.get_state()[1:3]; k*m + n*k doubles
@@ -100,10 +107,6 @@ int plsa_init_factors_device(plsa_ctx *ctx, int32_t k, uint64_t seed);
  * back (set_state it to leave the host generator where the reference would).  Bit-identical to
  * the host path, ~7x faster at config 3.                                                        */
 int plsa_init_factors_mt19937(plsa_ctx *ctx, int32_t k, uint32_t *state_io);
-/* Diagnostics: the k float64 topic marginals (enstop/utils.py:24-29, `marginal[i] += ndarray[i, j]` left to right) that the
- * last plsa_init_factors_mt19937 call divided by.  The device evaluates that sequential sum from per-chunk parity pairs
- * (csrc/plsa_kernels.hpp: k_mt_chunk_pairs); the tests pin it bit for bit to numpy's own sequential accumulation.   */
-int plsa_mt_marginals(plsa_ctx *ctx, double *out, int32_t k);
 /* The initialisation of plsa_refit (enstop/plsa.py:979-981): p_z_given_d = rng.rand(n, k), L1 row
  * normalised in float64, cast to float32 -- drawn on the device from the same stream -- against the
  * given fixed topics V [k, m] (host, float32).                                                      */
@@ -113,7 +116,6 @@ int plsa_copy_components_to_device(plsa_ctx *ctx, void *dst_device_km);
 /* ---- kernel-level operators ---------------------------------------------------------------------
  * plsa_e_step           <- plsa_e_step                  enstop/plsa.py:39-107 (signature :26)
  *   materialises P(z|w,d) [nnz,k] in HBM; P_out (nullable) receives a host copy.
- * plsa_set_p            uploads a host P [nnz,k] (lets plsa_m_step be tested in isolation).
  * plsa_m_step           <- plsa_m_step                  enstop/plsa.py:124-204 (sw == NULL)
  *                       <- plsa_m_step_w_sample_weight  enstop/plsa.py:221-310 (sw != NULL)
  *                       <- plsa_refit_m_step            enstop/plsa.py:746-816 (update_v == 0)
@@ -122,9 +124,13 @@ int plsa_copy_components_to_device(plsa_ctx *ctx, void *dst_device_km);
  *   bit-reproducible); a float-atomic scatter was measured 17x slower on MI355X.
  * plsa_log_likelihood   <- log_likelihood               enstop/plsa.py:329-386
  *   sw == NULL means all-ones.  Accumulated in float64 on the device; the reference returns float32
- *   (callers cast).                                                                               */
+ *   (callers cast).
+ * plsa_set_arithmetic   arithmetic of the four operators above and of every later driver call on this context:
+ *   0 (default) the engine's own summation orders (float64 norm_pwz / likelihood), or a combination of PLSA_REFERENCE_SUMS
+ *   and PLSA_REFERENCE_LL (see the flags): plsa_e_step / plsa_m_step then return the reference's bits -- P(z|w,d), both
+ *   factors, norm_pwz and norm_pdz -- and plsa_log_likelihood the float32 running sum.                          */
+int plsa_set_arithmetic(plsa_ctx *ctx, int32_t mode);
 int plsa_e_step(plsa_ctx *ctx, float thresh, float *P_out);
-int plsa_set_p(plsa_ctx *ctx, const float *P);
 int plsa_m_step(plsa_ctx *ctx, const float *sw, int32_t update_v, float *norm_pwz, float *norm_pdz);
 int plsa_log_likelihood(plsa_ctx *ctx, const float *sw, double *ll);
 
@@ -184,8 +190,6 @@ int plsa_em_finish(plsa_ctx *ctx);
  * with a different number of documents makes the next use an error.                                          */
 int plsa_set_sample_weight(plsa_ctx *ctx, const float *sw /* [n] or NULL */);
 int plsa_accumulator_device(plsa_ctx *ctx, void **ptr, int64_t *n_floats);
-int plsa_accumulator_get(plsa_ctx *ctx, float *host);
-int plsa_accumulator_set(plsa_ctx *ctx, const float *host);
 
 /* ---- multi-GPU exchange: RCCL over xGMI, one process per GPU -------------------------------------------
  * Replaces the two exchange steps of the reference: np.vstack of the members' topics
@@ -207,64 +211,28 @@ int plsa_accumulator_set(plsa_ctx *ctx, const float *host);
  *                         stream-ordered between plsa_em_accumulate and plsa_em_finish; plsa_fit with
  *                         PLSA_SHARDED issues the same call itself -- every collective of a communicator goes on
  *                         the context's one stream, in the same program order on every rank
- *   plsa_comm_allgather_host / _allreduce_f64 (op 0 sum, 1 max) / _broadcast_host / _barrier
- *                         small host payloads staged through HBM (seeds, timings, member stacks)
+ *   plsa_comm_allgather_host / _broadcast_host
+ *                         small host payloads staged through HBM (seeds, P(z|d) row blocks of a doc-sharded fit);
+ *                         barrier and float64 all-reduce (timings): plsa_hip_diag.h
  * Without a communicator (world = 1) every call degenerates to the identity.                          */
 #define PLSA_COMM_ID_BYTES 128
 int plsa_comm_unique_id(void *id128);
 int plsa_comm_init(plsa_ctx *ctx, const void *id128, int32_t rank, int32_t world);
 int plsa_comm_destroy(plsa_ctx *ctx);
-/* RCCL's own text for the last failure in this process (ncclGetLastError); ctx may be NULL.  No reference
- * counterpart (dask / joblib raise Python exceptions, enstop_.py:209-217); read by enstop_amd/comm.py::report_failure
- * so that a failed multi-GPU start says which stage and why. */
-int plsa_comm_last_error(plsa_ctx *ctx, char *buf, int64_t cap);
 int plsa_comm_info(plsa_ctx *ctx, int32_t *rank, int32_t *world);
-int plsa_comm_barrier(plsa_ctx *ctx);
 int plsa_stack_reserve(plsa_ctx *ctx, int64_t slots, int64_t m, int32_t k, void **base_device);
 int plsa_comm_allgather_stack(plsa_ctx *ctx, int64_t slots, int64_t m, int32_t k, float **host);
 /* the same gather with the caller's own host array as the destination ([slots * world][k][m] floats, e.g. the NumPy array
  * that np.vstack would have returned, enstop_.py:231): one pass instead of page-locked buffer + copy */
 int plsa_comm_allgather_stack_to(plsa_ctx *ctx, int64_t slots, int64_t m, int32_t k, float *dst);
 int plsa_comm_allgather_host(plsa_ctx *ctx, const void *send, int64_t bytes, void *recv /* world * bytes */);
-int plsa_comm_allreduce_f64(plsa_ctx *ctx, double *inout, int64_t count, int32_t op);
 int plsa_comm_broadcast_host(plsa_ctx *ctx, void *buf, int64_t bytes, int32_t root);
 int plsa_allreduce_accumulator(plsa_ctx *ctx);
-
-/* The materialised P array is placed by probing: up to PLSA_PLACEMENT_CANDIDATES (default 4)
- * allocations are streamed through once and the fastest is kept (HBM placement alone moves the
- * E-step by ~15 %).  Reports the last probe: candidates tried and the fill
- * bandwidth of the kept / the worst candidate (0 when no probing took place).                    */
-int plsa_placement_info(plsa_ctx *ctx, int32_t *candidates, double *best_gbps, double *worst_gbps);
-
-/* Schedule of the column pass for the current structure (diagnostics; bench.py reports it): the visiting list is
- * walked in chunks, XCD x takes the chunks [xcd_lo[x], xcd_lo[x+1]); the boundaries are MEASURED -- timed launches
- * of the pass itself, stretches resized until the eight XCDs finish together (csrc/plsa_hip.hip::ensure_balance).
- * xcd_end_us: per-XCD finish times of the last timed launch (0 when none ran: small corpora, PLSA_BALANCE=0).
- * Results never depend on the boundaries.  No counterpart in the reference (its loops are per-thread ranges of
- * numba.prange, enstop/plsa.py:91).  Any pointer may be NULL.                                               */
-int plsa_schedule_info(plsa_ctx *ctx, int32_t *xcd_lo /*[9]*/, double *xcd_end_us /*[8]*/, int32_t *timed_launches,
-                       int32_t *item_len, int64_t *n_items);
 
 /* frees the large scratch buffers (materialised P, column-pass partials, the ensemble member stack and its DEVICE gather
  * buffers); they are re-created on demand.  The page-locked host buffer whose address plsa_comm_allgather_stack handed
  * out stays valid. */
 int plsa_release_scratch(plsa_ctx *ctx);
-
-/* ---- measurement --------------------------------------------------------------------------------
- * HIP events on the context's own stream around every kernel launch (bench.py roofline figures).  */
-int plsa_timing_enable(plsa_ctx *ctx, int32_t on);
-int plsa_timing_reset(plsa_ctx *ctx);
-/* total milliseconds and launch count of kernels whose name starts with `prefix`. */
-int plsa_timing_get(plsa_ctx *ctx, const char *prefix, double *total_ms, int64_t *launches);
-/* newline-separated "name launches total_ms" report into buf. */
-int plsa_timing_report(plsa_ctx *ctx, char *buf, int64_t cap);
-/* achievable streaming bandwidth of this device, GB/s, over `bytes` of scratch HBM:
- * kind 0 = fill with non-temporal stores, 1 = fill with plain stores, 2 = copy (bytes read + bytes
- * written counted), 3 = read-only stream (small sizes probe the L2 / Infinity-Cache service rate),
- * 4 / 5 / 6 = non-temporal fill in the E-step's store order (each wave writes 16 / 4 / 64 consecutive
- * 1-KB rows before moving on).
- * The practical ceiling the E-step's P write is compared with.   */
-int plsa_measure_stream_bandwidth(plsa_ctx *ctx, int64_t bytes, int32_t kind, int32_t reps, double *gbps);
 
 /* ---- topic combination --------------------------------------------------
  * plsa_all_pairs_hellinger <- enstop/enstop_.py:258-266: the all-pairs Hellinger distance matrix of the
@@ -280,34 +248,6 @@ int plsa_all_pairs_kl(plsa_ctx *ctx, const float *topics, int64_t t, int64_t m, 
  *   L1-normalised; out [n_clusters, m] float32 on the host.                                           */
 int plsa_cluster_representatives(plsa_ctx *ctx, const float *topics, int64_t t, int64_t m,
                                  const int32_t *labels, const double *weights, int32_t n_clusters, float *out);
-
-/* ---- host helper ---------------------------------------------------------------------------------
- * plsa_host_normalize_rows <- enstop/utils.py:8-41 normalize(ndarray, axis=1): float64, in place,
- *   sequential marginal, used by the factor initialisation (enstop/plsa.py:510-511, 980).          */
-void plsa_host_normalize_rows(double *a, int64_t rows, int64_t cols);
-
-/* plsa_host_mt19937_jump: advance a numpy.random.RandomState key (624 words) by 624 * 2^log2_blocks
- *   outputs with the jump polynomial the device initialisation uses (csrc/mt_jump.hpp); the position
- *   inside the block is unaffected by a whole-block jump.  Host-only (tests pin the polynomial
- *   arithmetic against NumPy without a GPU).  Returns 0, or 1 if log2_blocks is outside [0, 40].   */
-int plsa_host_mt19937_jump(uint32_t *key /*[624]*/, int32_t log2_blocks);
-
-/* synthetic bag-of-words CSR generated on the device (bench.py / large-size tests; not part of the
- * reference): lognormal document lengths, Zipf(s) word ids, the stored count of a (doc, word) pair is its
- * multiplicity among the document's token draws (a multinomial bag of words).  The result
- * becomes base + active matrix.  nnz_target is approximate; the exact nnz is returned.            */
-int plsa_generate_synthetic(plsa_ctx *ctx, int64_t n, int64_t m, int64_t nnz_target, double zipf_s,
-                            uint64_t seed, int64_t *nnz_out);
-/* the same with TOPICAL structure (round 5; the corpus above draws every token independently -- no co-occurrence, unlike
- * text such as the reference's 20-Newsgroups, notebooks/EnsTop with 20-Newsgroups.ipynb:49): document d draws a topic
- * mixture theta_d ~ Dirichlet(alpha) over k0 latent topics, every topic has its own Zipf(s) ranking of the vocabulary,
- * a token comes from the shared ranking with probability `background` and otherwise from topic t ~ theta_d: the
- * generative model pLSA assumes.  1 <= k0 <= 256, alpha > 0, 0 <= background <= 1; deterministic in all arguments. */
-int plsa_generate_synthetic_topics(plsa_ctx *ctx, int64_t n, int64_t m, int64_t nnz_target, double zipf_s,
-                                   uint64_t seed, int32_t k0, double alpha, double background, int64_t *nnz_out);
-/* ground truth of the topical corpus currently held as the base matrix: out[d] = the latent topic with the largest share
- * of document d's mixture theta_d (tests: does a fit recover the planted structure; experiments: document orderings). */
-int plsa_synthetic_dominant_topics(plsa_ctx *ctx, int32_t *out /* [n], host */);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "plsa_hip.h"
+#include "plsa_hip_diag.h"   /* plsa_comm_barrier / plsa_comm_allreduce_f64 only: the one-rank communicator check below */
 #include "golden/fit_k8_tol0_fixture.h"
 
 static unsigned long long s = 88172645463325252ull;

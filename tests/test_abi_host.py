@@ -11,10 +11,29 @@ import scipy.sparse as sp
 from conftest import ROOT, load_golden, golden_csr
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "plsa_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(plsa_[a-z0-9_]+)\s*\(", text)))
+def _declared_symbols(headers=("plsa_hip.h", "plsa_hip_diag.h")):
+    """include/plsa_hip.h is the drop-in boundary; include/plsa_hip_diag.h holds diagnostics / measurement / test plumbing of
+    the same library (round 6 split).  Both are bound by enstop_amd/_lib.py and exported by libplsa_hip.so."""
+    out = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(plsa_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
+
+
+def test_the_drop_in_header_is_small_and_free_of_diagnostics():
+    """What a maintainer binds for the enstop_.py:52-53 seam: at most 40 entries, none of them a probe, a timer, a generator
+    or a schedule report (those live in plsa_hip_diag.h), and the two headers do not overlap."""
+    main, diag = _declared_symbols(("plsa_hip.h",)), _declared_symbols(("plsa_hip_diag.h",))
+    assert len(main) <= 40, len(main)
+    assert not set(main) & set(diag)
+    for word in ("timing", "measure", "synthetic", "schedule_info", "placement", "hw_queues", "marginals", "device_info"):
+        assert not [s for s in main if word in s], word
+    for needed in ("plsa_create", "plsa_upload_csr", "plsa_set_factors", "plsa_fit", "plsa_refit", "plsa_get_factors",
+                   "plsa_e_step", "plsa_m_step", "plsa_log_likelihood", "plsa_bootstrap", "plsa_set_arithmetic",
+                   "plsa_comm_init", "plsa_comm_allgather_stack_to", "plsa_destroy", "plsa_last_error"):
+        assert needed in main, needed
 
 
 def test_header_symbols_exported_and_bound():
@@ -29,8 +48,8 @@ def test_header_symbols_exported_and_bound():
 
 
 def test_every_entry_point_is_documented_with_the_interface_it_replaces():
-    """INTEGRATION.md names every symbol of include/plsa_hip.h (next to the reference interface it stands for,
-    or as plumbing / measurement without a counterpart); the library links RCCL directly."""
+    """INTEGRATION.md names every symbol of include/plsa_hip.h next to the reference interface it stands for, and every
+    symbol of include/plsa_hip_diag.h as plumbing / measurement without a counterpart; the library links RCCL directly."""
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     missing = [s for s in _declared_symbols() if s not in doc and s.replace("plsa_timing_", "_") not in doc]
     assert not missing, missing

@@ -62,3 +62,38 @@ def test_defaults_and_oracle_usage():
     outside = src.replace(inside, "")
     code_lines = [l for l in outside.splitlines() if "import" in l and "oracle" in l]
     assert not code_lines, code_lines
+
+
+def test_the_printed_line_is_compact_and_carries_the_timed_loop_roofline():
+    """The driver keeps a 2000-character tail of stdout and parses `roofline` out of the line: the default line is the compact one
+    (compact_line) -- contract keys, `roofline` with the north-star kernel (k_e_step, labelled as the separate materialised leg)
+    AND `timed_loop` = the dominant kernel of the loop `value` times, `cpu_baseline`, one short object per other BASELINE
+    configuration and ensemble leg -- built here from a committed full record of a real run."""
+    b = _bench()
+    out = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg3_1gpu_final_tree.json")))
+    d = out["roofline_dominant_fused"]
+    out["roofline"]["leg"] = "materialised (separate from value)"
+    out["roofline"]["timed_loop"] = {"kernel": d["kernel"], "avg_ms": d["avg_launch_ms"], "algorithmic_GB": d["algorithmic_GB_per_launch"],
+                                     "frac": d["frac"], "traffic_GB": 8.11, "traffic_ratio": 7.3, "frac_on_traffic": 0.62,
+                                     "share_of_ms_per_step": 0.51}
+    for leg in ("config1", "ensemble_20ng_shape"):
+        out["other_configs"][leg]["corpus"] = b.corpus_kind(b.TOPICAL_20NG)
+    line = b.compact_line(out, "gpurun_out/bench_full_cfg3_n1.json")
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 2000, len(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    r = line["roofline"]
+    assert r["kernel"] == "k_e_step" and r["leg"].startswith("materialised") and r["bound"] == "hbm" and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    t = r["timed_loop"]
+    assert t["kernel"].startswith("k_") and 0 < t["frac"] < 1 and t["avg_ms"] > 0 and t["traffic_ratio"] > 1
+    assert set(line["other_configs"]) >= {"config1", "config2", "config5", "config3_topical", "ensemble_20ng_shape"}
+    assert line["other_configs"]["config1"]["corpus"] == "topical" and line["config"]["corpus"].startswith("independent")
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+    # the 20-Newsgroups configurations default to the topical stand-in, config 3 to SURVEY 8d's generator
+    import types
+    assert b.corpus_options(types.SimpleNamespace(topics=-1, config=4))["topics"] == 20
+    assert b.corpus_options(types.SimpleNamespace(topics=-1, config=3)) == {}
+    assert b.corpus_options(types.SimpleNamespace(topics=0, config=1)) == {}

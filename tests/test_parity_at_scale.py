@@ -43,7 +43,10 @@ downloaded for the oracle.  Every comparison is made against three builds of the
 Asserted: HIP == wide and HIP == n64 inside the north-star tolerances (factors 1e-4 of the largest entry,
 log-likelihood 1e-5 relative; measured ~1e-6), and HIP's distance to strict is no larger than strict's
 own distance to wide (i.e. the gap IS the reference's rounding, not a defect of the port).
-Every figure is written to gpurun_out/r05_parity_at_scale.json (copied to profiles/ by hand).
+Round 6: every BASELINE-sized leg also runs in THE REFERENCE'S ROUNDING (PLSA_REFERENCE_SUMS, enstop_amd/csrc/plsa_ref_kernels.hpp)
+and asserts the literal north-star tolerances there: bit-identical factors against the strict oracle (configs 1, 2, 3-sample)
+and against the reference's own run (fit_cfg1_shape.npz), 1e-4 / 1e-5 against the numba-compiled reference after 50 iterations.
+Every figure is written to gpurun_out/r06_parity_at_scale.json (copied to profiles/ by hand).
 """
 import json
 import os
@@ -66,7 +69,7 @@ CONFIG2 = dict(n=100_000, m=50_000, nnz=10_000_000, k=32)
 def _flush_report():
     try:
         os.makedirs(REPORT_DIR, exist_ok=True)
-        with open(os.path.join(REPORT_DIR, "r05_parity_at_scale.json"), "w") as f:
+        with open(os.path.join(REPORT_DIR, "r06_parity_at_scale.json"), "w") as f:
             json.dump(REPORT, f, indent=1, sort_keys=True)
     except OSError:
         pass
@@ -135,6 +138,49 @@ def corpus(amd, cfg):
     return _corpora[key]
 
 
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return bool(a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+
+
+def _reference_arithmetic_leg(amd, oracles, eng, coo, U0, V0, strict, rec, n_iter, n_iter_per_test):
+    """PLSA_REFERENCE_SUMS at a BASELINE size: the fit must return the strict oracle's factors BIT FOR BIT (the strict oracle =
+    the reference's source semantics, pinned bit for bit by the reference-generated fixtures), i.e. the literal north-star
+    tolerance against the reference's own arithmetic with nothing to spare and nothing missing.  Then the two likelihoods on
+    those factors: the sequential float32 one (PLSA_REFERENCE_LL) against the oracle on ONE thread, the float64-accumulated
+    one against the oracle's float64 accumulator.  `strict` = (U, V, trace, iters) of the strict oracle from (U0, V0)."""
+    r, c, v = coo
+    ones = np.ones(U0.shape[0], np.float32)
+    eng.set_factors(U0, V0)
+    t0 = time.time()
+    iters, trace = eng.fit(None, n_iter=n_iter, n_iter_per_test=n_iter_per_test, tolerance=0.0, e_step_thresh=1e-32,
+                           flags=amd.PLSA_FUSED | amd.PLSA_REFERENCE_SUMS, trace=True)
+    sec = time.time() - t0
+    U, V = eng.get_factors()
+    out = rec.setdefault("reference_arithmetic", {})
+    out.update({"seconds": round(sec, 3), "ms_per_iteration": round(1e3 * sec / max(iters, 1), 2),
+                "U_bits_equal_strict_oracle": bits_equal(U, strict[0]), "V_bits_equal_strict_oracle": bits_equal(V, strict[1]),
+                "vs_strict": {"U": errs(U, strict[0]), "V": errs(V, strict[1])}})
+    o = oracles["strict"]
+    o.set_threads(1)
+    ll_seq_o = float(o.log_likelihood(r, c, v, strict[1], strict[0], ones))
+    o.set_threads(oracles["threads"])
+    ll64_o = float(oracles["n64"].log_likelihood(r, c, v, strict[1], strict[0], ones))
+    ll64_h = float(eng.log_likelihood())                       # the engine holds the fit's final factors
+    eng.set_arithmetic("reference_source")
+    ll_seq_h = float(np.float32(eng.log_likelihood()))
+    eng.set_arithmetic(None)
+    out["final_log_likelihood"] = {"sequential_float32": {"hip": ll_seq_h, "oracle_one_thread": ll_seq_o,
+                                                          "rel": abs(ll_seq_h - ll_seq_o) / abs(ll_seq_o)},
+                                   "float64_accumulator": {"hip": ll64_h, "oracle": ll64_o, "rel": abs(ll64_h - ll64_o) / abs(ll64_o)},
+                                   "sequential_vs_float64": abs(ll_seq_o - ll64_o) / abs(ll64_o)}
+    _flush_report()
+    assert iters == strict[3] == n_iter
+    assert out["U_bits_equal_strict_oracle"] and out["V_bits_equal_strict_oracle"], out["vs_strict"]
+    assert out["final_log_likelihood"]["sequential_float32"]["rel"] <= 1e-5, out["final_log_likelihood"]
+    assert out["final_log_likelihood"]["float64_accumulator"]["rel"] <= 1e-6, out["final_log_likelihood"]
+
+
 def _fit_case(amd, oracles, cfg, name, n_iter, n_iter_per_test):
     X = corpus(amd, cfg)
     n, m = X.shape
@@ -185,6 +231,8 @@ def _fit_case(amd, oracles, cfg, name, n_iter, n_iter_per_test):
                 for f in ("U", "V"):
                     assert s_[f]["peak_rel"] <= 1.5 * w[f]["peak_rel"] + 2e-5, (sched, variant, f, s_[f], w[f])
                 assert s_["ll_rel"] <= 1.5 * w["ll_rel"] + 1e-5, (sched, variant, s_["ll_rel"], w["ll_rel"])
+        # the reference's rounding as an option (PLSA_REFERENCE_SUMS): the strict oracle's bits at this size
+        _reference_arithmetic_leg(amd, oracles, eng, (r, c, v), U0, V0, ref["strict"], rec, n_iter, n_iter_per_test)
         # kernel level, one step from the initial factors: norm_pwz and the un-normalised P(w|z)
         eng.set_factors(U0, V0)
         eng.e_step(1e-32, want_host_copy=False)
@@ -247,6 +295,12 @@ def test_config1_default_tolerance_stops_where_the_oracle_stops(amd, oracles):
             eng.set_factors(U0, V0)
             iters, trace = eng.fit(None, flags=flags, trace=True, **kw)
             stops[sched], traces[sched] = int(iters), [float(x) for x in trace]
+        # the reference's rounding: with the accurate likelihood, and with the source's sequential float32 one
+        for sched, flags in (("hip_reference_sums", amd.PLSA_REFERENCE_SUMS),
+                             ("hip_reference_sums_and_sequential_ll", amd.PLSA_REFERENCE_SUMS | amd.PLSA_REFERENCE_LL)):
+            eng.set_factors(U0, V0)
+            iters, trace = eng.fit(None, flags=flags, trace=True, **kw)
+            stops[sched], traces[sched] = int(iters), [float(x) for x in trace]
     rec["stop_iteration"] = stops
     rec["log_likelihood_traces"] = traces
     _flush_report()
@@ -254,6 +308,9 @@ def test_config1_default_tolerance_stops_where_the_oracle_stops(amd, oracles):
     nl = len(traces["n64"])
     assert len(traces["hip_fused"]) == nl and ll_rel(traces["hip_fused"], traces["n64"]) <= 1e-5
     assert ll_rel(traces["hip_materialised"][:nl], traces["n64"]) <= 1e-5
+    # PLSA_REFERENCE_SUMS | PLSA_REFERENCE_LL is the reference's source on one thread: same stop iteration, same trace
+    assert stops["hip_reference_sums_and_sequential_ll"] == stops["strict_1_thread"], stops
+    assert ll_rel(traces["hip_reference_sums_and_sequential_ll"], traces["strict_1_thread"]) <= 1e-5
 
 
 def test_cfg1_reference_run(amd, oracles):
@@ -296,6 +353,18 @@ def test_cfg1_reference_run(amd, oracles):
         for f in ("U", "V"):
             assert vs_ref[f] <= 1.5 * ref_vs_exact[f] + 2e-5, (sched, f, vs_ref, ref_vs_exact)
         assert vs_ref["ll_rel"] <= 1.5 * ref_vs_exact["ll_rel"] + 1e-5, (sched, vs_ref, ref_vs_exact)
+    # arithmetic="reference_source": the reference's OWN output at this BASELINE size, bit for bit (factors) and to the last
+    # place of the float32 logarithm (its sequential float32 log-likelihood, 3.4e-3 from the exact value)
+    U, V, info = amd.plsa_fit(X, k, ones, return_info=True, arithmetic="reference_source", **kw)
+    trace = np.asarray(info["log_likelihood_trace"])[:len(g["ll_trace"])]
+    rec["reference_arithmetic"] = {"U_bits_equal_reference": bits_equal(U, g["U"]),
+                                   "V_sample_bits_equal_reference": bits_equal(V[:, cols], g["V_sample"]),
+                                   "vs_reference": {"U": peak_rel(U, g["U"]), "V": peak_rel(V[:, cols], g["V_sample"]),
+                                                    "ll_rel": ll_rel(trace, g["ll_trace"])}}
+    _flush_report()
+    assert info["n_iter"] == int(g["iters"])
+    assert rec["reference_arithmetic"]["U_bits_equal_reference"] and rec["reference_arithmetic"]["V_sample_bits_equal_reference"], rec["reference_arithmetic"]
+    assert rec["reference_arithmetic"]["vs_reference"]["ll_rel"] <= 1e-5, rec["reference_arithmetic"]
 
 
 def test_cfg1_numba_compiled_reference(amd, oracles):
@@ -340,9 +409,34 @@ def test_cfg1_numba_compiled_reference(amd, oracles):
             rec[sched] = {"vs_compiled_reference_after_50_iterations": vs_ref, "default_tolerance_stop_iteration": int(stop)}
             _flush_report()
             assert stop == stops_ref[1], (sched, stop, stops_ref)
+            # DEFAULT arithmetic (float64 norm_pwz / likelihood): more accurate than the reference, hence bounded by the
+            # reference's own distance to exact arithmetic, not by the north-star figures
             for f in ("U", "V"):
                 assert vs_ref[f] <= 1.5 * ref_vs_exact[f] + 2e-5, (sched, f, vs_ref, ref_vs_exact)
             assert vs_ref["ll_rel"] <= 1.5 * ref_vs_exact["ll_rel"] + 1e-5, (sched, vs_ref, ref_vs_exact)
+        # THE REFERENCE'S ROUNDING (arithmetic="reference", PLSA_REFERENCE_SUMS): north_star's literal tolerances against the
+        # reference as its users run it -- 1e-4 on both factor matrices, 1e-5 on every tested log-likelihood -- after all 50
+        # iterations, and the same default-tolerance stop iteration.  (Either schedule flag: the mode has one kernel sequence.)
+        for sched, flags in (("reference_arithmetic", amd.PLSA_FUSED | amd.PLSA_REFERENCE_SUMS),
+                             ("reference_arithmetic_materialised_flag", amd.PLSA_REFERENCE_SUMS)):
+            eng.set_factors(U0, V0)
+            iters, trace = eng.fit(None, n_iter=50, n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=flags, trace=True)
+            U, V = eng.get_factors()
+            vs_ref = {"U": peak_rel(U, g["U50"]), "V": peak_rel(V[:, cols], g["V50_sample"]),
+                      "V_rowsum": float(np.abs(V.astype(np.float64).sum(axis=1) - g["V50_rowsum64"]).max()),
+                      "ll_rel": ll_rel(trace, g["ll50"])}
+            eng.set_factors(U0, V0)
+            stop, _ = eng.fit(None, n_iter=100, n_iter_per_test=10, tolerance=1e-3, e_step_thresh=1e-32, flags=flags)
+            eng.set_factors(U0, V0)
+            stop_src, _ = eng.fit(None, n_iter=100, n_iter_per_test=10, tolerance=1e-3, e_step_thresh=1e-32,
+                                  flags=flags | amd.PLSA_REFERENCE_LL)
+            rec[sched] = {"vs_compiled_reference_after_50_iterations": vs_ref, "default_tolerance_stop_iteration": int(stop),
+                          "default_tolerance_stop_iteration_with_the_sequential_float32_likelihood": int(stop_src)}
+            _flush_report()
+            assert iters == 50
+            assert vs_ref["U"] <= 1e-4 and vs_ref["V"] <= 1e-4, (sched, vs_ref)
+            assert vs_ref["ll_rel"] <= 1e-5, (sched, vs_ref)
+            assert stop == stops_ref[1], (sched, stop, stops_ref)
 
 
 def test_cfg1_numba_compiled_refit(amd, oracles):
@@ -583,11 +677,12 @@ def test_config3_shape_row_sample_vs_oracle(amd, oracles):
         U, V = U0.copy(), V0.copy()
         _, _, trace, iters = oracles[variant].plsa_fit_inner(r, c, v, V, U, ones, n_iter=2, n_iter_per_test=1,
                                                              tolerance=0.0, e_step_thresh=1e-32, return_trace=True)
-        ref[variant] = (U, V, trace)
+        ref[variant] = (U, V, trace, iters)
     rec["strict_vs_wide"] = {"U": errs(ref["strict"][0], ref["wide"][0]), "V": errs(ref["strict"][1], ref["wide"][1]),
                              "ll_rel": ll_rel(ref["strict"][2], ref["wide"][2])}
     with amd.Engine() as eng:
         eng.upload_csr(X)
+        _reference_arithmetic_leg(amd, oracles, eng, (r, c, v), U0, V0, ref["strict"], rec, 2, 1)
         for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
             eng.set_factors(U0, V0)
             iters, trace = eng.fit(None, n_iter=2, n_iter_per_test=1, tolerance=0.0, e_step_thresh=1e-32, flags=flags,

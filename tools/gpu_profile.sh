@@ -5,8 +5,8 @@ R=$PWD
 mkdir -p $R/gpurun_out/prof
 export TMPDIR=/tmp
 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -3
-timeout 1500 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 300 gpurun_out/bench_default.err
-for c in 2 1 5; do timeout 900 python bench.py --config $c --no-cpu-baseline --no-pmc > gpurun_out/bench_cfg$c.json 2> gpurun_out/bench_cfg$c.err; done
+timeout 1500 python bench.py --full > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 300 gpurun_out/bench_default.err
+for c in 2 1 5; do timeout 900 python bench.py --full --config $c --no-cpu-baseline --no-pmc > gpurun_out/bench_cfg$c.json 2> gpurun_out/bench_cfg$c.err; done
 # the N = 2 launch path on this single-GPU box: bench.py spawns its own ranks; RCCL refuses two ranks on one
 # device, so this is the host-file TEST MODE (labelled as such in the JSON) -- and the RCCL attempt must fail
 timeout 600 python bench.py --gpus 2 --config 2 --steps 20 --no-cpu-baseline --exchange files > gpurun_out/bench_cfg2_world2_files.json 2> gpurun_out/bench_cfg2_world2_files.err
@@ -23,7 +23,7 @@ for kind, name in ((0, "fill nt"), (1, "fill plain"), (2, "copy")):
 PY
 cat gpurun_out/stream_probe.txt
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o bench -- python $R/bench.py --no-cpu-baseline --no-pmc --no-ensemble --no-other-configs > $R/gpurun_out/prof/bench_under_rocprof.json 2> $R/gpurun_out/prof/rocprof_stats.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o bench -- python $R/bench.py --full --no-cpu-baseline --no-pmc --no-ensemble --no-other-configs > $R/gpurun_out/prof/bench_under_rocprof.json 2> $R/gpurun_out/prof/rocprof_stats.err
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof/pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-ensemble --no-other-configs > /dev/null 2> $R/gpurun_out/prof/rocprof_fetch.err
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof/pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-ensemble --no-other-configs > /dev/null 2> $R/gpurun_out/prof/rocprof_write.err
 cd $R
@@ -50,6 +50,6 @@ PY
 head -12 gpurun_out/prof/bench_kernel_stats.csv | cut -c1-160
 # round 5: BASELINE configs[3] as its own command (32 members on the 20NG shape), the topical corpus with its counter traffic,
 # the extended parity fuzz
-timeout 600 python bench.py --config 4 --steps 200 --no-cpu-baseline > gpurun_out/bench_cfg4.json 2> gpurun_out/bench_cfg4.err
-timeout 900 python bench.py --topics 64 --no-cpu-baseline --no-ensemble --no-other-configs > gpurun_out/bench_cfg3_topical.json 2> gpurun_out/bench_cfg3_topical.err
+timeout 600 python bench.py --full --config 4 --steps 200 --no-cpu-baseline > gpurun_out/bench_cfg4.json 2> gpurun_out/bench_cfg4.err
+timeout 900 python bench.py --full --topics 64 --no-cpu-baseline --no-ensemble --no-other-configs > gpurun_out/bench_cfg3_topical.json 2> gpurun_out/bench_cfg3_topical.err
 for s in 1 2 3 4 5; do timeout 900 python tests/fuzz_parity.py 1000 $s 2>&1 | tail -1; done | tee gpurun_out/fuzz_parity_5x1000.txt

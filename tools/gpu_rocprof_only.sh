@@ -1,5 +1,5 @@
 R=$PWD; mkdir -p $R/gpurun_out/prof; export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/prof
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o bench -- python $R/bench.py --no-cpu-baseline --no-pmc --no-ensemble --no-other-configs > $R/gpurun_out/prof/bench_under_rocprof.json 2> $R/gpurun_out/prof/rocprof_stats.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o bench -- python $R/bench.py --full --no-cpu-baseline --no-pmc --no-ensemble --no-other-configs > $R/gpurun_out/prof/bench_under_rocprof.json 2> $R/gpurun_out/prof/rocprof_stats.err
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof/pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-ensemble --no-other-configs > /dev/null 2> $R/gpurun_out/prof/rocprof_fetch.err
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof/pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-ensemble --no-other-configs > /dev/null 2> $R/gpurun_out/prof/rocprof_write.err
 cd $R
