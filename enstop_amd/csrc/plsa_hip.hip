@@ -22,7 +22,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -288,6 +290,119 @@ int ensure_best_placement(plsa_ctx *c, DevBuf &b, size_t bytes, int max_candidat
     b.p = cand[best]; b.cap = bytes;
     if (gbps) { gbps[0] = bytes / 1e9 / (ms[best] / 1e3); gbps[1] = bytes / 1e9 / (ms[worst] / 1e3); }
     if (n_tried) *n_tried = (int)cand.size();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Large host <-> device copies.  The boundary takes ordinary (pageable) host arrays -- NumPy's -- and a plain hipMemcpy
+// of such memory ran at 25 GB/s up / 10 GB/s down on the GPU box (profiles/r05_pcie_inclusive_plsa_fit_from_host.jsonl: 60 of
+// the 72 ms a config-3 fit spends outside its iterations).  From STAGE_MIN bytes on, a copy is cut into 8-MB chunks that
+// STAGE_THREADS helper threads move through page-locked slots of their own (two each, one HIP stream each): the host-side
+// memcpy of one chunk (and the first-touch page faults of a fresh destination array) overlaps the PCIe transfer of the
+// others.  The slots are process-wide (64 MB page-locked once), copies of different contexts take turns.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t STAGE_CHUNK = (size_t)8 << 20;
+constexpr int STAGE_THREADS = 4;
+constexpr size_t STAGE_MIN = (size_t)48 << 20;
+struct HostStage {
+    std::mutex mu;
+    int device = -1;
+    void *slot[STAGE_THREADS][2] = {};
+    hipStream_t stream[STAGE_THREADS] = {};
+    hipEvent_t ev[STAGE_THREADS][2] = {};
+    bool ok = false, tried = false;
+} g_stage;
+
+bool stage_ready(int device) {        // (g_stage.mu held)
+    if (g_stage.tried && g_stage.device == device) return g_stage.ok;
+    if (g_stage.tried) {              // another device: rebuild the streams / events there, keep the host slots
+        for (int t = 0; t < STAGE_THREADS; ++t) {
+            if (g_stage.stream[t]) (void)hipStreamDestroy(g_stage.stream[t]);
+            for (int b = 0; b < 2; ++b) if (g_stage.ev[t][b]) (void)hipEventDestroy(g_stage.ev[t][b]);
+            g_stage.stream[t] = nullptr; g_stage.ev[t][0] = g_stage.ev[t][1] = nullptr;
+        }
+    }
+    g_stage.tried = true; g_stage.device = device; g_stage.ok = true;
+    const char *off = getenv("PLSA_STAGED_COPIES");
+    if (off && atoi(off) == 0) { g_stage.ok = false; return false; }
+    for (int t = 0; t < STAGE_THREADS && g_stage.ok; ++t) {
+        for (int b = 0; b < 2; ++b) {
+            if (!g_stage.slot[t][b] && hipHostMalloc(&g_stage.slot[t][b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) g_stage.ok = false;
+            if (hipEventCreateWithFlags(&g_stage.ev[t][b], hipEventDisableTiming) != hipSuccess) g_stage.ok = false;
+        }
+        if (hipStreamCreateWithFlags(&g_stage.stream[t], hipStreamNonBlocking) != hipSuccess) g_stage.ok = false;
+    }
+    if (!g_stage.ok) (void)hipGetLastError();
+    return g_stage.ok;
+}
+
+// dev <- host (to_device) or host <- dev, `bytes` contiguous on both sides.  The caller has synchronised whatever produced
+// the source; on return the data is in place (every helper stream drained).  Returns false if the staged path is unavailable.
+bool staged_copy(plsa_ctx *c, void *dev, void *host, size_t bytes, bool to_device) {
+    if (bytes < STAGE_MIN) return false;
+    std::lock_guard<std::mutex> lock(g_stage.mu);
+    if (!stage_ready(c->device)) return false;
+    const size_t n_chunks = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
+    bool failed[STAGE_THREADS] = {};
+    auto worker = [&](int t) {
+        if (hipSetDevice(c->device) != hipSuccess) { failed[t] = true; return; }
+        hipStream_t st = g_stage.stream[t];
+        if (to_device) {
+            int b = 0;
+            for (size_t i = t; i < n_chunks; i += STAGE_THREADS, b ^= 1) {
+                const size_t off = i * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - off);
+                if (hipEventSynchronize(g_stage.ev[t][b]) != hipSuccess) { failed[t] = true; return; }   // the slot's previous transfer
+                memcpy(g_stage.slot[t][b], (const char *)host + off, len);
+                if (hipMemcpyAsync((char *)dev + off, g_stage.slot[t][b], len, hipMemcpyHostToDevice, st) != hipSuccess ||
+                    hipEventRecord(g_stage.ev[t][b], st) != hipSuccess) { failed[t] = true; return; }
+            }
+        } else {
+            // chunk j+1 is on its way into the other slot while chunk j is copied out to the caller's pages
+            size_t i = t;
+            int b = 0;
+            auto issue = [&](size_t ci, int slot) {
+                const size_t off = ci * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - off);
+                return hipMemcpyAsync(g_stage.slot[t][slot], (const char *)dev + off, len, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                       hipEventRecord(g_stage.ev[t][slot], st) == hipSuccess;
+            };
+            if (i < n_chunks && !issue(i, b)) { failed[t] = true; return; }
+            for (; i < n_chunks; i += STAGE_THREADS, b ^= 1) {
+                const size_t nxt = i + STAGE_THREADS;
+                if (nxt < n_chunks && !issue(nxt, b ^ 1)) { failed[t] = true; return; }
+                if (hipEventSynchronize(g_stage.ev[t][b]) != hipSuccess) { failed[t] = true; return; }
+                const size_t off = i * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - off);
+                memcpy((char *)host + off, g_stage.slot[t][b], len);
+            }
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) failed[t] = true;
+    };
+    std::thread th[STAGE_THREADS];
+    for (int t = 1; t < STAGE_THREADS; ++t) th[t] = std::thread(worker, t);
+    worker(0);
+    for (int t = 1; t < STAGE_THREADS; ++t) th[t].join();
+    (void)hipSetDevice(c->device);
+    for (int t = 0; t < STAGE_THREADS; ++t)
+        if (failed[t]) { (void)hipGetLastError(); return false; }      // the caller repeats the copy the plain way
+    return true;
+}
+
+// host -> device on the context's stream order: everything enqueued on c->stream so far is complete when the staged path
+// writes (it waits), and the data is in place when this returns, so later work on c->stream sees it
+int copy_to_device(plsa_ctx *c, void *dev, const void *host, size_t bytes) {
+    if (bytes >= STAGE_MIN) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (staged_copy(c, dev, const_cast<void *>(host), bytes, true)) return 0;
+    }
+    HIPCHK(c, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+// device -> host; the data is in `host` on return
+int copy_to_host(plsa_ctx *c, void *host, const void *dev, size_t bytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bytes >= STAGE_MIN && staged_copy(c, const_cast<void *>(dev), host, bytes, false)) return 0;
+    HIPCHK(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -1447,9 +1562,9 @@ int plsa_upload_csr(plsa_ctx *c, const int32_t *indptr, const int32_t *indices, 
     CHK(ensure(c, c->b_col, sizeof(int) * (size_t)nnz));
     CHK(ensure(c, c->b_val, sizeof(float) * (size_t)nnz));
     HIPCHK(c, hipMemcpyAsync(c->b_indptr.p, indptr, sizeof(int) * (size_t)(n + 1), hipMemcpyHostToDevice, c->stream));
-    if (nnz) {
-        HIPCHK(c, hipMemcpyAsync(c->b_col.p, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->b_val.p, data, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
+    if (nnz) {      // (large arrays: chunked through page-locked slots by helper threads, see staged_copy)
+        CHK(copy_to_device(c, c->b_col.p, indices, sizeof(int) * (size_t)nnz));
+        CHK(copy_to_device(c, c->b_val.p, data, sizeof(float) * (size_t)nnz));
     }
     // the header's contract, checked on the device (the arrays are there now; one streaming pass): a violation is a
     // status code for the caller, not a GPU fault three calls later
@@ -1566,8 +1681,11 @@ int plsa_set_factors(plsa_ctx *c, const float *U, const float *V, int64_t n, int
     c->p_valid = false;
     c->cu = 0;
     if (kp != k) HIPCHK(c, hipMemsetAsync(c->U[0].p, 0, sizeof(float) * (size_t)n * kp, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(c->U[0].p, sizeof(float) * kp, U, sizeof(float) * k, sizeof(float) * k,
-                               (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (kp == k)
+        CHK(copy_to_device(c, c->U[0].p, U, sizeof(float) * (size_t)n * k));
+    else
+        HIPCHK(c, hipMemcpy2DAsync(c->U[0].p, sizeof(float) * kp, U, sizeof(float) * k, sizeof(float) * k,
+                                   (size_t)n, hipMemcpyHostToDevice, c->stream));
     if (V) {
         c->cv = 0;
         CHK(ensure(c, c->tmp0, sizeof(float) * (size_t)k * m));
@@ -1731,17 +1849,21 @@ int plsa_refit_init_mt19937(plsa_ctx *c, const float *V, int64_t m, int32_t k, u
 int plsa_get_factors(plsa_ctx *c, float *U, float *V) {
     HIPCHK(c, hipSetDevice(c->device));
     CHK(need_factors(c));
-    if (U)
-        HIPCHK(c, hipMemcpy2DAsync(U, sizeof(float) * c->k, c->U[c->cu].p, sizeof(float) * c->kp,
-                                   sizeof(float) * c->k, (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
-    if (V) {
+    if (V) {        // transposed on the device first: it is in flight while P(z|d) travels
         CHK(ensure(c, c->tmp0, sizeof(float) * (size_t)c->k * c->m));
         dim3 grid((unsigned)((c->m + 31) / 32), (unsigned)((c->kp + 31) / 32));
         hipLaunchKernelGGL(plsa::k_vt_to_v, grid, dim3(256), 0, c->stream, c->Vt[c->cv].as<float>(),
                            c->tmp0.as<float>(), c->k, (int)c->m, c->kp);
         CHK(launch_check(c, "k_vt_to_v"));
-        HIPCHK(c, hipMemcpyAsync(V, c->tmp0.p, sizeof(float) * (size_t)c->k * c->m, hipMemcpyDeviceToHost, c->stream));
     }
+    if (U) {
+        if (c->kp == c->k)      // rows are contiguous: one linear copy (the strided 2-D form ran at 10 GB/s from 1 M x 64)
+            CHK(copy_to_host(c, U, c->U[c->cu].p, sizeof(float) * (size_t)c->n * c->k));
+        else
+            HIPCHK(c, hipMemcpy2DAsync(U, sizeof(float) * c->k, c->U[c->cu].p, sizeof(float) * c->kp,
+                                       sizeof(float) * c->k, (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (V) CHK(copy_to_host(c, V, c->tmp0.p, sizeof(float) * (size_t)c->k * c->m));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -5,7 +5,7 @@
 // from ~1e6 non-zeros on.  The kernels below evaluate the reference's statements with the
 // reference's roundings instead -- every sum one float32 accumulator, added in the order the reference's loops add --
 // so that a fit in this mode returns the bits `enstop/plsa.py` computes when its source is executed statement by
-// statement (the fixtures under tests/golden/*.npz, produced by the reference itself, are met bit for bit):
+// statement (the fixtures under tests/golden, produced by the reference itself, are met bit for bit):
 //
 //   reference statement (enstop/plsa.py)                       here
 //   :96-105  v = P(w|z) P(z|d); norm += v (z = 0 .. k-1);      k_ref_e_step     one lane per non-zero walks the topics in
@@ -213,28 +213,35 @@ constexpr int CHAIN_TILE = 8192;                       // floats per LDS tile (3
 constexpr int CHAIN_F4 = CHAIN_TILE / 4 / CHAIN_THREADS;   // float4 per lane and tile (2)
 constexpr int CHAIN_DEPTH = 4;                         // tiles in flight in registers
 
+// The adding wave is bound by its own instruction stream (one wave: every instruction costs four cycles), so a tile row
+// sits in LDS at a COMPILE-TIME stride of 64 NZ floats whatever kp is: the row loop is then nothing but ds_read_b32 with
+// immediate offsets and the dependent v_add_f32 (first version, run-time stride kp + per-element predicates: ~10
+// instructions = 20-30 ns per row; 63 / 240 / 447 ms per iteration at config 1 / 2 / the config-3 150 k sample).  Lanes
+// beyond kp read padding and add it into accumulators nobody stores.
 template <int NZ>
 __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__restrict__ rowidx,
                                                                   const float *__restrict__ vals, i64 nnz,
                                                                   const float *__restrict__ P,
                                                                   const float *__restrict__ sw, int kp,
                                                                   float *__restrict__ norm_pwz) {
+    constexpr int STRIDE = 64 * NZ;                            // floats between two rows of a tile in LDS
+    constexpr int ROWS = CHAIN_TILE / STRIDE;                  // rows per tile (128 / NZ)
     __shared__ float4 tile[2][CHAIN_TILE / 4];
     const int tid = threadIdx.x;
-    const int rows_per_tile = CHAIN_TILE / kp;                 // whole rows only
-    const int f4_per_tile = rows_per_tile * kp / 4;
-    const i64 n_tiles = (nnz + rows_per_tile - 1) / rows_per_tile;
     const int kq = kp >> 2;
-    // the lane's float4 slots inside a tile and the tile-relative row each belongs to (the same for every tile)
-    int slot[CHAIN_F4], srow[CHAIN_F4];
+    const int f4_per_tile = ROWS * kq;                         // float4 of P one tile covers (<= 2048)
+    const i64 n_tiles = (nnz + ROWS - 1) / ROWS;
+    // the lane's float4 slots inside a tile: tile-relative row and LDS position (the same for every tile)
+    int slot[CHAIN_F4], srow[CHAIN_F4], spos[CHAIN_F4];
 #pragma unroll
     for (int s = 0; s < CHAIN_F4; ++s) {
         slot[s] = tid + CHAIN_THREADS * s;
         srow[s] = slot[s] / kq;
+        spos[s] = srow[s] * (STRIDE / 4) + (slot[s] - srow[s] * kq);
     }
     float4 reg[CHAIN_DEPTH][CHAIN_F4];
     auto fetch = [&](i64 t, float4 (&dst)[CHAIN_F4]) {
-        const i64 row0 = t * rows_per_tile;
+        const i64 row0 = t * ROWS;
 #pragma unroll
         for (int s = 0; s < CHAIN_F4; ++s) {
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -261,34 +268,28 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__r
             float4 *buf = tile[dd & 1];                      // CHAIN_DEPTH is even: buffer parity == parity of t
 #pragma unroll
             for (int s = 0; s < CHAIN_F4; ++s)
-                if (slot[s] < f4_per_tile) buf[slot[s]] = reg[dd][s];
+                if (slot[s] < f4_per_tile) buf[spos[s]] = reg[dd][s];
             __syncthreads();
             fetch(t + CHAIN_DEPTH, reg[dd]);
             if (tid < 64) {
-                const float *rowp = reinterpret_cast<const float *>(buf);
-                const int rows = (int)min((i64)rows_per_tile, nnz - t * rows_per_tile);
+                const float *rp = reinterpret_cast<const float *>(buf) + tid;
+                const int rows = (int)min((i64)ROWS, nnz - t * ROWS);
                 constexpr int UN = NZ >= 8 ? 2 : (NZ == 4 ? 4 : 8);     // rows whose LDS reads are issued ahead of their adds
                 int r = 0;
-                for (; r + UN <= rows; r += UN) {
+                for (; r + UN <= rows; r += UN, rp += UN * STRIDE) {
                     float v[UN][NZ];
 #pragma unroll
                     for (int u = 0; u < UN; ++u)
 #pragma unroll
-                        for (int c = 0; c < NZ; ++c) {
-                            const int z = tid + 64 * c;
-                            v[u][c] = z < kp ? rowp[(r + u) * kp + z] : 0.0f;
-                        }
+                        for (int c = 0; c < NZ; ++c) v[u][c] = rp[u * STRIDE + 64 * c];
 #pragma unroll
                     for (int u = 0; u < UN; ++u)
 #pragma unroll
                         for (int c = 0; c < NZ; ++c) acc[c] += v[u][c];      // plsa.py:193
                 }
-                for (; r < rows; ++r)
+                for (; r < rows; ++r, rp += STRIDE)
 #pragma unroll
-                    for (int c = 0; c < NZ; ++c) {
-                        const int z = tid + 64 * c;
-                        acc[c] += z < kp ? rowp[r * kp + z] : 0.0f;
-                    }
+                    for (int c = 0; c < NZ; ++c) acc[c] += rp[64 * c];
             }
         }
     }
@@ -353,20 +354,21 @@ __global__ __launch_bounds__(64) void k_ref_ll_chain(const float *__restrict__ t
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const i64 first = base + (i64)p * 64;
-            if (first >= nnz) break;
-            reinterpret_cast<float *>(sx[p & 1])[lane] = cur[p];
-            wave_lds_fence();
-            const int cnt = (int)min((i64)64, nnz - first);
-            if (cnt == 64) {
+            if (first < nnz) {                               // (uniform; no `break`: the loop must unroll, cur[] stays in registers)
+                reinterpret_cast<float *>(sx[p & 1])[lane] = cur[p];
+                wave_lds_fence();
+                const int cnt = (int)min((i64)64, nnz - first);
+                if (cnt == 64) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const float4 v = sx[p & 1][c];
-                    s += v.x; s += v.y; s += v.z; s += v.w;          // plsa.py:383
+                    for (int c = 0; c < 16; ++c) {
+                        const float4 v = sx[p & 1][c];
+                        s += v.x; s += v.y; s += v.z; s += v.w;          // plsa.py:383
+                    }
+                } else {
+                    for (int c = 0; c < cnt; ++c) s += reinterpret_cast<const float *>(sx[p & 1])[c];
                 }
-            } else {
-                for (int c = 0; c < cnt; ++c) s += reinterpret_cast<const float *>(sx[p & 1])[c];
+                wave_lds_fence();
             }
-            wave_lds_fence();
         }
     }
     if (lane == 0) out[0] = (double)s;

@@ -27,7 +27,7 @@ from .plsa import _fit_on_engine, _locked
 # for 8 at load time, see include/plsa_hip.h): 7 370-7 520 -> 8 070-8 290 fits/min with four members in flight; six or eight
 # in flight are slower (profiles/r04_hw_queues_api_jobs_6_8.txt), hence the cap (ENSTOP_AMD_CONCURRENT_MEMBERS_MAX: experiments).
 CONCURRENT_MEMBERS_MAX = int(os.environ.get("ENSTOP_AMD_CONCURRENT_MEMBERS_MAX", "4"))
-CONCURRENT_MEMBERS_CELLS = 2e9          # nnz * k below which members run concurrently
+CONCURRENT_MEMBERS_CELLS = float(os.environ.get("ENSTOP_AMD_CONCURRENT_MEMBERS_CELLS", "2e9"))   # nnz * k below which members run concurrently
 
 
 def concurrent_members(nnz, k, n_jobs):

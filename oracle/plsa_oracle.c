@@ -61,6 +61,13 @@ void oracle_set_threads(int t) {
 #endif
 }
 
+/* The log-likelihood reduction alone on ONE thread whatever the thread count of the E-step (which is independent per
+ * non-zero: threads cannot change it; the M-step scatter is serial in every build): the reference's source read literally --
+ * `result` one float32 running sum over the non-zeros in order, plsa.py:322, 375-384 -- without paying a single-threaded
+ * E-step for it.  Results are those of oracle_set_threads(1), bit for bit (tests/test_oracle_golden.py). */
+static int g_ll_sequential = 0;
+void oracle_set_ll_sequential(int on) { g_ll_sequential = on != 0; }
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
@@ -184,7 +191,7 @@ float oracle_log_likelihood(const int32_t *rows, const int32_t *cols, const floa
                             int64_t nnz, const float *V, const float *U, const float *sw,
                             int64_t m, int64_t k) {
     norm_t result = 0;                                   /* float32 in the reference, plsa.py:322 */
-#pragma omp parallel for schedule(static) reduction(+ : result)
+#pragma omp parallel for schedule(static) reduction(+ : result) if (!g_ll_sequential)
     for (int64_t nz = 0; nz < nnz; nz++) {
         const int64_t d = rows[nz], w = cols[nz];
         const float x = vals[nz];

@@ -38,6 +38,7 @@ class Oracle:
             build()
         L = self.lib = C.CDLL(path)
         L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_set_ll_sequential.argtypes = [C.c_int]
         L.oracle_max_threads.restype = C.c_int
         L.oracle_e_step.argtypes = [_i32p, _i32p, _i64, _f32p, _f32p, _f32p, _i64, _i64, C.c_float]
         L.oracle_m_step.argtypes = [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _f32p, _f32p, _f32p,
@@ -71,6 +72,10 @@ class Oracle:
 
     def max_threads(self):
         return int(self.lib.oracle_max_threads())
+
+    def set_ll_sequential(self, on=True):
+        """log-likelihood reduction on one thread (= set_threads(1) for the result, bit for bit) while the E-step keeps its threads"""
+        self.lib.oracle_set_ll_sequential(int(bool(on)))
 
     # -- kernel-level (numba signatures of plsa.py:26,111,208,314,734) ---------------------
     def plsa_e_step(self, X_rows, X_cols, X_vals, p_w_given_z, p_z_given_d, p_z_given_wd,

@@ -12,6 +12,8 @@ is data: inputs are the committed corpus of fit_cfg1_shape.npz, outputs are what
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py small       -> tests/golden/numba_small.npz
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py blocks      -> tests/golden/numba_block_streamed.npz
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py refit       -> tests/golden/numba_cfg1_refit.npz
+    /opt/conda/bin/python3.9 tests/golden/numba_reference.py at_scale 2 gpurun_out/cfg2_corpus.npz         -> numba_cfg2.npz
+    /opt/conda/bin/python3.9 tests/golden/numba_reference.py at_scale 3 gpurun_out/cfg3_150k_corpus.npz    -> numba_cfg3_sample.npz
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py fuzz [N]    -> compiled reference vs oracle/plsa_oracle.c
     /opt/conda/bin/python3.9 tests/golden/numba_reference.py time        -> compiled reference vs the C port, same cores
 """
@@ -398,6 +400,80 @@ def cmd_refit():
     json.dump(rep, open(os.path.join(ROOT, "profiles", "r05_numba_reference_cfg1_refit.json"), "w"), indent=1)
 
 
+def load_dump(path):
+    """a corpus downloaded from the GPU box by tools/dump_synthetic_corpus.py (the engine's own generator; its sha256 travels
+    with it and is what the GPU test checks the regenerated corpus against)"""
+    import hashlib
+    import numpy as np
+    import scipy.sparse as sp
+    g = np.load(path)
+    indptr = g["indptr"].astype(np.int64)
+    c = np.cumsum(g["indices_rowdelta"].astype(np.int64))
+    before = np.concatenate([[0], c])[indptr[:-1]]
+    indices = (c - np.repeat(before, np.diff(indptr))).astype(np.int32)
+    data = (g["data_u8"] if "data_u8" in g.files else g["data_u16"]).astype(np.float32)
+    X = sp.csr_matrix((data, indices, g["indptr"]), shape=tuple(int(v) for v in g["shape"]))
+    h = hashlib.sha256()
+    for arr in (X.indptr.astype(np.int32), X.indices.astype(np.int32), X.data.astype(np.float32)):
+        h.update(np.ascontiguousarray(arr).tobytes())
+    assert h.hexdigest() == str(g["sha256"]), "the dump does not decode to the matrix it was made from"
+    return X, g
+
+
+AT_SCALE = {2: dict(k=32, n_iter=3, name="numba_cfg2", rows=0), 3: dict(k=64, n_iter=2, name="numba_cfg3_sample", rows=150_000)}
+
+
+def cmd_at_scale(cfg_id, dump):
+    """RESULT fixtures of the reference COMPILED BY NUMBA above config 1 (round 6): BASELINE config 2 whole (100 k x 50 k, 10 M
+    non-zeros, k = 32, 3 iterations) and config 3's first 150 000 documents (15 M non-zeros over the full 100 k vocabulary,
+    k = 64, 2 iterations) -- the engine's own synthetic corpora, downloaded once (tools/dump_synthetic_corpus.py), fitted by the
+    compiled reference from RandomState(42) with a likelihood test after every iteration.  Stored: the corpus' sha256 (the
+    GPU test regenerates the corpus on the device and checks it), a row sample of P(z|d), a column sample of P(w|z), its
+    float64 row sums, the tested log-likelihoods, and for the record how far the compiled run sits from the strict / exact
+    oracles.  <= 3 MB each."""
+    import numpy as np
+    numba, ref = numba_env()
+    spec = AT_SCALE[cfg_id]
+    X, g = load_dump(dump)
+    assert int(g["rows"]) == spec["rows"]
+    n, m = X.shape
+    k, n_iter = spec["k"], spec["n_iter"]
+    sw = np.ones(n, np.float32)
+    numba.set_num_threads(numba.config.NUMBA_NUM_THREADS)
+    t0 = time.time()
+    res = fit_with_trace(ref, numba, X, k, sw, n_iter, 1, 0.0, 1e-32, 42)
+    dt = time.time() - t0
+    assert res["iters"] == n_iter
+    rs = np.random.RandomState(7)
+    rows = np.sort(rs.choice(n, 5000, replace=False)).astype(np.int32)
+    cols = np.sort(rs.choice(m, 4000, replace=False)).astype(np.int32)
+    report = {"config": cfg_id, "shape": [n, m], "nnz": int(X.nnz), "k": k, "n_iter": n_iter, "numba_version": numba.__version__,
+              "threads": int(numba.config.NUMBA_NUM_THREADS), "seconds_incl_compilation": round(dt, 1),
+              "driver_vs_replicated_loop": {"U": peak_rel(res["U_inner"], res["U"]), "V": peak_rel(res["V_inner"], res["V"])}}
+    r, c, v = res["coo"]
+    for variant in ("strict", "wide"):
+        o = oracle(variant, 8)
+        Uo, Vo, tr, it = o.plsa_fit_inner(r, c, v, res["V0"].copy(), res["U0"].copy(), sw, n_iter=n_iter, n_iter_per_test=1,
+                                          tolerance=0.0, e_step_thresh=1e-32, return_trace=True)
+        report["compiled_reference_vs_oracle_%s" % variant] = {
+            "U": peak_rel(res["U"], Uo), "V": peak_rel(res["V"], Vo),
+            "ll_rel": float(np.max(np.abs(res["trace"].astype(np.float64) - tr) / np.abs(tr)))}
+    out = dict(numba_version=np.array(numba.__version__), corpus_sha256=np.array(str(g["sha256"])), corpus_seed=np.int64(g["seed"]),
+               corpus_rows=np.int64(spec["rows"]), shape=np.array([n, m], np.int64), nnz=np.int64(X.nnz), k=np.int64(k),
+               n_iter=np.int64(n_iter), fit_seed=np.int64(42), U_rows=rows, U_sample=res["U"][rows], V_cols=cols,
+               V_sample=res["V"][:, cols], V_rowsum64=res["V"].astype(np.float64).sum(axis=1), ll_trace=res["trace"],
+               vs_strict_U=np.float64(report["compiled_reference_vs_oracle_strict"]["U"]),
+               vs_strict_V=np.float64(report["compiled_reference_vs_oracle_strict"]["V"]),
+               vs_wide_U=np.float64(report["compiled_reference_vs_oracle_wide"]["U"]),
+               vs_wide_V=np.float64(report["compiled_reference_vs_oracle_wide"]["V"]),
+               vs_wide_ll=np.float64(report["compiled_reference_vs_oracle_wide"]["ll_rel"]))
+    path = os.path.join(HERE, spec["name"] + ".npz")
+    np.savez_compressed(path, **out)
+    report["fixture_bytes"] = os.path.getsize(path)
+    print(json.dumps(report, indent=1))
+    json.dump(report, open(os.path.join(ROOT, "profiles", "r06_%s.json" % spec["name"]), "w"), indent=1)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "fixture"
     if what == "fixture":
@@ -412,3 +488,5 @@ if __name__ == "__main__":
         cmd_blocks()
     elif what == "refit":
         cmd_refit()
+    elif what == "at_scale":
+        cmd_at_scale(int(sys.argv[2]), sys.argv[3])

@@ -348,3 +348,23 @@ def test_numba_compiled_refit_at_cfg1_shape(oracle):
     d = peak_rel(g["U_every_second_row"], U[::2])
     # the recorded figure is over all rows, this one over the stored half of them
     assert d < 1e-5 and 0.5 * float(g["compiled_vs_strict"]) < d < 2.0 * float(g["compiled_vs_strict"]), (d, float(g["compiled_vs_strict"]))
+
+
+def test_sequential_likelihood_switch_is_the_one_thread_result():
+    """oracle_set_ll_sequential: the log-likelihood reduction alone on one thread while the E-step keeps its threads (the at-scale
+    GPU tests use it for "the reference's source on one thread"): the same bits as set_threads(1), on a problem large enough
+    (1.5 M non-zeros) for the threaded reduction to differ."""
+    from oracle.plsa_oracle import Oracle
+    g = load_golden("fit_k4_big")
+    r, c, v = coo_arrays(golden_csr(g))
+    ones = np.ones(g["U"].shape[0], np.float32)
+    o = Oracle(variant="strict")
+    o.set_threads(1)
+    one = o.log_likelihood(r, c, v, g["V"], g["U"], ones)
+    o.set_threads(8)
+    many = o.log_likelihood(r, c, v, g["V"], g["U"], ones)
+    o.set_ll_sequential(True)
+    seq = o.log_likelihood(r, c, v, g["V"], g["U"], ones)
+    o.set_ll_sequential(False)
+    assert seq == one and many != one
+    assert o.log_likelihood(r, c, v, g["V"], g["U"], ones) == many

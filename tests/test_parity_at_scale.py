@@ -138,6 +138,42 @@ def corpus(amd, cfg):
     return _corpora[key]
 
 
+def _numba_fixture_leg(X, fixture, results, rec):
+    """Round 6: RESULT fixtures of the reference COMPILED BY NUMBA above config 1 (tests/golden/numba_cfg2.npz,
+    numba_cfg3_sample.npz; tests/golden/numba_reference.py at_scale).  `results` = {label: (U, V, trace)} of fits of this very
+    corpus from RandomState(42) with the fixture's iteration count and a likelihood test after every iteration.  Asserted:
+    (i) the engine's generator still produces the corpus the compiled reference was run on (sha256); (ii) in THE REFERENCE'S
+    ROUNDING ("reference_arithmetic") north_star's literal tolerances against the compiled reference: 1e-4 on the sampled
+    P(z|d) rows and P(w|z) columns, 1e-5 on every tested log-likelihood; (iii) in the DEFAULT arithmetic (float64 norm_pwz /
+    likelihood) the relaxed bound -- no further from the compiled reference than it is from exact arithmetic."""
+    import hashlib
+    from conftest import load_golden, peak_rel
+    g = load_golden(fixture)
+    h = hashlib.sha256()
+    for a in (X.indptr.astype(np.int32), X.indices.astype(np.int32), X.data.astype(np.float32)):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert h.hexdigest() == str(g["corpus_sha256"]), "the synthetic corpus of %s changed" % fixture
+    rows, cols = g["U_rows"], g["V_cols"]
+    out = rec.setdefault("vs_numba_compiled_reference", {
+        "fixture": fixture, "numba_version": str(g["numba_version"]),
+        "compiled_reference_vs_exact": {"U": float(g["vs_wide_U"]), "V": float(g["vs_wide_V"]), "ll_rel": float(g["vs_wide_ll"])},
+        "compiled_reference_vs_strict_oracle": {"U": float(g["vs_strict_U"]), "V": float(g["vs_strict_V"])}})
+    for label, (U, V, trace) in results.items():
+        out[label] = {"U": peak_rel(U[rows], g["U_sample"]), "V": peak_rel(V[:, cols], g["V_sample"]),
+                      "V_rowsum": float(np.abs(V.astype(np.float64).sum(axis=1) - g["V_rowsum64"]).max()),
+                      "ll_rel": ll_rel(np.asarray(trace)[:len(g["ll_trace"])], g["ll_trace"])}
+    _flush_report()
+    for label, e in out.items():
+        if not isinstance(e, dict) or "ll_rel" not in e or label.startswith("compiled_"):
+            continue
+        if label == "reference_arithmetic":
+            assert e["U"] <= 1e-4 and e["V"] <= 1e-4 and e["ll_rel"] <= 1e-5, (fixture, label, e)
+        else:
+            w = out["compiled_reference_vs_exact"]
+            assert e["U"] <= 1.5 * w["U"] + 2e-5 and e["V"] <= 1.5 * w["V"] + 2e-5, (fixture, label, e, w)
+            assert e["ll_rel"] <= 1.5 * w["ll_rel"] + 1e-5, (fixture, label, e, w)
+
+
 def bits_equal(a, b):
     a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
     return bool(a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)))
@@ -162,9 +198,9 @@ def _reference_arithmetic_leg(amd, oracles, eng, coo, U0, V0, strict, rec, n_ite
                 "U_bits_equal_strict_oracle": bits_equal(U, strict[0]), "V_bits_equal_strict_oracle": bits_equal(V, strict[1]),
                 "vs_strict": {"U": errs(U, strict[0]), "V": errs(V, strict[1])}})
     o = oracles["strict"]
-    o.set_threads(1)
+    o.set_ll_sequential(True)
     ll_seq_o = float(o.log_likelihood(r, c, v, strict[1], strict[0], ones))
-    o.set_threads(oracles["threads"])
+    o.set_ll_sequential(False)
     ll64_o = float(oracles["n64"].log_likelihood(r, c, v, strict[1], strict[0], ones))
     ll64_h = float(eng.log_likelihood())                       # the engine holds the fit's final factors
     eng.set_arithmetic("reference_source")
@@ -179,9 +215,10 @@ def _reference_arithmetic_leg(amd, oracles, eng, coo, U0, V0, strict, rec, n_ite
     assert out["U_bits_equal_strict_oracle"] and out["V_bits_equal_strict_oracle"], out["vs_strict"]
     assert out["final_log_likelihood"]["sequential_float32"]["rel"] <= 1e-5, out["final_log_likelihood"]
     assert out["final_log_likelihood"]["float64_accumulator"]["rel"] <= 1e-6, out["final_log_likelihood"]
+    return U, V, trace
 
 
-def _fit_case(amd, oracles, cfg, name, n_iter, n_iter_per_test):
+def _fit_case(amd, oracles, cfg, name, n_iter, n_iter_per_test, numba_fixture=None):
     X = corpus(amd, cfg)
     n, m = X.shape
     k = cfg["k"]
@@ -208,6 +245,7 @@ def _fit_case(amd, oracles, cfg, name, n_iter, n_iter_per_test):
     # at config 1 that alone carries it 1.3e-4 away from exact arithmetic
     rec["n64_vs_wide"] = {"U": errs(ref["n64"][0], ref["wide"][0]), "V": errs(ref["n64"][1], ref["wide"][1]),
                           "ll_rel": ll_rel(ref["n64"][2], ref["wide"][2])}
+    results = {}
     with amd.Engine() as eng:
         eng.upload_csr(X)
         for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
@@ -215,6 +253,7 @@ def _fit_case(amd, oracles, cfg, name, n_iter, n_iter_per_test):
             iters, trace = eng.fit(None, n_iter=n_iter, n_iter_per_test=n_iter_per_test, tolerance=0.0,
                                    e_step_thresh=1e-32, flags=flags, trace=True)
             U, V = eng.get_factors()
+            results[sched] = (U, V, trace)
             out = rec.setdefault(sched, {})
             for variant in ("strict", "n64", "wide"):
                 Uo, Vo, tr_o, it_o = ref[variant]
@@ -232,7 +271,10 @@ def _fit_case(amd, oracles, cfg, name, n_iter, n_iter_per_test):
                     assert s_[f]["peak_rel"] <= 1.5 * w[f]["peak_rel"] + 2e-5, (sched, variant, f, s_[f], w[f])
                 assert s_["ll_rel"] <= 1.5 * w["ll_rel"] + 1e-5, (sched, variant, s_["ll_rel"], w["ll_rel"])
         # the reference's rounding as an option (PLSA_REFERENCE_SUMS): the strict oracle's bits at this size
-        _reference_arithmetic_leg(amd, oracles, eng, (r, c, v), U0, V0, ref["strict"], rec, n_iter, n_iter_per_test)
+        results["reference_arithmetic"] = _reference_arithmetic_leg(amd, oracles, eng, (r, c, v), U0, V0, ref["strict"], rec,
+                                                                    n_iter, n_iter_per_test)
+        if numba_fixture:
+            _numba_fixture_leg(X, numba_fixture, results, rec)
         # kernel level, one step from the initial factors: norm_pwz and the un-normalised P(w|z)
         eng.set_factors(U0, V0)
         eng.e_step(1e-32, want_host_copy=False)
@@ -283,10 +325,12 @@ def test_config1_default_tolerance_stops_where_the_oracle_stops(amd, oracles):
                                    ("strict_1_thread", "strict", 1),
                                    ("strict_%d_threads" % oracles["threads"], "strict", oracles["threads"])):
         o = oracles[variant]
-        o.set_threads(threads)
+        # "one thread": only the log-likelihood reduction depends on the thread count (module docstring) -- it alone runs
+        # sequentially, the E-step keeps its threads: the same bits as set_threads(1) in a third of the time
+        o.set_ll_sequential(threads == 1)
         t0 = time.time()
         _, _, trace, iters = o.plsa_fit_inner(r, c, v, V0.copy(), U0.copy(), ones, return_trace=True, **kw)
-        o.set_threads(oracles["threads"])
+        o.set_ll_sequential(False)
         stops[name], traces[name] = int(iters), [float(x) for x in trace]
         rec.setdefault("oracle_seconds", {})[name] = round(time.time() - t0, 1)
     with amd.Engine() as eng:
@@ -425,18 +469,16 @@ def test_cfg1_numba_compiled_reference(amd, oracles):
             vs_ref = {"U": peak_rel(U, g["U50"]), "V": peak_rel(V[:, cols], g["V50_sample"]),
                       "V_rowsum": float(np.abs(V.astype(np.float64).sum(axis=1) - g["V50_rowsum64"]).max()),
                       "ll_rel": ll_rel(trace, g["ll50"])}
-            eng.set_factors(U0, V0)
-            stop, _ = eng.fit(None, n_iter=100, n_iter_per_test=10, tolerance=1e-3, e_step_thresh=1e-32, flags=flags)
-            eng.set_factors(U0, V0)
-            stop_src, _ = eng.fit(None, n_iter=100, n_iter_per_test=10, tolerance=1e-3, e_step_thresh=1e-32,
-                                  flags=flags | amd.PLSA_REFERENCE_LL)
-            rec[sched] = {"vs_compiled_reference_after_50_iterations": vs_ref, "default_tolerance_stop_iteration": int(stop),
-                          "default_tolerance_stop_iteration_with_the_sequential_float32_likelihood": int(stop_src)}
+            rec[sched] = {"vs_compiled_reference_after_50_iterations": vs_ref}
+            if flags & amd.PLSA_FUSED:       # (the stop iterations once: the other flag runs the same kernels)
+                eng.set_factors(U0, V0)
+                stop, _ = eng.fit(None, n_iter=100, n_iter_per_test=10, tolerance=1e-3, e_step_thresh=1e-32, flags=flags)
+                rec[sched]["default_tolerance_stop_iteration"] = int(stop)
+                assert stop == stops_ref[1], (sched, stop, stops_ref)
             _flush_report()
             assert iters == 50
             assert vs_ref["U"] <= 1e-4 and vs_ref["V"] <= 1e-4, (sched, vs_ref)
             assert vs_ref["ll_rel"] <= 1e-5, (sched, vs_ref)
-            assert stop == stops_ref[1], (sched, stop, stops_ref)
 
 
 def test_cfg1_numba_compiled_refit(amd, oracles):
@@ -655,7 +697,7 @@ def test_config2_doc_sharded_fit(amd, oracles):
 
 
 def test_config2_fit_vs_oracle(amd, oracles):
-    _fit_case(amd, oracles, CONFIG2, "config2", n_iter=3, n_iter_per_test=1)
+    _fit_case(amd, oracles, CONFIG2, "config2", n_iter=3, n_iter_per_test=1, numba_fixture="numba_cfg2")
 
 
 def test_config3_shape_row_sample_vs_oracle(amd, oracles):
@@ -680,14 +722,16 @@ def test_config3_shape_row_sample_vs_oracle(amd, oracles):
         ref[variant] = (U, V, trace, iters)
     rec["strict_vs_wide"] = {"U": errs(ref["strict"][0], ref["wide"][0]), "V": errs(ref["strict"][1], ref["wide"][1]),
                              "ll_rel": ll_rel(ref["strict"][2], ref["wide"][2])}
+    results = {}
     with amd.Engine() as eng:
         eng.upload_csr(X)
-        _reference_arithmetic_leg(amd, oracles, eng, (r, c, v), U0, V0, ref["strict"], rec, 2, 1)
+        results["reference_arithmetic"] = _reference_arithmetic_leg(amd, oracles, eng, (r, c, v), U0, V0, ref["strict"], rec, 2, 1)
         for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
             eng.set_factors(U0, V0)
             iters, trace = eng.fit(None, n_iter=2, n_iter_per_test=1, tolerance=0.0, e_step_thresh=1e-32, flags=flags,
                                    trace=True)
             U, V = eng.get_factors()
+            results[sched] = (U, V, trace)
             out = rec.setdefault(sched, {})
             for variant in ("strict", "wide"):
                 out["vs_" + variant] = {"U": errs(U, ref[variant][0]), "V": errs(V, ref[variant][1]),
@@ -698,15 +742,17 @@ def test_config3_shape_row_sample_vs_oracle(amd, oracles):
             s_, w_ = out["vs_strict"], rec["strict_vs_wide"]
             for f in ("U", "V"):
                 assert s_[f]["peak_rel"] <= 1.5 * w_[f]["peak_rel"] + 2e-5, (sched, f, s_[f], w_[f])
+    if os.path.exists(os.path.join(ROOT, "tests", "golden", "numba_cfg3_sample.npz")):
+        _numba_fixture_leg(X, "numba_cfg3_sample", results, rec)
 
 
 def test_config3_full_corpus_vs_oracle(amd, oracles):
     """BASELINE configs[2] WHOLE: 1 M documents x 100 k words, 100 M non-zeros, k = 64 -- two EM iterations of both
-    schedules against the oracle in n64 arithmetic (the reference's algorithm with float64 norm_pwz / log-likelihood
-    sums) and in exact (wide) arithmetic; its 25.7 GB P(z|w,d) array lives in host memory, ~20 s per iteration on the
-    serial M-step.  This is the asserted config-3 check: a defect above 2^31 bytes / 1e8 entries that both schedules
-    share cannot hide here.  Asserted: within 1e-4 / 1e-5 of exact arithmetic; no further from n64 than n64 is from
-    exact (measured: HIP 9.9e-5 from n64 on P(w|z) -- n64's float32 column sums)."""
+    schedules against the oracle in exact (wide) arithmetic; its 25.7 GB P(z|w,d) array lives in host memory, ~20 s per
+    iteration on the serial M-step.  This is the asserted config-3 check: a defect above 2^31 bytes / 1e8 entries that both
+    schedules share cannot hide here.  Asserted: within 1e-4 / 1e-5 of exact arithmetic.  (Round 5 also ran the n64 build:
+    HIP 9.9e-5 from its float32 column sums; since round 6 the reference's float32 arithmetic is compared bit for bit on the
+    150 000-document sample instead, and the suite stays under eight minutes.)"""
     from enstop_amd.engine import reset_engines
     reset_engines()
     with amd.Engine() as eng:
@@ -721,7 +767,10 @@ def test_config3_full_corpus_vs_oracle(amd, oracles):
     rec = REPORT.setdefault("config3_full_corpus", {"shape": [n, m], "nnz": int(X.nnz), "k": k, "n_iter": n_iter,
                                                     "oracle_threads": oracles["threads"]})
     ref = {}
-    for variant in ("n64", "wide"):
+    # round 6: the exact-arithmetic build only.  (Round 5 also ran the n64 build here -- another 41-second pass -- and found HIP
+    # 9.9e-5 from its float32 column sums, profiles/r05_parity_at_scale.json; the reference's float32 arithmetic is now compared
+    # BIT FOR BIT on the 150 000-document sample, test_config3_shape_row_sample_vs_oracle, PLSA_REFERENCE_SUMS.)
+    for variant in ("wide",):
         t0 = time.time()
         Uo, Vo = U0.copy(), V0.copy()
         _, _, tr_o, it_o = oracles[variant].plsa_fit_inner(r, c, v, Vo, Uo, ones, n_iter=n_iter, n_iter_per_test=1,
@@ -729,9 +778,6 @@ def test_config3_full_corpus_vs_oracle(amd, oracles):
         ref[variant] = (Uo, Vo, tr_o, it_o)
         rec.setdefault("oracle_seconds", {})[variant] = round(time.time() - t0, 1)
     del r, c, v
-    # n64 adds a head word's column (up to 1 M entries) into ONE float32, sequentially: its own distance to exact
-    rec["n64_vs_wide"] = {"U": errs(ref["n64"][0], ref["wide"][0]), "V": errs(ref["n64"][1], ref["wide"][1]),
-                          "ll_rel": ll_rel(ref["n64"][2], ref["wide"][2])}
     with amd.Engine() as eng:
         eng.upload_csr(X)
         for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
@@ -741,17 +787,13 @@ def test_config3_full_corpus_vs_oracle(amd, oracles):
             U, V = eng.get_factors()
             out = rec.setdefault(sched, {"U_rowsum_max_dev": float(np.abs(U.sum(axis=1, dtype=np.float64) - 1).max()),
                                          "V_rowsum_max_dev": float(np.abs(V.sum(axis=1, dtype=np.float64) - 1).max())})
-            for variant in ("n64", "wide"):
+            for variant in ("wide",):
                 Uo, Vo, tr_o, it_o = ref[variant]
                 assert iters == it_o == n_iter
                 out["vs_" + variant] = {"U": errs(U, Uo), "V": errs(V, Vo), "ll_rel": ll_rel(trace, tr_o)}
             _flush_report()
             e = out["vs_wide"]
             assert e["U"]["peak_rel"] <= 1e-4 and e["V"]["peak_rel"] <= 1e-4 and e["ll_rel"] <= 1e-5, (sched, e)
-            e, w = out["vs_n64"], rec["n64_vs_wide"]
-            for f in ("U", "V"):
-                assert e[f]["peak_rel"] <= 1.5 * w[f]["peak_rel"] + 2e-5, (sched, f, e[f], w[f])
-            assert e["ll_rel"] <= 1.5 * w["ll_rel"] + 1e-5, (sched, e, w)
             eng.release_scratch()
 
 
@@ -759,7 +801,7 @@ def test_config5_row_sample_vs_streamed_oracle(amd, oracles):
     """BASELINE configs[4] (5 M x 200 k, 500 M nnz, k = 128): the first 500 000 documents of that corpus -- 50 M
     non-zeros over the full 200 k vocabulary -- against the block-streamed oracle (the loop of
     enstop/streamed_plsa.py:469-603, which never holds an nnz x k array; the config-5 route of the reference's
-    block_parallel / streamed classes) in n64 and wide arithmetic; one EM iteration + both likelihoods, both schedules,
+    block_parallel / streamed classes) in exact (wide) arithmetic; one EM iteration + both likelihoods, both schedules,
     the streamed loop's stop rule (PLSA_STOP_NO_ZERO_ARM)."""
     from enstop_amd.engine import reset_engines
     reset_engines()
@@ -775,7 +817,7 @@ def test_config5_row_sample_vs_streamed_oracle(amd, oracles):
     rec = REPORT.setdefault("config5_first_500k_docs", {"shape": [n, m], "nnz": int(X.nnz), "k": k, "n_iter": 1,
                                                         "oracle": "streamed loop, block_size 1048576"})
     ref = {}
-    for variant in ("n64", "wide"):
+    for variant in ("wide",):           # (round 5 also ran the n64 build: 8.3e-6 / 3.5e-5 from exact; one 35-second pass less)
         t0 = time.time()
         U, V = U0.copy(), V0.copy()
         _, _, trace, iters = oracles[variant].streamed_plsa_fit_inner(r, c, v, V, U, ones, block_size=1 << 20, n_iter=1,
@@ -792,12 +834,12 @@ def test_config5_row_sample_vs_streamed_oracle(amd, oracles):
                                    flags=flags | amd.engine.PLSA_STOP_NO_ZERO_ARM, trace=True)
             U, V = eng.get_factors()
             out = rec.setdefault(sched, {})
-            for variant in ("n64", "wide"):
+            for variant in ("wide",):
                 Uo, Vo, tr_o, it_o = ref[variant]
                 assert iters == it_o == 1
                 out["vs_" + variant] = {"U": errs(U, Uo), "V": errs(V, Vo), "ll_rel": ll_rel(trace, tr_o)}
             _flush_report()
-            for variant in ("n64", "wide"):
+            for variant in ("wide",):
                 e = out["vs_" + variant]
                 assert e["U"]["peak_rel"] <= 1e-4 and e["V"]["peak_rel"] <= 1e-4 and e["ll_rel"] <= 1e-5, (sched, variant, e)
             eng.release_scratch()
