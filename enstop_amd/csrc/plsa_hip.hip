@@ -311,6 +311,7 @@ struct HostStage {
     hipStream_t stream[STAGE_THREADS] = {};
     hipEvent_t ev[STAGE_THREADS][2] = {};
     bool ok = false, tried = false;
+    bool d2h_kernel = false;       // PLSA_D2H_KERNEL=1 (experiment): device-to-host chunks written by a copy kernel
 } g_stage;
 
 bool stage_ready(int device) {        // (g_stage.mu held)
@@ -325,6 +326,8 @@ bool stage_ready(int device) {        // (g_stage.mu held)
     g_stage.tried = true; g_stage.device = device; g_stage.ok = true;
     const char *off = getenv("PLSA_STAGED_COPIES");
     if (off && atoi(off) == 0) { g_stage.ok = false; return false; }
+    const char *dk = getenv("PLSA_D2H_KERNEL");
+    g_stage.d2h_kernel = dk && atoi(dk) != 0;
     for (int t = 0; t < STAGE_THREADS && g_stage.ok; ++t) {
         for (int b = 0; b < 2; ++b) {
             if (!g_stage.slot[t][b] && hipHostMalloc(&g_stage.slot[t][b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) g_stage.ok = false;
@@ -362,6 +365,14 @@ bool staged_copy(plsa_ctx *c, void *dev, void *host, size_t bytes, bool to_devic
             int b = 0;
             auto issue = [&](size_t ci, int slot) {
                 const size_t off = ci * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - off);
+                if (g_stage.d2h_kernel && len % 16 == 0) {
+                    // the device writes the page-locked slot itself (a copy kernel over PCIe) instead of the DMA engine
+                    const i64 n4 = (i64)(len / 16);
+                    hipLaunchKernelGGL(plsa::k_probe_copy, dim3((unsigned)std::min<i64>((n4 + 255) / 256, 2048)), dim3(256), 0, st,
+                                       reinterpret_cast<const float *>((const char *)dev + off),
+                                       reinterpret_cast<float *>(g_stage.slot[t][slot]), n4);
+                    return hipGetLastError() == hipSuccess && hipEventRecord(g_stage.ev[t][slot], st) == hipSuccess;
+                }
                 return hipMemcpyAsync(g_stage.slot[t][slot], (const char *)dev + off, len, hipMemcpyDeviceToHost, st) == hipSuccess &&
                        hipEventRecord(g_stage.ev[t][slot], st) == hipSuccess;
             };
@@ -1328,8 +1339,13 @@ int run_ref_m_step(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_
             const int *ri = c->rowidx.as<int>();
             float *out = c->norm_pwz.as<float>();
             auto go = [&](auto NZ) {
-                hipLaunchKernelGGL((plsa::ref::k_ref_norm_chain<decltype(NZ)::value>), dim3(1), dim3(plsa::ref::CHAIN_THREADS), 0,
-                                   c->ls, ri, c->val, c->nnz, p_base(c), d_sw, kp, out);
+                if (c->nnz <= 0) { (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)kp, c->ls); return; }
+                if (d_sw)
+                    hipLaunchKernelGGL((plsa::ref::k_ref_norm_chain<decltype(NZ)::value, true>), dim3(1), dim3(plsa::ref::CHAIN_THREADS), 0,
+                                       c->ls, ri, c->val, c->nnz, p_base(c), d_sw, kp, out);
+                else
+                    hipLaunchKernelGGL((plsa::ref::k_ref_norm_chain<decltype(NZ)::value, false>), dim3(1), dim3(plsa::ref::CHAIN_THREADS), 0,
+                                       c->ls, ri, c->val, c->nnz, p_base(c), d_sw, kp, out);
             };
             using std::integral_constant;
             if (kp <= 64) go(integral_constant<int, 1>{});

@@ -218,7 +218,7 @@ constexpr int CHAIN_DEPTH = 4;                         // tiles in flight in reg
 // immediate offsets and the dependent v_add_f32 (first version, run-time stride kp + per-element predicates: ~10
 // instructions = 20-30 ns per row; 63 / 240 / 447 ms per iteration at config 1 / 2 / the config-3 150 k sample).  Lanes
 // beyond kp read padding and add it into accumulators nobody stores.
-template <int NZ>
+template <int NZ, bool HAS_SW>
 __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__restrict__ rowidx,
                                                                   const float *__restrict__ vals, i64 nnz,
                                                                   const float *__restrict__ P,
@@ -239,41 +239,52 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__r
         srow[s] = slot[s] / kq;
         spos[s] = srow[s] * (STRIDE / 4) + (slot[s] - srow[s] * kq);
     }
-    float4 reg[CHAIN_DEPTH][CHAIN_F4];
-    auto fetch = [&](i64 t, float4 (&dst)[CHAIN_F4]) {
+    // What is kept in flight is the RAW data of CHAIN_DEPTH tiles (P values, count, weight); the products are formed when a
+    // tile is written to LDS, i.e. the loads a wave waits for are always its OLDEST (s_waitcnt vmcnt(n > 0)).  The loads are
+    // branch-free: a slot beyond the tile / the corpus reads entry 0 (valid: nnz >= 1 here) and is zeroed by a select.  (First
+    // version: products formed right after a load that sat under a branch -- every tile waited for all outstanding loads,
+    // one tile in flight instead of CHAIN_DEPTH, 2.2 us per tile, the whole kernel at 15 GB/s.)
+    float4 rp_[CHAIN_DEPTH][CHAIN_F4];
+    float rx_[CHAIN_DEPTH][CHAIN_F4], rw_[CHAIN_DEPTH][CHAIN_F4];
+    auto fetch = [&](i64 t, float4 (&dp)[CHAIN_F4], float (&dx)[CHAIN_F4], float (&dw)[CHAIN_F4]) {
         const i64 row0 = t * ROWS;
 #pragma unroll
         for (int s = 0; s < CHAIN_F4; ++s) {
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             const i64 nz = row0 + srow[s];
-            if (t < n_tiles && slot[s] < f4_per_tile && nz < nnz) {
-                const float4 p = *reinterpret_cast<const float4 *>(P + row0 * kp + (i64)slot[s] * 4);
-                const float x = vals[nz];
-                o.x = x * p.x; o.y = x * p.y; o.z = x * p.z; o.w = x * p.w;                 // plsa.py:188
-                if (sw) { const float wd = sw[rowidx[nz]]; o.x = o.x * wd; o.y = o.y * wd; o.z = o.z * wd; o.w = o.w * wd; }   // :294
-            }
-            dst[s] = o;
+            const bool ok = slot[s] < f4_per_tile && nz < nnz;
+            const i64 nzc = ok ? nz : 0;
+            dp[s] = *reinterpret_cast<const float4 *>(P + (ok ? row0 * kp + (i64)slot[s] * 4 : (i64)0));
+            dx[s] = vals[nzc];
+            dw[s] = HAS_SW ? sw[rowidx[nzc]] : 1.0f;
         }
     };
+    auto products = [&](i64 t, const float4 &p, float x, float wd, int s) {
+        const bool ok = slot[s] < f4_per_tile && t * ROWS + srow[s] < nnz;
+        float4 o;
+        o.x = x * p.x; o.y = x * p.y; o.z = x * p.z; o.w = x * p.w;                         // plsa.py:188
+        if (HAS_SW) { o.x = o.x * wd; o.y = o.y * wd; o.z = o.z * wd; o.w = o.w * wd; }     // plsa.py:294
+        o.x = ok ? o.x : 0.0f; o.y = ok ? o.y : 0.0f; o.z = ok ? o.z : 0.0f; o.w = ok ? o.w : 0.0f;
+        return o;
+    };
 #pragma unroll
-    for (int dd = 0; dd < CHAIN_DEPTH; ++dd) fetch(dd, reg[dd]);
+    for (int dd = 0; dd < CHAIN_DEPTH; ++dd) fetch(dd, rp_[dd], rx_[dd], rw_[dd]);
     float acc[NZ];
 #pragma unroll
     for (int t = 0; t < NZ; ++t) acc[t] = 0.0f;
     for (i64 t0 = 0; t0 < n_tiles; t0 += CHAIN_DEPTH) {
 #pragma unroll
         for (int dd = 0; dd < CHAIN_DEPTH; ++dd) {           // static register indices; tile t = t0 + dd
-            const i64 t = t0 + dd;
-            if (t >= n_tiles) break;                         // (uniform)
+            const i64 t = t0 + dd;                           // (a tile past the end holds zeros and has no rows: no early exit --
+                                                             //  with one the compiler drained all loads at every loop entry)
             float4 *buf = tile[dd & 1];                      // CHAIN_DEPTH is even: buffer parity == parity of t
 #pragma unroll
             for (int s = 0; s < CHAIN_F4; ++s)
-                if (slot[s] < f4_per_tile) buf[spos[s]] = reg[dd][s];
+                if (slot[s] < f4_per_tile) buf[spos[s]] = products(t, rp_[dd][s], rx_[dd][s], rw_[dd][s], s);
             __syncthreads();
-            fetch(t + CHAIN_DEPTH, reg[dd]);
+            fetch(t + CHAIN_DEPTH, rp_[dd], rx_[dd], rw_[dd]);
             if (tid < 64) {
                 const float *rp = reinterpret_cast<const float *>(buf) + tid;
-                const int rows = (int)min((i64)ROWS, nnz - t * ROWS);
+                const int rows = (int)max((i64)0, min((i64)ROWS, nnz - t * ROWS));
                 constexpr int UN = NZ >= 8 ? 2 : (NZ == 4 ? 4 : 8);     // rows whose LDS reads are issued ahead of their adds
                 int r = 0;
                 for (; r + UN <= rows; r += UN, rp += UN * STRIDE) {
