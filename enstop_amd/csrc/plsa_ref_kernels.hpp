@@ -24,7 +24,7 @@
 //   :378-384 dot += P(w|z) P(z|d); result += x log(dot) sw     k_ref_ll_terms + k_ref_ll_chain (PLSA_REFERENCE_LL only): one
 //                                                                               float32 running sum over all non-zeros
 //
-// None of this is fast (the chains are the point); it is a PARITY mode: 10-60 ms per iteration at the BASELINE sizes the
+// None of this is fast (the chains are the point); it is a PARITY mode: 20-110 ms per iteration at the BASELINE sizes the
 // tests run it on.  Layouts are the engine's (U [n,kp], Vt [m,kp] word-major, P [nnz,kp], pad entries zero: a zero product
 // adds +0.0, which changes no sum).
 #pragma once
@@ -157,27 +157,46 @@ __global__ __launch_bounds__(256) void k_ref_col_pass(const int *__restrict__ co
                                                       int m, const float *__restrict__ P, const float *__restrict__ sw,
                                                       float *__restrict__ Vacc, int kp) {
     constexpr int GPB = 256 / G;
-    constexpr int B = 8;
+    constexpr int B = NZ <= 2 ? 16 : 8;         // rows of P in flight per group
     const int li = threadIdx.x % G, gid = threadIdx.x / G;
     for (i64 w = (i64)blockIdx.x * GPB + gid; w < m; w += (i64)gridDim.x * GPB) {
         const int j0 = colptr[w], j1 = colptr[w + 1];
         float acc[NZ];
 #pragma unroll
         for (int t = 0; t < NZ; ++t) acc[t] = 0.0f;
+        if (j0 >= j1) {
+#pragma unroll
+            for (int t = 0; t < NZ; ++t) { const int z = li + G * t; if (z < kp) Vacc[w * kp + z] = 0.0f; }
+            continue;
+        }
+        // The Zipf-head columns are the long pole (one group walks up to n entries): the entry records (position in CSR order,
+        // count, document weight) of the NEXT batch are requested while the current batch's rows of P are in flight, so a batch
+        // costs one memory latency, not the two of "index, then the row it points to" (first version: 5.4 / 42 / 63 ms at
+        // config 1 / config 2 / the config-3 150 k sample).
+        i64 pos_n[B];
+        float x_n[B], wd_n[B];
+        auto load_records = [&](int jb) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const int j = min(jb + b, j1 - 1);
+                pos_n[b] = csc_pos[j];
+                x_n[b] = csc_val[j];
+                wd_n[b] = sw ? sw[csc_row[j]] : 1.0f;
+            }
+        };
+        load_records(j0);
         for (int jb = j0; jb < j1; jb += B) {
             float p[B][NZ], x[B], wd[B];
 #pragma unroll
             for (int b = 0; b < B; ++b) {
-                const int j = min(jb + b, j1 - 1);
-                const i64 pos = csc_pos[j];
-                x[b] = csc_val[j];
-                wd[b] = sw ? sw[csc_row[j]] : 1.0f;
+                x[b] = x_n[b]; wd[b] = wd_n[b];
 #pragma unroll
                 for (int t = 0; t < NZ; ++t) {
                     const int z = li + G * t;
-                    p[b][t] = z < kp ? P[pos * kp + z] : 0.0f;
+                    p[b][t] = z < kp ? P[pos_n[b] * kp + z] : 0.0f;
                 }
             }
+            load_records(min(jb + B, j1 - 1));     // (past the end: the last entry again, never added)
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 if (jb + b < j1) {
@@ -210,14 +229,23 @@ __global__ __launch_bounds__(256) void k_ref_col_pass(const int *__restrict__ co
 // ------------------------------------------------------------------------------------------------
 constexpr int CHAIN_THREADS = 1024;
 constexpr int CHAIN_TILE = 8192;                       // floats per LDS tile (32 KB; two tiles)
-constexpr int CHAIN_F4 = CHAIN_TILE / 4 / CHAIN_THREADS;   // float4 per lane and tile (2)
+constexpr int CHAIN_PRODUCERS = 768;                   // lanes that stream tiles in: the waves NOT on the adding wave's SIMD
+constexpr int CHAIN_F4 = (CHAIN_TILE / 4 + CHAIN_PRODUCERS - 1) / CHAIN_PRODUCERS;   // float4 per producer lane and tile (3)
 constexpr int CHAIN_DEPTH = 4;                         // tiles in flight in registers
 
-// The adding wave is bound by its own instruction stream (one wave: every instruction costs four cycles), so a tile row
-// sits in LDS at a COMPILE-TIME stride of 64 NZ floats whatever kp is: the row loop is then nothing but ds_read_b32 with
-// immediate offsets and the dependent v_add_f32 (first version, run-time stride kp + per-element predicates: ~10
-// instructions = 20-30 ns per row; 63 / 240 / 447 ms per iteration at config 1 / 2 / the config-3 150 k sample).  Lanes
-// beyond kp read padding and add it into accumulators nobody stores.
+// The adding wave (wave 0) is bound by its own instruction stream -- one wave: every instruction costs four cycles -- so
+//  * a tile row sits in LDS at a COMPILE-TIME stride of 64 NZ floats whatever kp is: the row loop is nothing but ds_read_b32 with
+//    immediate offsets and the dependent v_add_f32 (lanes beyond kp read padding into accumulators nobody stores);
+//  * wave 0 does nothing else, and the waves that share its SIMD (4, 8, 12: waves of a workgroup go round the four SIMDs)
+//    only keep the barriers: the twelve others stream the tiles in;
+//  * the producers keep the RAW data of CHAIN_DEPTH tiles in registers (P values, count, weight) and form the products when a
+//    tile is written to LDS, with branch-free loads from per-tile scalar bases + loop-invariant 32-bit lane offsets: a wave only
+//    ever waits for its OLDEST loads (s_waitcnt vmcnt(n > 0)) and spends ~17 instructions per float4.
+// History on the GPU (ms per EM iteration in the reference arithmetic, config 1 / config 2 / config-3 150 k sample; this kernel
+// runs beside the document and column passes and is the longer pole): run-time LDS stride + predicated reads 63 / 240 / 447;
+// compile-time stride 37 / 132 / 262; loads CHAIN_DEPTH tiles ahead 29 / 98 / 162; dedicated adding wave with its LDS reads one
+// batch ahead of its adds ~21 / 66 / 110 (the kernel alone: 19 / 64 / 101 ms = 6.4 ns per non-zero; a dependent v_add_f32 issues
+// every ~8 cycles, the sequential likelihood chain below runs at 3.7 ns per term).
 template <int NZ, bool HAS_SW>
 __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__restrict__ rowidx,
                                                                   const float *__restrict__ vals, i64 nnz,
@@ -228,79 +256,108 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__r
     constexpr int ROWS = CHAIN_TILE / STRIDE;                  // rows per tile (128 / NZ)
     __shared__ float4 tile[2][CHAIN_TILE / 4];
     const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform by construction: scalar branches below)
+    const bool producer = (wave & 3) != 0;                     // waves 1-3, 5-7, 9-11, 13-15
+    const int ptid = (wave - 1 - (wave >> 2)) * 64 + (tid & 63);   // 0 .. 767 among the producers
     const int kq = kp >> 2;
     const int f4_per_tile = ROWS * kq;                         // float4 of P one tile covers (<= 2048)
     const i64 n_tiles = (nnz + ROWS - 1) / ROWS;
-    // the lane's float4 slots inside a tile: tile-relative row and LDS position (the same for every tile)
-    int slot[CHAIN_F4], srow[CHAIN_F4], spos[CHAIN_F4];
+    // a producer lane's float4 slots inside a tile (the same for every tile): validity, tile-relative row, offset into the
+    // tile's part of P (floats), LDS position
+    bool sval[CHAIN_F4];
+    int srow[CHAIN_F4], soff[CHAIN_F4], spos[CHAIN_F4];
 #pragma unroll
     for (int s = 0; s < CHAIN_F4; ++s) {
-        slot[s] = tid + CHAIN_THREADS * s;
-        srow[s] = slot[s] / kq;
-        spos[s] = srow[s] * (STRIDE / 4) + (slot[s] - srow[s] * kq);
+        const int f = ptid + CHAIN_PRODUCERS * s;
+        sval[s] = producer && f < f4_per_tile;
+        srow[s] = sval[s] ? f / kq : 0;
+        soff[s] = sval[s] ? 4 * f : 0;
+        spos[s] = srow[s] * (STRIDE / 4) + (sval[s] ? f - srow[s] * kq : 0);
     }
-    // What is kept in flight is the RAW data of CHAIN_DEPTH tiles (P values, count, weight); the products are formed when a
-    // tile is written to LDS, i.e. the loads a wave waits for are always its OLDEST (s_waitcnt vmcnt(n > 0)).  The loads are
-    // branch-free: a slot beyond the tile / the corpus reads entry 0 (valid: nnz >= 1 here) and is zeroed by a select.  (First
-    // version: products formed right after a load that sat under a branch -- every tile waited for all outstanding loads,
-    // one tile in flight instead of CHAIN_DEPTH, 2.2 us per tile, the whole kernel at 15 GB/s.)
     float4 rp_[CHAIN_DEPTH][CHAIN_F4];
     float rx_[CHAIN_DEPTH][CHAIN_F4], rw_[CHAIN_DEPTH][CHAIN_F4];
+    // rows of tile t that exist (0 beyond the corpus); the loads of a tile beyond the end go to the last tile (valid addresses)
+    auto rows_of = [&](i64 t) { return (int)max((i64)0, min((i64)ROWS, nnz - t * ROWS)); };
     auto fetch = [&](i64 t, float4 (&dp)[CHAIN_F4], float (&dx)[CHAIN_F4], float (&dw)[CHAIN_F4]) {
-        const i64 row0 = t * ROWS;
+        const i64 row0 = min(t, n_tiles - 1) * ROWS;           // (uniform: scalar registers)
+        const int rows = t < n_tiles ? rows_of(t) : 0;
+        const float *Pt = P + row0 * kp;
+        const float *xt = vals + row0;
+        const int *rt = rowidx + row0;
 #pragma unroll
         for (int s = 0; s < CHAIN_F4; ++s) {
-            const i64 nz = row0 + srow[s];
-            const bool ok = slot[s] < f4_per_tile && nz < nnz;
-            const i64 nzc = ok ? nz : 0;
-            dp[s] = *reinterpret_cast<const float4 *>(P + (ok ? row0 * kp + (i64)slot[s] * 4 : (i64)0));
-            dx[s] = vals[nzc];
-            dw[s] = HAS_SW ? sw[rowidx[nzc]] : 1.0f;
+            const bool ok = sval[s] && srow[s] < rows;
+            dp[s] = *reinterpret_cast<const float4 *>(Pt + (ok ? soff[s] : 0));
+            dx[s] = xt[ok ? srow[s] : 0];
+            dw[s] = HAS_SW ? sw[rt[ok ? srow[s] : 0]] : 1.0f;
         }
     };
     auto products = [&](i64 t, const float4 &p, float x, float wd, int s) {
-        const bool ok = slot[s] < f4_per_tile && t * ROWS + srow[s] < nnz;
+        const bool ok = sval[s] && srow[s] < rows_of(t);
         float4 o;
         o.x = x * p.x; o.y = x * p.y; o.z = x * p.z; o.w = x * p.w;                         // plsa.py:188
         if (HAS_SW) { o.x = o.x * wd; o.y = o.y * wd; o.z = o.z * wd; o.w = o.w * wd; }     // plsa.py:294
         o.x = ok ? o.x : 0.0f; o.y = ok ? o.y : 0.0f; o.z = ok ? o.z : 0.0f; o.w = ok ? o.w : 0.0f;
         return o;
     };
-#pragma unroll
-    for (int dd = 0; dd < CHAIN_DEPTH; ++dd) fetch(dd, rp_[dd], rx_[dd], rw_[dd]);
+    // THREE loops, one per role, each free of inner branches (so that the producers' waits stay "oldest loads only"); every wave
+    // passes the same number of barriers: one per tile, the tile count rounded up to a multiple of CHAIN_DEPTH.
+    const i64 n_padded = (n_tiles + CHAIN_DEPTH - 1) / CHAIN_DEPTH * CHAIN_DEPTH;
     float acc[NZ];
 #pragma unroll
     for (int t = 0; t < NZ; ++t) acc[t] = 0.0f;
-    for (i64 t0 = 0; t0 < n_tiles; t0 += CHAIN_DEPTH) {
-#pragma unroll
-        for (int dd = 0; dd < CHAIN_DEPTH; ++dd) {           // static register indices; tile t = t0 + dd
-            const i64 t = t0 + dd;                           // (a tile past the end holds zeros and has no rows: no early exit --
-                                                             //  with one the compiler drained all loads at every loop entry)
-            float4 *buf = tile[dd & 1];                      // CHAIN_DEPTH is even: buffer parity == parity of t
-#pragma unroll
-            for (int s = 0; s < CHAIN_F4; ++s)
-                if (slot[s] < f4_per_tile) buf[spos[s]] = products(t, rp_[dd][s], rx_[dd][s], rw_[dd][s], s);
+    if (wave == 0) {
+        // the adding wave: tile t is complete in LDS after barrier t; the producers refill that buffer after barrier t + 1 at
+        // the earliest, which this wave reaches only when it is done with tile t
+        for (i64 t = 0; t < n_padded; ++t) {
             __syncthreads();
-            fetch(t + CHAIN_DEPTH, rp_[dd], rx_[dd], rw_[dd]);
-            if (tid < 64) {
-                const float *rp = reinterpret_cast<const float *>(buf) + tid;
-                const int rows = (int)max((i64)0, min((i64)ROWS, nnz - t * ROWS));
-                constexpr int UN = NZ >= 8 ? 2 : (NZ == 4 ? 4 : 8);     // rows whose LDS reads are issued ahead of their adds
-                int r = 0;
-                for (; r + UN <= rows; r += UN, rp += UN * STRIDE) {
-                    float v[UN][NZ];
+            const float *rp = reinterpret_cast<const float *>(tile[t & 1]) + tid;
+            const int rows = rows_of(t);
+            // software pipeline: the LDS reads of the NEXT batch of UN rows are in flight while this batch is added (one batch at
+            // a time left ~130 cycles of LDS latency exposed per 8 rows: 19 cycles = 9 ns per row; this kernel took 26 / 89 / 137 ms
+            // per iteration at config 1 / config 2 / the config-3 150 k sample)
+            constexpr int UN = NZ >= 8 ? 2 : (NZ == 4 ? 4 : 8);
+            float va[UN][NZ], vb[UN][NZ];
+            auto load = [&](float (&v)[UN][NZ], int r0) {
 #pragma unroll
-                    for (int u = 0; u < UN; ++u)
+                for (int u = 0; u < UN; ++u)
 #pragma unroll
-                        for (int c = 0; c < NZ; ++c) v[u][c] = rp[u * STRIDE + 64 * c];
+                    for (int c = 0; c < NZ; ++c) v[u][c] = rp[(r0 + u) * STRIDE + 64 * c];
+            };
+            auto add = [&](const float (&v)[UN][NZ]) {
 #pragma unroll
-                    for (int u = 0; u < UN; ++u)
+                for (int u = 0; u < UN; ++u)
 #pragma unroll
-                        for (int c = 0; c < NZ; ++c) acc[c] += v[u][c];      // plsa.py:193
-                }
-                for (; r < rows; ++r, rp += STRIDE)
+                    for (int c = 0; c < NZ; ++c) acc[c] += v[u][c];          // plsa.py:193
+            };
+            // ALL rows of the tile, unguarded: the producers write every row of every tile -- products, or +0.0 for the rows past
+            // the end of the corpus, and x + 0.0 == x -- so the loop has a compile-time trip count and the chain is one v_add_f32
+            // per row and topic (a per-row `r < rows` test put a v_cndmask behind every add: twice the dependent chain)
+            (void)rows;
+            load(va, 0);
+#pragma unroll 2
+            for (int r = 0; r < ROWS; r += 2 * UN) {
+                load(vb, r + UN);
+                add(va);
+                if (r + 2 * UN < ROWS) load(va, r + 2 * UN);
+                add(vb);
+            }
+        }
+    } else if (!producer) {
+        for (i64 t = 0; t < n_padded; ++t) __syncthreads();          // waves 4, 8, 12: they would share the adding wave's SIMD
+    } else {
 #pragma unroll
-                    for (int c = 0; c < NZ; ++c) acc[c] += rp[64 * c];
+        for (int dd = 0; dd < CHAIN_DEPTH; ++dd) fetch(dd, rp_[dd], rx_[dd], rw_[dd]);
+        for (i64 t0 = 0; t0 < n_padded; t0 += CHAIN_DEPTH) {
+#pragma unroll
+            for (int dd = 0; dd < CHAIN_DEPTH; ++dd) {       // static register indices; tile t = t0 + dd
+                const i64 t = t0 + dd;                       // (a tile past the end holds zeros and has no rows)
+                float4 *buf = tile[dd & 1];                  // CHAIN_DEPTH is even: buffer parity == parity of t
+#pragma unroll
+                for (int s = 0; s < CHAIN_F4; ++s)
+                    if (sval[s]) buf[spos[s]] = products(t, rp_[dd][s], rx_[dd][s], rw_[dd][s], s);
+                __syncthreads();
+                fetch(t + CHAIN_DEPTH, rp_[dd], rx_[dd], rw_[dd]);
             }
         }
     }
@@ -341,7 +398,9 @@ __global__ __launch_bounds__(256) void k_ref_ll_terms(const int *__restrict__ ro
     }
 }
 
-// one wave: terms are loaded 64 at a time (PF loads in flight), every lane adds them in order (same chain in all lanes)
+// one wave: terms are loaded 64 at a time (PF loads in flight), every lane adds them in order (the same chain in all lanes).
+// A tile of 64 terms goes through LDS (one write per lane, 16 broadcast ds_read_b128); the reads of tile p + 1 are in flight while
+// tile p is added.  Terms past the end are +0.0 (x + 0.0 == x): no tail case.
 __global__ __launch_bounds__(64) void k_ref_ll_chain(const float *__restrict__ terms, i64 nnz, double *__restrict__ out) {
     constexpr int PF = 16;
     __shared__ float4 sx[2][16];
@@ -353,6 +412,16 @@ __global__ __launch_bounds__(64) void k_ref_ll_chain(const float *__restrict__ t
         nxt[p] = i < nnz ? terms[i] : 0.0f;
     }
     float s = 0.0f;
+    auto stage = [&](float mine, int buf, float4 (&v)[16]) {
+        reinterpret_cast<float *>(sx[buf])[lane] = mine;
+        wave_lds_fence();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = sx[buf][c];
+    };
+    auto add = [&](const float4 (&v)[16]) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { s += v[c].x; s += v[c].y; s += v[c].z; s += v[c].w; }      // plsa.py:383
+    };
     for (i64 base = 0; base < nnz; base += 64 * PF) {
         float cur[PF];
 #pragma unroll
@@ -362,24 +431,16 @@ __global__ __launch_bounds__(64) void k_ref_ll_chain(const float *__restrict__ t
             const i64 i = base + 64 * PF + (i64)p * 64 + lane;
             nxt[p] = i < nnz ? terms[i] : 0.0f;
         }
+        float4 va[16], vb[16];
+        stage(cur[0], 0, va);
 #pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const i64 first = base + (i64)p * 64;
-            if (first < nnz) {                               // (uniform; no `break`: the loop must unroll, cur[] stays in registers)
-                reinterpret_cast<float *>(sx[p & 1])[lane] = cur[p];
-                wave_lds_fence();
-                const int cnt = (int)min((i64)64, nnz - first);
-                if (cnt == 64) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        const float4 v = sx[p & 1][c];
-                        s += v.x; s += v.y; s += v.z; s += v.w;          // plsa.py:383
-                    }
-                } else {
-                    for (int c = 0; c < cnt; ++c) s += reinterpret_cast<const float *>(sx[p & 1])[c];
-                }
-                wave_lds_fence();
-            }
+        for (int p = 0; p < PF; p += 2) {
+            stage(cur[p + 1], 1, vb);
+            add(va);
+            wave_lds_fence();
+            if (p + 2 < PF) stage(cur[p + 2], 0, va);
+            add(vb);
+            wave_lds_fence();
         }
     }
     if (lane == 0) out[0] = (double)s;

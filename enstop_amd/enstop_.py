@@ -30,6 +30,15 @@ CONCURRENT_MEMBERS_MAX = int(os.environ.get("ENSTOP_AMD_CONCURRENT_MEMBERS_MAX",
 CONCURRENT_MEMBERS_CELLS = float(os.environ.get("ENSTOP_AMD_CONCURRENT_MEMBERS_CELLS", "2e9"))   # nnz * k below which members run concurrently
 
 
+def _member_flags(kwargs):
+    """`flags=` and / or `arithmetic=` of plsa_topics / ensemble_of_topics -> the flags of the members' fits (None: defaults)"""
+    from .engine import arithmetic_flags, default_flags
+    flags, arithmetic = kwargs.get("flags", None), kwargs.get("arithmetic", None)
+    if arithmetic is None:
+        return flags
+    return (default_flags() if flags is None else flags) | arithmetic_flags(arithmetic)
+
+
 def concurrent_members(nnz, k, n_jobs):
     if n_jobs is None or n_jobs < 1 or nnz * float(k) >= CONCURRENT_MEMBERS_CELLS:
         return 1
@@ -101,7 +110,8 @@ def _member_on_engine(eng, k, bootstrap=True, random_state=None, init="random", 
 def plsa_topics(X, k, **kwargs):
     """Bootstrap-resample the documents of X and fit pLSA; returns the (k, n_words) topic matrix.
     Keyword arguments as the reference: bootstrap, random_state, init, n_iter, n_iter_per_test,
-    tolerance, e_step_thresh (default 1e-16 here, enstop_.py:99,111); plus device, flags."""
+    tolerance, e_step_thresh (default 1e-16 here, enstop_.py:99,111); plus device, flags, arithmetic ("reference": the
+    reference's float32 sums, rounding for rounding -- engine.arithmetic_flags)."""
     A = X.tocsr() if issparse(X) else csr_matrix(X)
     eng = get_engine(kwargs.get("device", None))
     eng.upload_csr(A)
@@ -109,7 +119,7 @@ def plsa_topics(X, k, **kwargs):
         eng, k, bootstrap=kwargs.get("bootstrap", True), random_state=kwargs.get("random_state", None),
         init=kwargs.get("init", "random"), n_iter=kwargs.get("n_iter", 100),
         n_iter_per_test=kwargs.get("n_iter_per_test", 10), tolerance=kwargs.get("tolerance", 0.001),
-        e_step_thresh=kwargs.get("e_step_thresh", 1e-16), flags=kwargs.get("flags", None))
+        e_step_thresh=kwargs.get("e_step_thresh", 1e-16), flags=_member_flags(kwargs))
 
 
 def nmf_topics(X, k, **kwargs):
@@ -176,7 +186,7 @@ def _ensemble_of_plsa_topics(X, k, n_jobs=4, n_runs=16, parallelism="dask", **kw
     member_kw = dict(bootstrap=kwargs.get("bootstrap", True), init=kwargs.get("init", "random"),
                      n_iter=kwargs.get("n_iter", 100), n_iter_per_test=kwargs.get("n_iter_per_test", 10),
                      tolerance=kwargs.get("tolerance", 0.001),
-                     e_step_thresh=kwargs.get("e_step_thresh", 1e-16), flags=kwargs.get("flags", None))
+                     e_step_thresh=kwargs.get("e_step_thresh", 1e-16), flags=_member_flags(kwargs))
     random_state = kwargs.get("random_state", None)
 
     if parallelism == "none":

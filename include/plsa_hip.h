@@ -51,7 +51,7 @@ enum {
                            norm_pwz[z] as ONE chain over all non-zeros (:193) -- the sum that puts the reference 1e-2 from exact
                            arithmetic at 3 M non-zeros.  Results are the bits of the reference's source executed statement by
                            statement (the fixtures under tests/golden; the numba-compiled reference sits 2e-5 from them at config 1).  The
-                           kernel sequence is the reference's (P(z|w,d) materialised; PLSA_FUSED is ignored); a parity mode, 10-60 ms
+                           kernel sequence is the reference's (P(z|w,d) materialised; PLSA_FUSED is ignored); a parity mode, 20-110 ms
                            per iteration at the BASELINE sizes, not available with PLSA_SHARDED.  The log-likelihood stays the
                            float64-accumulated one (which is what the compiled reference's vectorised reduction delivers to 1e-7) unless: */
     PLSA_REFERENCE_LL = 512, /* the log-likelihood as ONE float32 running sum over the non-zeros in COO order, its inner product a float32

@@ -160,3 +160,18 @@ def test_reference_mode_refuses_sharding(amd):
             eng.em_accumulate()
         eng.set_arithmetic(None)
         eng.em_accumulate()
+
+
+def test_ensemble_members_bits(amd):
+    """enstop_.py:84-115 (a bootstrapped member) and :220-231 (the serial ensemble sharing one RandomState) in the reference's
+    rounding: the members' topic matrices are the reference's bits -- device bootstrap gather, device MT19937 initialisation and
+    the reference-arithmetic EM kernels in one chain."""
+    g = load_golden("member_k6")
+    X = golden_csr(g)
+    k = int(g["k"])
+    kw = dict(n_iter=int(g["n_iter"]), n_iter_per_test=10, tolerance=0.0, e_step_thresh=float(g["thresh"]), arithmetic="reference")
+    same_bits(amd.plsa_topics(X, k, random_state=np.random.RandomState(5), **kw), g["V_rs5"], "member, RandomState(5)")
+    same_bits(amd.plsa_topics(X, k, random_state=9, **kw), g["V_int9"], "member, seed 9")
+    same_bits(amd.plsa_topics(X, k, random_state=9, bootstrap=False, **kw), g["V_nobootstrap"], "member without bootstrap")
+    stack = amd.ensemble_of_topics(X, k, n_runs=3, parallelism="none", random_state=np.random.RandomState(21), **kw)
+    same_bits(stack, g["V_stack_rs21"], "serial ensemble of three")
