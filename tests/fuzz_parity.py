@@ -27,6 +27,7 @@ def main():
     oracle.set_threads(8)
     rs = np.random.RandomState(seed)
     worst = dict(U=0.0, V=0.0, ll=0.0)
+    ref_bits = ref_cases = 0
     t0 = time.time()
     bad = 0
     for case in range(cases):
@@ -97,6 +98,25 @@ def main():
             tol = 1e-4 if thresh <= 1e-16 and X.nnz < 50_000 else (1e-3 if thresh <= 1e-16 else 2e-2)
             if eu > tol or ev > tol:
                 print("FACTOR MISMATCH %.2e %.2e" % (eu, ev), msg); bad += 1
+        # round 6: THE REFERENCE'S ROUNDING (arithmetic="reference_source": PLSA_REFERENCE_SUMS | PLSA_REFERENCE_LL) -- no tolerance:
+        # same iteration count (the sequential float32 likelihoods agree to the last place of the logarithm, so a different
+        # stop decision needs a test sitting within ~1e-7 of its tolerance) and then both factors BIT FOR BIT
+        oracle.set_ll_sequential(True)      # the reference's source on one thread (the E-step keeps its threads: same bits)
+        Uo, Vo, trace, iters = oracle.plsa_fit(X, k, sw, return_trace=True, **kw)
+        oracle.set_ll_sequential(False)
+        U, V, info = enstop_amd.plsa_fit(X, k, sw, return_info=True, arithmetic="reference_source", **kw)
+        ref_cases += 1
+        msg = "case %d knobs %r: n=%d m=%d k=%d dens=%g thresh=%g %r" % (case, knobs, n, m, k, dens, thresh, kw)
+        if info["n_iter"] != iters:
+            tr = info["log_likelihood_trace"].astype(np.float64); q = min(len(tr), len(trace))
+            fin = np.isfinite(trace[:q]) & np.isfinite(tr[:q])
+            e_ll = float(np.max(np.abs(tr[:q][fin] - trace[:q][fin]) / np.maximum(np.abs(trace[:q][fin]), 1e-30))) if fin.any() else 0.0
+            print("REFERENCE-ARITHMETIC ITER MISMATCH", msg, info["n_iter"], iters, "ll rel %.2e" % e_ll); bad += 1
+        elif not (np.array_equal(U.view(np.uint32), Uo.view(np.uint32)) and np.array_equal(V.view(np.uint32), Vo.view(np.uint32))):
+            # (-0.0 against +0.0 cannot occur: all sums are of non-negative terms)
+            print("REFERENCE-ARITHMETIC BITS DIFFER %.2e %.2e" % (np.abs(U - Uo).max(), np.abs(V - Vo).max()), msg); bad += 1
+        else:
+            ref_bits += 1
         if k <= 64 and case % 4 == 0:                          # refit against the oracle
             topics = Vo
             Uo2 = oracle.plsa_refit(X, topics, sw, n_iter=5, n_iter_per_test=2, tolerance=0.0, e_step_thresh=thresh, random_state=3)
@@ -106,7 +126,8 @@ def main():
                 print("REFIT MISMATCH %.2e" % eu, "case", case, knobs); bad += 1
         for k_ in knobs:
             os.environ.pop(k_, None)
-    print("cases %d  mismatches %d  worst rel err U %.2e V %.2e LL %.2e  (%.0f s)" % (cases, bad, worst["U"], worst["V"], worst["ll"], time.time() - t0))
+    print("cases %d  mismatches %d  worst rel err U %.2e V %.2e LL %.2e  reference arithmetic: %d of %d fits bit-identical to the oracle  (%.0f s)"
+          % (cases, bad, worst["U"], worst["V"], worst["ll"], ref_bits, ref_cases, time.time() - t0))
     sys.exit(1 if bad else 0)
 
 

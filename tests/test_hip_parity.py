@@ -1696,6 +1696,8 @@ def test_fuzz_slice(amd):
                          capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "mismatches 0" in out.stdout
+    # round 6: every case also runs once in the reference's rounding and must equal the strict oracle BIT FOR BIT
+    assert "200 of 200 fits bit-identical" in out.stdout, out.stdout[-500:]
 
 
 @pytest.mark.parametrize("per_test", [2, 3, 5])

@@ -175,3 +175,46 @@ def test_ensemble_members_bits(amd):
     same_bits(amd.plsa_topics(X, k, random_state=9, bootstrap=False, **kw), g["V_nobootstrap"], "member without bootstrap")
     stack = amd.ensemble_of_topics(X, k, n_runs=3, parallelism="none", random_state=np.random.RandomState(21), **kw)
     same_bits(stack, g["V_stack_rs21"], "serial ensemble of three")
+
+
+@pytest.mark.parametrize("k", [1, 3, 65, 128, 130, 300, 520, 1000])
+def test_wide_topic_counts_bits(amd, k):
+    """Topic counts beyond one wave (k > 64: two to sixteen topics per lane in the chains and passes), k = 1 and an odd k,
+    with document weights and e_step_thresh = 0 (denormal norms: the true division needs no rescue) -- against the strict
+    oracle, bit for bit, kernel level and a short weighted fit."""
+    import scipy.sparse as sp
+    from oracle.plsa_oracle import Oracle
+    o = Oracle(variant="strict")
+    o.set_threads(4)
+    o.set_ll_sequential(True)
+    rs = np.random.RandomState(100 + k)
+    n, m = 70, 90
+    X = sp.random(n, m, density=0.15, format="csr", random_state=rs, dtype=np.float64)
+    X.data = np.ceil(X.data * 4)
+    X = X.astype(np.float32)
+    r, c, v = coo_arrays(X)
+    U0 = rs.rand(n, k); U0 /= U0.sum(1, keepdims=True)
+    V0 = rs.rand(k, m); V0 /= V0.sum(1, keepdims=True)
+    U0 = U0.astype(np.float32); V0 = V0.astype(np.float32)
+    sw = (0.25 + rs.rand(n)).astype(np.float32)
+    for thresh in (np.float32(0.0), np.float32(1e-32)):
+        Po = np.zeros((X.nnz, k), np.float32)
+        o.plsa_e_step(r, c, v, V0, U0, Po, thresh)
+        P = np.zeros_like(Po)
+        amd.plsa_e_step(r, c, v, V0.copy(), U0.copy(), P, thresh, arithmetic="reference")
+        same_bits(P, Po, "P(z|w,d), thresh %g" % thresh)
+    Vo, Uo = V0.copy(), U0.copy()
+    nwo, ndo = np.zeros(k, np.float32), np.zeros(n, np.float32)
+    o.plsa_m_step_w_sample_weight(r, c, v, Vo, Uo, Po, sw, nwo, ndo)
+    V, U = V0.copy(), U0.copy()
+    nw, nd = np.zeros(k, np.float32), np.zeros(n, np.float32)
+    amd.plsa_m_step_w_sample_weight(r, c, v, V, U, Po, sw, nw, nd, arithmetic="reference")
+    same_bits(nw, nwo, "norm_pwz"); same_bits(nd, ndo, "norm_pdz"); same_bits(V, Vo, "P(w|z)"); same_bits(U, Uo, "P(z|d)")
+    ll_o = o.log_likelihood(r, c, v, Vo, Uo, sw)
+    ll = amd.log_likelihood(r, c, v, V, U, sw, arithmetic="reference_source")
+    assert abs(float(ll) - float(ll_o)) <= 2e-6 * abs(float(ll_o)), (ll, ll_o)
+    kw = dict(n_iter=4, n_iter_per_test=2, tolerance=0.0, e_step_thresh=0.0, random_state=5)
+    Uf_o, Vf_o, _, it_o = o.plsa_fit(X, k, sw, return_trace=True, **kw)
+    Uf, Vf, info = amd.plsa_fit(X, k, sw, return_info=True, arithmetic="reference", **kw)
+    assert info["n_iter"] == it_o
+    same_bits(Uf, Uf_o, "fit P(z|d)"); same_bits(Vf, Vf_o, "fit P(w|z)")
