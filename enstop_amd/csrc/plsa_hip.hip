@@ -870,7 +870,9 @@ int run_e_step(plsa_ctx *c, float thresh) {
         const size_t need = sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp;
         size_t free_b = 0, total_b = 0;
         if (!c->p_borrowed && c->P.cap < need && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + c->P.cap < need)
-            return fail(c, "materialising P(z|w,d) needs %.1f GB but only %.1f GB of HBM are free; use the fused "
+            return fail(c, c->ref_sums ? "the reference arithmetic (PLSA_REFERENCE_SUMS) stores P(z|w,d) like the reference does: %.1f GB needed, "
+                                         "%.1f GB of HBM free -- at this size only the default arithmetic is available"
+                                       : "materialising P(z|w,d) needs %.1f GB but only %.1f GB of HBM are free; use the fused "
                            "schedule (PLSA_FUSED), which never stores it, or tile the documents (plsa_em_accumulate_materialised)", need / 1e9, (free_b + c->P.cap) / 1e9);
     }
     if (c->p_borrowed || c->p_lent) {

@@ -752,7 +752,8 @@ def test_config3_full_corpus_vs_oracle(amd, oracles):
     iteration on the serial M-step.  This is the asserted config-3 check: a defect above 2^31 bytes / 1e8 entries that both
     schedules share cannot hide here.  Asserted: within 1e-4 / 1e-5 of exact arithmetic.  (Round 5 also ran the n64 build:
     HIP 9.9e-5 from its float32 column sums; since round 6 the reference's float32 arithmetic is compared bit for bit on the
-    150 000-document sample instead, and the suite stays under eight minutes.)"""
+    150 000-document sample instead -- and, ONE iteration, on this whole corpus: PLSA_REFERENCE_SUMS against the strict oracle,
+    P(z|d) and P(w|z) bit for bit over all 100 M non-zeros.)"""
     from enstop_amd.engine import reset_engines
     reset_engines()
     with amd.Engine() as eng:
@@ -777,7 +778,22 @@ def test_config3_full_corpus_vs_oracle(amd, oracles):
                                                            tolerance=0.0, e_step_thresh=1e-32, return_trace=True)
         ref[variant] = (Uo, Vo, tr_o, it_o)
         rec.setdefault("oracle_seconds", {})[variant] = round(time.time() - t0, 1)
-    del r, c, v
+    # round 6: THE WHOLE of config 3 in the reference's rounding.  ONE iteration of the strict oracle (another 20 s) and of
+    # PLSA_REFERENCE_SUMS: bit for bit -- including the state the reference's float32 norm_pwz is in at this size (recorded: each
+    # topic's one running sum over 100 M terms of ~0.02 stops growing once its ulp exceeds twice the term)
+    t0 = time.time()
+    Us, Vs = U0.copy(), V0.copy()
+    _, _, tr_s, it_s = oracles["strict"].plsa_fit_inner(r, c, v, Vs, Us, ones, n_iter=1, n_iter_per_test=1, tolerance=0.0,
+                                                        e_step_thresh=1e-32, return_trace=True)
+    rec.setdefault("oracle_seconds", {})["strict_one_iteration"] = round(time.time() - t0, 1)
+    rec["reference_float32_topics_row_sums_after_one_iteration"] = {
+        "min": float(Vs.sum(axis=1, dtype=np.float64).min()), "max": float(Vs.sum(axis=1, dtype=np.float64).max()),
+        "exact_arithmetic": float(ref["wide"][1].sum(axis=1, dtype=np.float64).max())}
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        _reference_arithmetic_leg(amd, oracles, eng, (r, c, v), U0, V0, (Us, Vs, tr_s, it_s), rec, 1, 1)
+        eng.release_scratch()
+    del r, c, v, Us, Vs
     with amd.Engine() as eng:
         eng.upload_csr(X)
         for sched, flags in (("fused", amd.PLSA_FUSED), ("materialised", 0)):
