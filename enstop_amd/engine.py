@@ -70,33 +70,6 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-class FactorLanding:
-    """The result arrays of a fit, allocated BEFORE the iterations and touched by a side thread while the GPU works (the fill
-    releases the GIL): a fresh 282 MB pair of arrays costs the device-to-host copy of config 3's factors 10 ms in first-touch
-    page faults (16.5 ms against the 6 ms the bytes need); the ensemble's member stack has had the same treatment since round 4.
-    Below LANDING_MIN bytes nothing is started (a thread costs more than the faults)."""
-    LANDING_MIN = 32 << 20
-
-    def __init__(self, n, m, k, want_u=True, want_v=True):
-        self.shape = (n, m, k)
-        self.U = np.empty((n, k), np.float32) if want_u else None
-        self.V = np.empty((k, m), np.float32) if want_v else None
-        self._threads = []
-        for a in (self.U, self.V):
-            if a is not None and a.nbytes >= self.LANDING_MIN:
-                t = threading.Thread(target=a.fill, args=(0.0,), daemon=True)
-                t.start()
-                self._threads.append(t)
-
-    def take(self, n, m, k, want_u, want_v):
-        for t in self._threads:
-            t.join()
-        self._threads = []
-        if (n, m, k) != self.shape:                      # (a fit that changed the active matrix: plain arrays)
-            return (np.empty((n, k), np.float32) if want_u else None, np.empty((k, m), np.float32) if want_v else None)
-        return (self.U if want_u else None, self.V if want_v else None)
-
-
 class Engine:
     def __init__(self, device=None):
         self._L = _lib.load()
@@ -258,15 +231,10 @@ class Engine:
         self._ok(self._L.plsa_mt_marginals(self._h, out, int(self.k)))
         return out
 
-    def get_factors(self, want_u=True, want_v=True, out=None):
-        """(P(z|d) [n, k], P(w|z) [k, m]) as float32 host arrays.  `out`: a FactorLanding made before the fit -- its arrays are
-        then already resident in memory (see FactorLanding) and the copy is not slowed by first-touch page faults."""
+    def get_factors(self, want_u=True, want_v=True):
         n, m, _ = self.shape
-        if out is not None:
-            U, V = out.take(n, m, self.k, want_u, want_v)
-        else:
-            U = np.empty((n, self.k), np.float32) if want_u else None
-            V = np.empty((self.k, m), np.float32) if want_v else None
+        U = np.empty((n, self.k), np.float32) if want_u else None
+        V = np.empty((self.k, m), np.float32) if want_v else None
         self._ok(self._L.plsa_get_factors(self._h, ptr(U), ptr(V)))
         return U, V
 

@@ -23,7 +23,7 @@ from scipy.sparse import csr_matrix, issparse
 from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_array, check_random_state
 
-from .engine import PLSA_SW_LL_ONLY, PLSA_STOP_NO_ZERO_ARM, FactorLanding, arithmetic_flags, default_flags, get_engine
+from .engine import PLSA_SW_LL_ONLY, PLSA_STOP_NO_ZERO_ARM, arithmetic_flags, default_flags, get_engine
 from .utils import (_check_sample_weight, coherence, log_lift, mean_coherence, mean_log_lift, normalize,
                     standardize_input)
 
@@ -294,10 +294,9 @@ def plsa_fit(X, k, sample_weight, init="random", n_iter=100, n_iter_per_test=10,
     eng.upload_csr(X)
     if arithmetic is not None:
         flags = (default_flags() if flags is None else flags) | arithmetic_flags(arithmetic)
-    landing = FactorLanding(X.shape[0], X.shape[1], k)          # result arrays made resident while the GPU iterates
     iters, ll = _fit_on_engine(eng, k, sample_weight, init, n_iter, n_iter_per_test, tolerance,
                                e_step_thresh, random_state, flags, trace=return_info, X_for_init=X)
-    p_z_given_d, p_w_given_z = eng.get_factors(out=landing)
+    p_z_given_d, p_w_given_z = eng.get_factors()
     if return_info:
         return p_z_given_d, p_w_given_z, dict(n_iter=iters, log_likelihood_trace=ll)
     return p_z_given_d, p_w_given_z
@@ -344,9 +343,8 @@ def plsa_refit(X, topics, sample_weight, n_iter=50, n_iter_per_test=10, toleranc
     sw = None
     if sample_weight is not None and np.any(np.asarray(sample_weight) != 1.0):
         sw = np.asarray(sample_weight, np.float32)
-    landing = FactorLanding(X.shape[0], X.shape[1], k, want_v=False)
     iters, ll = eng.refit(sw, n_iter, n_iter_per_test, tolerance, e_step_thresh, flags, trace=return_info)
-    U, _ = eng.get_factors(want_v=False, out=landing)
+    U, _ = eng.get_factors(want_v=False)
     if return_info:
         return U, dict(n_iter=iters, log_likelihood_trace=ll)
     return U

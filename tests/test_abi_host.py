@@ -300,3 +300,37 @@ def test_mt19937_block_jump_matches_numpy(seed, advance, log2_blocks):
     np.testing.assert_array_equal(key[1:], want[1:])
     assert (key[0] ^ want[0]) & 0x80000000 == 0        # only the top bit of word 0 is generator state
     assert lib.plsa_host_mt19937_jump(key.ctypes.data_as(C.POINTER(C.c_uint32)), 41) == 1
+
+
+def test_headers_are_plain_c():
+    """Both headers compile as C (a cgo / JNI / ctypes-generator style consumer never sees C++): gcc -fsyntax-only, -Wall -Werror."""
+    import subprocess
+    for h in ("plsa_hip.h", "plsa_hip_diag.h"):
+        out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
+                              os.path.join(ROOT, "include", h)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+
+
+def test_arithmetic_keyword_and_environment_map_to_the_flags(monkeypatch):
+    """`arithmetic=` / ENSTOP_AMD_ARITHMETIC -> PLSA_REFERENCE_SUMS (| PLSA_REFERENCE_LL); the values are the header's."""
+    from enstop_amd import engine, PLSA, StreamedPLSA, BlockParallelPLSA
+    hdr = open(os.path.join(ROOT, "include", "plsa_hip.h")).read()
+    assert re.search(r"PLSA_REFERENCE_SUMS\s*=\s*256", hdr) and re.search(r"PLSA_REFERENCE_LL\s*=\s*512", hdr)
+    assert engine.PLSA_REFERENCE_SUMS == 256 and engine.PLSA_REFERENCE_LL == 512
+    assert engine.arithmetic_flags(None) == 0 == engine.arithmetic_flags("default")
+    assert engine.arithmetic_flags("reference") == 256 and engine.arithmetic_flags("reference_source") == 768
+    assert engine.arithmetic_flags(512) == 512
+    with pytest.raises(ValueError):
+        engine.arithmetic_flags("fast")
+    with pytest.raises(ValueError):
+        engine.arithmetic_flags(1)
+    monkeypatch.delenv("ENSTOP_AMD_ARITHMETIC", raising=False)
+    monkeypatch.delenv("ENSTOP_AMD_MATERIALISE", raising=False)
+    assert engine.default_flags() == engine.PLSA_FUSED
+    monkeypatch.setenv("ENSTOP_AMD_ARITHMETIC", "reference")
+    assert engine.default_flags() == engine.PLSA_FUSED | 256
+    monkeypatch.delenv("ENSTOP_AMD_ARITHMETIC")
+    assert PLSA(arithmetic="reference")._flags() & 256 and not PLSA()._flags() & 256
+    assert StreamedPLSA(arithmetic="reference_source")._flags() & 768 == 768
+    assert BlockParallelPLSA(arithmetic="reference").get_params()["arithmetic"] == "reference"
+
