@@ -311,7 +311,6 @@ struct HostStage {
     hipStream_t stream[STAGE_THREADS] = {};
     hipEvent_t ev[STAGE_THREADS][2] = {};
     bool ok = false, tried = false;
-    bool d2h_kernel = false;       // PLSA_D2H_KERNEL=1 (experiment): device-to-host chunks written by a copy kernel
 } g_stage;
 
 bool stage_ready(int device) {        // (g_stage.mu held)
@@ -326,8 +325,6 @@ bool stage_ready(int device) {        // (g_stage.mu held)
     g_stage.tried = true; g_stage.device = device; g_stage.ok = true;
     const char *off = getenv("PLSA_STAGED_COPIES");
     if (off && atoi(off) == 0) { g_stage.ok = false; return false; }
-    const char *dk = getenv("PLSA_D2H_KERNEL");
-    g_stage.d2h_kernel = dk && atoi(dk) != 0;
     for (int t = 0; t < STAGE_THREADS && g_stage.ok; ++t) {
         for (int b = 0; b < 2; ++b) {
             if (!g_stage.slot[t][b] && hipHostMalloc(&g_stage.slot[t][b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) g_stage.ok = false;
@@ -365,14 +362,6 @@ bool staged_copy(plsa_ctx *c, void *dev, void *host, size_t bytes, bool to_devic
             int b = 0;
             auto issue = [&](size_t ci, int slot) {
                 const size_t off = ci * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - off);
-                if (g_stage.d2h_kernel && len % 16 == 0) {
-                    // the device writes the page-locked slot itself (a copy kernel over PCIe) instead of the DMA engine
-                    const i64 n4 = (i64)(len / 16);
-                    hipLaunchKernelGGL(plsa::k_probe_copy, dim3((unsigned)std::min<i64>((n4 + 255) / 256, 2048)), dim3(256), 0, st,
-                                       reinterpret_cast<const float *>((const char *)dev + off),
-                                       reinterpret_cast<float *>(g_stage.slot[t][slot]), n4);
-                    return hipGetLastError() == hipSuccess && hipEventRecord(g_stage.ev[t][slot], st) == hipSuccess;
-                }
                 return hipMemcpyAsync(g_stage.slot[t][slot], (const char *)dev + off, len, hipMemcpyDeviceToHost, st) == hipSuccess &&
                        hipEventRecord(g_stage.ev[t][slot], st) == hipSuccess;
             };

@@ -367,4 +367,5 @@ def test_sequential_likelihood_switch_is_the_one_thread_result():
     seq = o.log_likelihood(r, c, v, g["V"], g["U"], ones)
     o.set_ll_sequential(False)
     assert seq == one and many != one
-    assert o.log_likelihood(r, c, v, g["V"], g["U"], ones) == many
+    again = o.log_likelihood(r, c, v, g["V"], g["U"], ones)            # the switch is off again: the threaded reduction
+    assert again != one and abs(float(again) - float(many)) <= 1e-6 * abs(float(many))   # (OpenMP combines the partials in any order)

@@ -44,6 +44,19 @@ def label(name):
     return None
 
 
+f = os.path.join(G, "bench_default_line.json")
+if os.path.exists(f) and os.path.getsize(f) > 0:      # the line exactly as the default command printed it (round 6: compact)
+    shutil.copy(f, os.path.join(P, "%s_bench_cfg3_1gpu_compact_line.json" % tag))
+for src, dst in (("bench_cfg4.json", "%s_bench_cfg4_1gpu.json"), ("bench_cfg3_topical.json", "%s_bench_cfg3_topical_1gpu.json")):
+    f = os.path.join(G, src)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        json.dump(last_json(f), open(os.path.join(P, dst % tag), "w"), indent=1)
+f = os.path.join(G, "fuzz_parity_5x1000.txt")
+if os.path.exists(f):
+    shutil.copy(f, os.path.join(P, "%s_fuzz_parity_5x1000.txt" % tag))
+f = os.path.join(G, "pytest_gpu.log")
+if os.path.exists(f):
+    shutil.copy(f, os.path.join(P, "%s_pytest_gpu.log" % tag))
 for cfg, src in ((3, "bench_default.json"), (1, "bench_cfg1.json"), (2, "bench_cfg2.json"), (5, "bench_cfg5.json")):
     f = os.path.join(G, src)
     if os.path.exists(f):
