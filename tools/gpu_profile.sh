@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -3
 # the default command exactly as the driver runs it: the compact line on stdout, the full object in gpurun_out/bench_full_cfg3_n1.json
 timeout 1500 python bench.py > gpurun_out/bench_default_line.json 2> gpurun_out/bench_default.err; tail -c 300 gpurun_out/bench_default.err
-wc -c gpurun_out/bench_default_line.json; cp gpurun_out/bench_full_cfg3_n1.json gpurun_out/bench_default.json
+wc -c gpurun_out/bench_default_line.json; python -c "import json; print(json.dumps(json.load(open('gpurun_out/bench_full_cfg3_n1.json'))))" > gpurun_out/bench_default.json
 for c in 2 1 5; do timeout 900 python bench.py --full --config $c --no-cpu-baseline --no-pmc > gpurun_out/bench_cfg$c.json 2> gpurun_out/bench_cfg$c.err; done
 # the N = 2 launch path on this single-GPU box: bench.py spawns its own ranks; RCCL refuses two ranks on one
 # device, so this is the host-file TEST MODE (labelled as such in the JSON) -- and the RCCL attempt must fail
