@@ -218,3 +218,56 @@ def test_wide_topic_counts_bits(amd, k):
     Uf, Vf, info = amd.plsa_fit(X, k, sw, return_info=True, arithmetic="reference", **kw)
     assert info["n_iter"] == it_o
     same_bits(Uf, Uf_o, "fit P(z|d)"); same_bits(Vf, Vf_o, "fit P(w|z)")
+
+
+STREAMFIT_CASES = ["streamfit_k6", "streamfit_k4_weighted", "streamfit_k5_earlystop", "streamfit_k8_thresh",
+                   "streamfit_k1_zero_change"]
+
+
+@pytest.mark.parametrize("case", STREAMFIT_CASES)
+def test_streamed_module_fit_bits(amd, case):
+    """enstop/streamed_plsa.py (blocks of non-zeros through double-buffered factors, :341-391) adds in plsa.py's order -- its
+    fixtures, generated by running THAT module, are met bit for bit by the reference arithmetic under its stop rule (no
+    `change == 0` arm, :596-597), in-range threshold and weights included."""
+    from enstop_amd.streamed_plsa import plsa_fit as streamed_fit
+    g = load_golden(case)
+    X = golden_csr(g)
+    U, V, info = streamed_fit(X, int(g["k"]), g["sw"], block_size=int(g["block_size"]), n_iter=int(g["n_iter"]),
+                              n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+                              e_step_thresh=float(g["thresh"]), random_state=int(g["fit_seed"]), return_info=True,
+                              arithmetic="reference_source")
+    assert info["n_iter"] == int(g["iters"])
+    same_bits(U, g["U"], case + " P(z|d)"); same_bits(V, g["V"], case + " P(w|z)")
+
+
+@pytest.mark.parametrize("case", ["streamrefit_k6", "streamrefit_k8_weighted_thresh"])
+def test_streamed_module_refit_bits(amd, case):
+    from enstop_amd.streamed_plsa import plsa_refit as streamed_refit
+    g = load_golden(case)
+    X = golden_csr(g)
+    U, info = streamed_refit(X, g["topics"], g["sw"], block_size=int(g["block_size"]), n_iter=int(g["n_iter"]),
+                             n_iter_per_test=int(g["n_iter_per_test"]), tolerance=float(g["tol"]),
+                             e_step_thresh=float(g["thresh"]), random_state=np.random.RandomState(42), return_info=True,
+                             arithmetic="reference")
+    assert info["n_iter"] == int(g["iters"])
+    same_bits(U, g["U"], case)
+
+
+@pytest.mark.parametrize("case", ["estimator_int", "estimator_float", "estimator_int_emptyrows"])
+def test_estimator_bits(amd, case):
+    """`PLSA.fit_transform` / `transform` as the reference's estimator runs them (plsa.py:1117-1220: validation, float input
+    L1-row-normalised, empty documents dropped and restored as float64 zeros, transform = 50 refit iterations from seed 42):
+    with `arithmetic="reference"` the fitted attributes and the transformed rows are the reference's bits."""
+    import scipy.sparse as sp
+    g = load_golden(case)
+    shape = tuple(int(s) for s in g["shape"])
+    X = sp.csr_matrix((g["data"], g["indices"], g["indptr"]), shape=shape)
+    model = amd.PLSA(n_components=int(g["k"]), n_iter=30, n_iter_per_test=10, tolerance=0.0, random_state=11,
+                     arithmetic="reference")
+    emb = model.fit_transform(X)
+    assert str(np.asarray(emb).dtype) == str(g["embedding_dtype"])
+    assert np.array_equal(np.asarray(emb, np.float64), np.asarray(g["embedding"], np.float64)), \
+        np.abs(np.asarray(emb, np.float64) - g["embedding"]).max()
+    same_bits(model.components_, g["components"], case + " components_")
+    Xt = sp.csr_matrix((g["t_data"], g["t_indices"], g["t_indptr"]), shape=tuple(int(s) for s in g["t_shape"]))
+    same_bits(model.transform(Xt), g["transformed"], case + " transform")
