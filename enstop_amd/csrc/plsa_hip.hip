@@ -302,21 +302,22 @@ int ensure_best_placement(plsa_ctx *c, DevBuf &b, size_t bytes, int max_candidat
 // others.  The slots are process-wide (64 MB page-locked once), copies of different contexts take turns.
 // ---------------------------------------------------------------------------------------------
 constexpr size_t STAGE_CHUNK = (size_t)8 << 20;
-constexpr int STAGE_THREADS = 4;
+constexpr int STAGE_THREADS_MAX = 8;
+int g_stage_threads = 4;          // helper threads in use (PLSA_STAGE_THREADS, 1 .. 8)
 constexpr size_t STAGE_MIN = (size_t)48 << 20;
 struct HostStage {
     std::mutex mu;
     int device = -1;
-    void *slot[STAGE_THREADS][2] = {};
-    hipStream_t stream[STAGE_THREADS] = {};
-    hipEvent_t ev[STAGE_THREADS][2] = {};
+    void *slot[STAGE_THREADS_MAX][2] = {};
+    hipStream_t stream[STAGE_THREADS_MAX] = {};
+    hipEvent_t ev[STAGE_THREADS_MAX][2] = {};
     bool ok = false, tried = false;
 } g_stage;
 
 bool stage_ready(int device) {        // (g_stage.mu held)
     if (g_stage.tried && g_stage.device == device) return g_stage.ok;
     if (g_stage.tried) {              // another device: rebuild the streams / events there, keep the host slots
-        for (int t = 0; t < STAGE_THREADS; ++t) {
+        for (int t = 0; t < STAGE_THREADS_MAX; ++t) {
             if (g_stage.stream[t]) (void)hipStreamDestroy(g_stage.stream[t]);
             for (int b = 0; b < 2; ++b) if (g_stage.ev[t][b]) (void)hipEventDestroy(g_stage.ev[t][b]);
             g_stage.stream[t] = nullptr; g_stage.ev[t][0] = g_stage.ev[t][1] = nullptr;
@@ -325,7 +326,9 @@ bool stage_ready(int device) {        // (g_stage.mu held)
     g_stage.tried = true; g_stage.device = device; g_stage.ok = true;
     const char *off = getenv("PLSA_STAGED_COPIES");
     if (off && atoi(off) == 0) { g_stage.ok = false; return false; }
-    for (int t = 0; t < STAGE_THREADS && g_stage.ok; ++t) {
+    const char *nt = getenv("PLSA_STAGE_THREADS");
+    if (nt) g_stage_threads = std::max(1, std::min(STAGE_THREADS_MAX, atoi(nt)));
+    for (int t = 0; t < g_stage_threads && g_stage.ok; ++t) {
         for (int b = 0; b < 2; ++b) {
             if (!g_stage.slot[t][b] && hipHostMalloc(&g_stage.slot[t][b], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) g_stage.ok = false;
             if (hipEventCreateWithFlags(&g_stage.ev[t][b], hipEventDisableTiming) != hipSuccess) g_stage.ok = false;
@@ -343,7 +346,8 @@ bool staged_copy(plsa_ctx *c, void *dev, void *host, size_t bytes, bool to_devic
     std::lock_guard<std::mutex> lock(g_stage.mu);
     if (!stage_ready(c->device)) return false;
     const size_t n_chunks = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
-    bool failed[STAGE_THREADS] = {};
+    const int STAGE_THREADS = g_stage_threads;
+    bool failed[STAGE_THREADS_MAX] = {};
     auto worker = [&](int t) {
         if (hipSetDevice(c->device) != hipSuccess) { failed[t] = true; return; }
         hipStream_t st = g_stage.stream[t];
@@ -376,7 +380,7 @@ bool staged_copy(plsa_ctx *c, void *dev, void *host, size_t bytes, bool to_devic
         }
         if (hipStreamSynchronize(st) != hipSuccess) failed[t] = true;
     };
-    std::thread th[STAGE_THREADS];
+    std::thread th[STAGE_THREADS_MAX];
     for (int t = 1; t < STAGE_THREADS; ++t) th[t] = std::thread(worker, t);
     worker(0);
     for (int t = 1; t < STAGE_THREADS; ++t) th[t].join();
