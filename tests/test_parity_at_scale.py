@@ -321,9 +321,10 @@ def test_config1_default_tolerance_stops_where_the_oracle_stops(amd, oracles):
     kw = dict(n_iter=100, n_iter_per_test=10, tolerance=1e-3, e_step_thresh=1e-32)
     rec = REPORT.setdefault("config1_default_tolerance", {"shape": [n, m], "nnz": int(X.nnz), "k": k, **kw})
     stops, traces = {}, {}
+    # (rounds 4-5 also RECORDED the strict build with its likelihood reduced on N threads -- it stops at 61, like numba's compiled
+    #  reduction, profiles/r05_parity_at_scale.json; nothing was asserted on it and the run cost the suite 8 s)
     for name, variant, threads in (("n64", "n64", oracles["threads"]), ("wide", "wide", oracles["threads"]),
-                                   ("strict_1_thread", "strict", 1),
-                                   ("strict_%d_threads" % oracles["threads"], "strict", oracles["threads"])):
+                                   ("strict_1_thread", "strict", 1)):
         o = oracles[variant]
         # "one thread": only the log-likelihood reduction depends on the thread count (module docstring) -- it alone runs
         # sequentially, the E-step keeps its threads: the same bits as set_threads(1) in a third of the time
