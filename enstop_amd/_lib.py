@@ -81,6 +81,7 @@ SIGNATURES = {
     "plsa_comm_allreduce_f64": (C.c_int, [_ctx, _f64p, _i64, _i32]),
     "plsa_comm_broadcast_host": (C.c_int, [_ctx, _vp, _i64, _i32]),
     "plsa_allreduce_accumulator": (C.c_int, [_ctx]),
+    "plsa_reference_chain_info": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
     "plsa_placement_info": (C.c_int, [_ctx, C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "plsa_schedule_info": (C.c_int, [_ctx, C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(_i32), C.POINTER(_i32),
                                      C.POINTER(C.c_int64)]),

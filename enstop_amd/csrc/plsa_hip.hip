@@ -139,6 +139,16 @@ struct plsa_ctx {
     // ref_ll:   the log-likelihood one float32 running sum over the non-zeros (plsa.py:322 read literally)
     bool ref_sums = false, ref_ll = false;
     DevBuf ref_terms;              // float32 [nnz]: per-entry log-likelihood terms of the sequential sum
+    // norm_pwz of the reference arithmetic from per-chunk parity pairs (k_ref_pair_*): PLSA_REF_CHAIN = pairs | serial | auto
+    // (auto, default: pairs from 4096 non-zeros on, back to the serial chain for the rest of a corpus' fits once more than a
+    // quarter of the chunks of an iteration took the walk's slow way -- chains that drift too far from the real sums)
+    int ref_chain_mode = 0;        // 0 auto, 1 always pairs, 2 always the serial chain
+    bool ref_pairs_off = false;    // auto mode: the current corpus went back to the serial chain
+    DevBuf ref_csum, ref_pairs, ref_exps, ref_stats;
+    unsigned long long *h_ref_stats = nullptr;   // pinned [2]: chunks that took the slow way / chunks, of the last finished walk
+    hipEvent_t ev_ref_stats = nullptr;
+    bool ref_stats_pending = false;
+    unsigned long long ref_slow_total = 0, ref_chunks_total = 0;   // accumulated over the walks read back so far (plsa_reference_chain_info)
     int placement_candidates = 4, placement_tried = 0;
     double placement_gbps[2] = {0.0, 0.0};
     size_t p_shift = 0;   // experiment knob: byte offset of P inside its allocation (PLSA_P_OFFSET_KB)
@@ -544,6 +554,7 @@ void set_active_pointers(plsa_ctx *c) {
     c->ritems_valid = false;
     c->eitems_valid = false;
     c->p_valid = false;
+    c->ref_pairs_off = false;
 }
 
 int ensure_rowidx(plsa_ctx *c) {
@@ -855,6 +866,7 @@ int need_factors(plsa_ctx *c) {
 // kernel wrappers
 // ---------------------------------------------------------------------------------------------
 int run_ref_e_step(plsa_ctx *c, float thresh);
+int run_ref_norm_pwz(plsa_ctx *c, const float *d_sw);
 int run_ref_m_step(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_pdz);
 int run_ref_loglik(plsa_ctx *c, const float *d_sw, double *out);
 
@@ -1314,6 +1326,92 @@ int run_ref_e_step(plsa_ctx *c, float thresh) {
     return 0;
 }
 
+// norm_pwz[z] = the reference's ONE float32 running sum over all non-zeros (plsa.py:193) on c->ls: from per-chunk parity pairs and a
+// walk (k_ref_pair_*), or by the serial chain (k_ref_norm_chain); same bits either way.
+int run_ref_norm_pwz(plsa_ctx *c, const float *d_sw) {
+    const int kp = c->kp;
+    const int *ri = c->rowidx.as<int>();
+    float *out = c->norm_pwz.as<float>();
+    if (c->nnz <= 0) { HIPCHK(c, hipMemsetAsync(out, 0, sizeof(float) * (size_t)kp, c->ls)); return 0; }
+    // the last walk's count of slow chunks, if it has arrived (never waited for)
+    if (c->ref_stats_pending && hipEventQuery(c->ev_ref_stats) == hipSuccess) {
+        c->ref_stats_pending = false;
+        const unsigned long long slow = c->h_ref_stats[0], chunks = c->h_ref_stats[1];
+        c->ref_slow_total += slow; c->ref_chunks_total += chunks;
+        if (c->ref_chain_mode == 0 && chunks > 0 && slow * 4 > chunks) c->ref_pairs_off = true;
+    }
+    const bool pairs = c->ref_chain_mode == 1 || (c->ref_chain_mode == 0 && !c->ref_pairs_off && c->nnz >= 4096);
+    auto by_nz = [&](auto &&go) {
+        using std::integral_constant;
+        if (kp <= 64) go(integral_constant<int, 1>{});
+        else if (kp <= 128) go(integral_constant<int, 2>{});
+        else if (kp <= 256) go(integral_constant<int, 4>{});
+        else if (kp <= 512) go(integral_constant<int, 8>{});
+        else go(integral_constant<int, 16>{});
+    };
+    if (!pairs) {
+        Scope s(c, "k_ref_norm_chain");
+        by_nz([&](auto NZ) {
+            if (d_sw)
+                hipLaunchKernelGGL((plsa::ref::k_ref_norm_chain<decltype(NZ)::value, true>), dim3(1), dim3(plsa::ref::CHAIN_THREADS), 0,
+                                   c->ls, ri, c->val, c->nnz, p_base(c), d_sw, kp, out);
+            else
+                hipLaunchKernelGGL((plsa::ref::k_ref_norm_chain<decltype(NZ)::value, false>), dim3(1), dim3(plsa::ref::CHAIN_THREADS), 0,
+                                   c->ls, ri, c->val, c->nnz, p_base(c), d_sw, kp, out);
+        });
+        return launch_check(c, "k_ref_norm_chain");
+    }
+    const i64 n_chunks = (c->nnz + plsa::ref::PAIR_L - 1) / plsa::ref::PAIR_L;
+    const i64 n_super = (n_chunks + plsa::ref::PAIR_SC - 1) / plsa::ref::PAIR_SC, n_pad = n_super * plsa::ref::PAIR_SC;
+    CHK(ensure(c, c->ref_csum, sizeof(double) * (size_t)n_pad * kp));
+    CHK(ensure(c, c->ref_pairs, sizeof(uint4) * (size_t)n_chunks * kp));
+    CHK(ensure(c, c->ref_exps, sizeof(unsigned short) * (size_t)n_chunks * kp));
+    CHK(ensure(c, c->ref_stats, 16));
+    if (!c->h_ref_stats) {
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_ref_stats), 16, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_ref_stats, hipEventDisableTiming));
+    }
+    const int grid = grid_for(c, n_super, 4);
+    double *csum = c->ref_csum.as<double>();
+    uint4 *prs = c->ref_pairs.as<uint4>();
+    unsigned short *exps = c->ref_exps.as<unsigned short>();
+    unsigned long long *stats = c->ref_stats.as<unsigned long long>();
+    HIPCHK(c, hipMemsetAsync(stats, 0, 16, c->ls));
+    by_nz([&](auto NZ) {
+        constexpr int nz = decltype(NZ)::value;
+        auto go = [&](auto SW) {
+            constexpr bool sw = decltype(SW)::value;
+            {
+                Scope s(c, "k_ref_pair_sums");
+                hipLaunchKernelGGL((plsa::ref::k_ref_pair_sums<nz, sw>), dim3(grid), dim3(256), 0, c->ls, ri, c->val, c->nnz, p_base(c),
+                                   d_sw, kp, n_chunks, n_pad, csum);
+            }
+            {
+                Scope s(c, "k_ref_pair_prefix");
+                hipLaunchKernelGGL(plsa::ref::k_ref_pair_prefix, dim3(kp), dim3(256), 0, c->ls, csum, n_chunks, n_pad);
+            }
+            {
+                Scope s(c, "k_ref_pair_build");
+                hipLaunchKernelGGL((plsa::ref::k_ref_pair_build<nz, sw>), dim3(grid), dim3(256), 0, c->ls, ri, c->val, c->nnz, p_base(c),
+                                   d_sw, kp, n_chunks, n_pad, csum, prs, exps);
+            }
+            {
+                Scope s(c, "k_ref_pair_walk");
+                hipLaunchKernelGGL((plsa::ref::k_ref_pair_walk<nz, sw>), dim3(1), dim3(64), 0, c->ls, ri, c->val, c->nnz, p_base(c), d_sw,
+                                   kp, n_chunks, prs, exps, out, stats);
+            }
+        };
+        if (d_sw) go(std::true_type{}); else go(std::false_type{});
+    });
+    CHK(launch_check(c, "k_ref_pair_walk"));
+    if (!c->ref_stats_pending) {       // (one read-back in flight at a time; a walk whose count is skipped is simply not counted)
+        HIPCHK(c, hipMemcpyAsync(c->h_ref_stats, stats, 16, hipMemcpyDeviceToHost, c->ls));
+        HIPCHK(c, hipEventRecord(c->ev_ref_stats, c->ls));
+        c->ref_stats_pending = true;
+    }
+    return 0;
+}
+
 // plsa.py:172-204 / 277-310 / 795-816 from the materialised P: U[out], (update_v) Vt[out]; swaps the buffers in.
 // The norm_pwz chain (one workgroup, nnz dependent additions per topic) runs on the second stream beside the document
 // and column passes.
@@ -1328,27 +1426,7 @@ int run_ref_m_step(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         c->ls = c->stream2;
-        {
-            Scope s(c, "k_ref_norm_chain");
-            const int kp = c->kp;
-            const int *ri = c->rowidx.as<int>();
-            float *out = c->norm_pwz.as<float>();
-            auto go = [&](auto NZ) {
-                if (c->nnz <= 0) { (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)kp, c->ls); return; }
-                if (d_sw)
-                    hipLaunchKernelGGL((plsa::ref::k_ref_norm_chain<decltype(NZ)::value, true>), dim3(1), dim3(plsa::ref::CHAIN_THREADS), 0,
-                                       c->ls, ri, c->val, c->nnz, p_base(c), d_sw, kp, out);
-                else
-                    hipLaunchKernelGGL((plsa::ref::k_ref_norm_chain<decltype(NZ)::value, false>), dim3(1), dim3(plsa::ref::CHAIN_THREADS), 0,
-                                       c->ls, ri, c->val, c->nnz, p_base(c), d_sw, kp, out);
-            };
-            using std::integral_constant;
-            if (kp <= 64) go(integral_constant<int, 1>{});
-            else if (kp <= 128) go(integral_constant<int, 2>{});
-            else if (kp <= 256) go(integral_constant<int, 4>{});
-            else if (kp <= 512) go(integral_constant<int, 8>{});
-            else go(integral_constant<int, 16>{});
-        }
+        CHK(run_ref_norm_pwz(c, d_sw));
         c->ls = c->stream;
         CHK(launch_check(c, "k_ref_norm_chain"));
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
@@ -1508,6 +1586,8 @@ int plsa_create(int device, plsa_ctx **out) {
     if (const char *s = getenv("PLSA_FORCE_WIDE")) c->force_wide = atoi(s) != 0;
     if (const char *s = getenv("PLSA_MT_CHAIN")) c->mt_chain = atoi(s) != 0;
     if (const char *s = getenv("PLSA_SPECULATE")) c->speculate = atoi(s);
+    if (const char *s = getenv("PLSA_REF_CHAIN"))      // norm_pwz of the reference arithmetic: auto (default) | pairs | serial
+        c->ref_chain_mode = !strcmp(s, "pairs") ? 1 : (!strcmp(s, "serial") ? 2 : 0);
     *out = c;
     return 0;
 }
@@ -1526,7 +1606,7 @@ void plsa_destroy(plsa_ctx *c) {
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->U[2], &c->Vt[0], &c->Vt[1], &c->Vt[2], &c->Vacc,
                      &c->P, &c->sw, &c->sw_res, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
-                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp, &c->ref_terms};
+                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp, &c->ref_terms, &c->ref_csum, &c->ref_pairs, &c->ref_exps, &c->ref_stats};
     if (c->p_borrowed) { c->P.p = nullptr; c->P.cap = 0; }      // lent memory is the lender's to free
     for (DevBuf *b : all) release(*b);
     for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -2577,6 +2657,21 @@ int plsa_allreduce_accumulator(plsa_ctx *c) {
     return 0;
 }
 
+int plsa_reference_chain_info(plsa_ctx *c, int64_t *slow_chunks, int64_t *chunks, int32_t *serial_now) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->ref_stats_pending) {
+        c->ref_stats_pending = false;
+        c->ref_slow_total += c->h_ref_stats[0]; c->ref_chunks_total += c->h_ref_stats[1];
+        if (c->ref_chain_mode == 0 && c->h_ref_stats[1] > 0 && c->h_ref_stats[0] * 4 > c->h_ref_stats[1]) c->ref_pairs_off = true;
+    }
+    if (slow_chunks) *slow_chunks = (int64_t)c->ref_slow_total;
+    if (chunks) *chunks = (int64_t)c->ref_chunks_total;
+    if (serial_now) *serial_now = (c->ref_chain_mode == 2 || (c->ref_chain_mode == 0 && c->ref_pairs_off)) ? 1 : 0;
+    return 0;
+}
+
 int plsa_placement_info(plsa_ctx *c, int32_t *candidates, double *best_gbps, double *worst_gbps) {
     if (candidates) *candidates = c->placement_tried;
     if (best_gbps) *best_gbps = c->placement_gbps[0];
@@ -2601,7 +2696,7 @@ int plsa_release_scratch(plsa_ctx *c) {
     // the next materialising call allocate a private full-size array); a LENT one is freed: the caller ends the loans first
     if (!c->p_borrowed) release(c->P);
     c->p_lent = false;
-    release(c->ref_terms);
+    release(c->ref_terms); release(c->ref_csum); release(c->ref_pairs); release(c->ref_exps);
     release(c->partial); release(c->tmp0); release(c->tmp1); release(c->tmp2); release(c->cubtmp);
     release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly); release(c->mt_seq);
     // member stack + gather buffers of the ensemble exchange (16 runs x 64 topics x 100 k words = 0.4 GB): re-created

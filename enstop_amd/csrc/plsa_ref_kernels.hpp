@@ -371,6 +371,251 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__r
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same chain WITHOUT nnz dependent additions: norm_pwz[z] from per-chunk (parity -> increment) pairs, the technique of
+// k_mt_chunk_pairs / k_mt_marginal_walk (plsa_kernels.hpp; there: float64 sums of 53-bit draws) carried over to float32 sums of
+// arbitrary non-negative float32 addends.
+//
+// While the running sum S stays inside one binade [2^e, 2^(e+1)) it is an integer multiple M of u = 2^(e-23), 2^23 <= M < 2^24, and
+// one rounded addition of t = mt * 2^(Et - 150) (mt the 24-bit significand, Et the biased exponent, 1 for denormals) is
+//     M' = M + q + c,    sh = E - Et,  q = mt >> sh,  r = mt mod 2^sh,  c = [r > 2^(sh-1)] or ([r == 2^(sh-1)] and (M + q) odd)
+// (round to nearest even; sh >= 1: an addend from S's own binade or above pushes S out of it; sh >= 26: t < u / 2 changes
+// nothing): the increment depends on M only through its PARITY.  A chunk of 64 addends therefore maps the parity at its start to
+// a total increment -- a pair (T0, T1) every chunk computes ON ITS OWN (k_ref_pair_build) for the binade the chunk's approximate
+// real prefix sum points at AND for the neighbouring binade when that prefix lies within ~12 % of a binade edge (the float32 chain
+// itself drifts from the real sum by up to a few per cent at BASELINE sizes).  One wave then walks the chunks, lane = topic
+// (k_ref_pair_walk): S's bit pattern takes the pair of the candidate binade that IS S's binade, iff the pair is valid and M + T stays
+// below 2^24 (no crossing inside the chunk: T only grows); otherwise -- the ~25 binade crossings per topic, the first chunk (S = 0), a
+// drift beyond the window, a negative or non-finite addend -- the 64 addends of that chunk are added one by one with real float32
+// additions (all lanes load the rows, only the lanes that need it add).  The checks make the result independent of the guesses: the
+// bits are those of the sequential chain above (tests: every bitwise test of the mode runs through this path, and both paths are
+// compared on tie-heavy dyadic inputs); the guesses only decide how many chunks take the slow way (counted, reported, and a fit
+// whose chains drift too far -- the whole of config 3, where the reference's sum stops growing -- goes back to the serial chain).
+// ------------------------------------------------------------------------------------------------
+constexpr int PAIR_L = 64;            // addends per chunk
+constexpr int PAIR_SC = 8;            // chunks a wave handles back to back (8 consecutive float64 chunk sums per lane: one 64-B line)
+constexpr unsigned PAIR_INVALID = 0xFFFFFFFFu;
+constexpr unsigned short PAIR_NOOP = 0xFFFFu;                     // exps record of a chunk whose addends are all zero
+
+// t of (row, z) exactly as every other kernel of this file forms it
+template <bool HAS_SW>
+__device__ __forceinline__ float pair_addend(const float *__restrict__ P, const float *__restrict__ vals,
+                                             const int *__restrict__ rowidx, const float *__restrict__ sw, i64 row, int kp, int z) {
+    float t = vals[row] * P[row * kp + z];                    // plsa.py:188
+    if (HAS_SW) t = t * sw[rowidx[row]];                      // plsa.py:294
+    return t;
+}
+
+// float64 sum of every chunk's addends per topic: csum[z][c], chunk index fastest (n_pad chunks per topic)
+template <int NZ, bool HAS_SW>
+__global__ __launch_bounds__(256) void k_ref_pair_sums(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
+                                                       const float *__restrict__ P, const float *__restrict__ sw, int kp,
+                                                       i64 n_chunks, i64 n_pad, double *__restrict__ csum) {
+    const int lane = threadIdx.x & 63;
+    const i64 wid = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((i64)gridDim.x * blockDim.x) >> 6;
+    const i64 n_super = (n_chunks + PAIR_SC - 1) / PAIR_SC;
+    for (i64 sc = wid; sc < n_super; sc += nw) {
+        double sum8[PAIR_SC][NZ];
+#pragma unroll
+        for (int c8 = 0; c8 < PAIR_SC; ++c8) {
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) sum8[c8][q] = 0.0;
+            const i64 row0 = (sc * PAIR_SC + c8) * PAIR_L;
+#pragma unroll 8
+            for (int j = 0; j < PAIR_L; ++j) {
+                const i64 row = row0 + j;
+                if (row < nnz) {                                 // (uniform)
+#pragma unroll
+                    for (int q = 0; q < NZ; ++q) {
+                        const int z = lane + 64 * q;
+                        if (z < kp) sum8[c8][q] += (double)pair_addend<HAS_SW>(P, vals, rowidx, sw, row, kp, z);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) {
+            const int z = lane + 64 * q;
+            if (z < kp) {
+#pragma unroll
+                for (int c8 = 0; c8 < PAIR_SC; ++c8) csum[(i64)z * n_pad + sc * PAIR_SC + c8] = sum8[c8][q];
+            }
+        }
+    }
+}
+
+// csum[z][:] -> its exclusive prefix sums, in place; one workgroup per topic (any summation order will do: the walk checks every guess)
+__global__ __launch_bounds__(256) void k_ref_pair_prefix(double *__restrict__ csum, i64 n_chunks, i64 n_pad) {
+    __shared__ double slab_sum[256];
+    double *a = csum + (i64)blockIdx.x * n_pad;
+    const i64 slab = (n_chunks + 255) / 256;
+    const i64 lo = min(n_chunks, (i64)threadIdx.x * slab), hi = min(n_chunks, lo + slab);
+    double s = 0.0;
+    for (i64 i = lo; i < hi; ++i) s += a[i];
+    slab_sum[threadIdx.x] = s;
+    __syncthreads();
+    double run = 0.0;
+    for (int t = 0; t < (int)threadIdx.x; ++t) run += slab_sum[t];
+    for (i64 i = lo; i < hi; ++i) { const double v = a[i]; a[i] = run; run += v; }
+}
+
+// binade candidates of a chunk from its approximate prefix: biased float32 exponents, 0 = none
+__device__ __forceinline__ void pair_candidates(double prefix, int &ea, int &eb) {
+    ea = eb = 0;
+    const float pf = (float)prefix;
+    if (!(pf > 0.0f)) return;
+    const unsigned b = __float_as_uint(pf);
+    const int e = (int)(b >> 23);
+    if (e < 1 || e > 252) return;
+    ea = e;
+    const unsigned frac = b & 0x7FFFFFu;                          // position inside the binade: 0 .. 2^23
+    if (frac < (1u << 20)) eb = e - 1;                            // within 12.5 % above the lower edge: S may still be below it
+    else if (frac > (7u << 20)) eb = e + 1;                       // within 12.5 % below the upper edge: S may already be beyond
+    if (eb < 1 || eb > 252) eb = 0;
+}
+
+// one addend into the four running (candidate, starting parity) totals; returns false if the addend rules a candidate out
+struct PairState {
+    unsigned t0, t1;      // totals for starting parity 0 / 1
+    bool ok;
+};
+__device__ __forceinline__ void pair_step(PairState &st, int e_cand, unsigned tb) {
+    // tb: bit pattern of a non-negative finite addend (checked by the caller)
+    const int et_raw = (int)(tb >> 23);
+    const unsigned mt = et_raw ? ((tb & 0x7FFFFFu) | 0x800000u) : (tb & 0x7FFFFFu);
+    if (mt == 0u) return;                                          // + 0.0
+    const int sh = e_cand - (et_raw ? et_raw : 1);
+    if (sh < 1) { st.ok = false; return; }                         // an addend from S's binade or above: S leaves the binade
+    if (sh > 25) return;                                           // t < u / 2: the rounded sum is S
+    const unsigned q = mt >> sh, r = mt & ((1u << sh) - 1u), half = 1u << (sh - 1);
+    const unsigned up = r > half ? 1u : 0u, tie = r == half ? 1u : 0u;
+    st.t0 += q + (up | (tie & ((st.t0 + q) & 1u)));                // parity of M + q with M even at the chunk's start
+    st.t1 += q + (up | (tie & ((st.t1 + 1u + q) & 1u)));           // ... with M odd
+}
+
+// per (chunk, topic): the two candidate binades and their (T0, T1); pairs[c][z] = {T0_A, T1_A, T0_B, T1_B}, exps[c][z] = E_A | E_B << 8
+template <int NZ, bool HAS_SW>
+__global__ __launch_bounds__(256) void k_ref_pair_build(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
+                                                        const float *__restrict__ P, const float *__restrict__ sw, int kp,
+                                                        i64 n_chunks, i64 n_pad, const double *__restrict__ prefix,
+                                                        uint4 *__restrict__ pairs, unsigned short *__restrict__ exps) {
+    const int lane = threadIdx.x & 63;
+    const i64 wid = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((i64)gridDim.x * blockDim.x) >> 6;
+    const i64 n_super = (n_chunks + PAIR_SC - 1) / PAIR_SC;
+    for (i64 sc = wid; sc < n_super; sc += nw) {
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) {
+            const int z = lane + 64 * q;
+            if (z >= kp) continue;
+            double pre[PAIR_SC];
+#pragma unroll
+            for (int c8 = 0; c8 < PAIR_SC; ++c8) pre[c8] = prefix[(i64)z * n_pad + sc * PAIR_SC + c8];
+            for (int c8 = 0; c8 < PAIR_SC; ++c8) {
+                const i64 c = sc * PAIR_SC + c8;
+                if (c >= n_chunks) break;
+                int ea, eb;
+                pair_candidates(pre[c8], ea, eb);
+                PairState A = {0u, 0u, ea != 0}, B = {0u, 0u, eb != 0};
+                bool all_zero = true;                            // a chunk of + 0.0 addends leaves ANY sum as it is (padding topics,
+                const i64 row0 = c * PAIR_L;                     // topics the E-step threshold emptied, stretches of zero responsibilities)
+#pragma unroll 4
+                for (int j = 0; j < PAIR_L; ++j) {
+                    const i64 row = row0 + j;
+                    if (row >= nnz) break;
+                    const float t = pair_addend<HAS_SW>(P, vals, rowidx, sw, row, kp, z);
+                    const unsigned tb = __float_as_uint(t);
+                    if ((tb >> 31) != 0u ? (tb << 1) != 0u : (tb >> 23) == 0xFFu) { A.ok = B.ok = all_zero = false; break; }   // negative (not -0) / inf / nan
+                    all_zero = all_zero && (tb << 1) == 0u;
+                    if (A.ok) pair_step(A, ea, tb & 0x7FFFFFFFu);
+                    if (B.ok) pair_step(B, eb, tb & 0x7FFFFFFFu);
+                }
+                uint4 o;
+                o.x = A.ok ? A.t0 : PAIR_INVALID; o.y = A.ok ? A.t1 : PAIR_INVALID;
+                o.z = B.ok ? B.t0 : PAIR_INVALID; o.w = B.ok ? B.t1 : PAIR_INVALID;
+                pairs[c * kp + z] = o;
+                exps[c * kp + z] = all_zero ? PAIR_NOOP : (unsigned short)((A.ok ? ea : 0) | ((B.ok ? eb : 0) << 8));
+            }
+        }
+    }
+}
+
+// the walk: ONE wave, lane = topic (z = lane + 64 q).  stats[0] += chunks that took the slow way (per wave, not per lane).
+template <int NZ, bool HAS_SW>
+__global__ __launch_bounds__(64) void k_ref_pair_walk(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
+                                                      const float *__restrict__ P, const float *__restrict__ sw, int kp,
+                                                      i64 n_chunks, const uint4 *__restrict__ pairs,
+                                                      const unsigned short *__restrict__ exps, float *__restrict__ norm_pwz,
+                                                      unsigned long long *__restrict__ stats) {
+    constexpr int AHEAD = 4;                                    // chunk records requested ahead of their use
+    const int lane = threadIdx.x;
+    unsigned sbits[NZ];
+#pragma unroll
+    for (int q = 0; q < NZ; ++q) sbits[q] = 0u;                 // + 0.0
+    uint4 rec[AHEAD][NZ];
+    unsigned short ex[AHEAD][NZ];
+    auto fetch = [&](i64 c, uint4 (&r)[NZ], unsigned short (&e)[NZ]) {
+        const i64 cc = min(c, n_chunks - 1);
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) {
+            const int z = lane + 64 * q;
+            const i64 at = cc * kp + (z < kp ? z : 0);
+            r[q] = pairs[at];
+            e[q] = exps[at];
+        }
+    };
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) fetch(a, rec[a], ex[a]);
+    unsigned long long slow = 0;
+    for (i64 c0 = 0; c0 < n_chunks; c0 += AHEAD) {
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) {
+            const i64 c = c0 + a;
+            if (c < n_chunks) {                                  // (uniform)
+                bool need[NZ];
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < NZ; ++q) {
+                    const unsigned s = sbits[q];
+                    const unsigned es = s >> 23;                 // sign bit included: a negative sum matches no candidate
+                    const unsigned m = (s & 0x7FFFFFu) | 0x800000u;
+                    const unsigned ea = ex[a][q] & 0xFFu, eb = ex[a][q] >> 8;
+                    const bool useA = ea != 0u && es == ea, useB = eb != 0u && es == eb;
+                    const unsigned t0 = useA ? rec[a][q].x : rec[a][q].z, t1 = useA ? rec[a][q].y : rec[a][q].w;
+                    const unsigned t = (m & 1u) ? t1 : t0;
+                    const unsigned mn = m + t;
+                    const bool fast = (useA || useB) && t != PAIR_INVALID && mn < 0x1000000u;
+                    if (fast) sbits[q] = (es << 23) | (mn & 0x7FFFFFu);
+                    need[q] = !fast && ex[a][q] != PAIR_NOOP && (lane + 64 * q) < kp;
+                    any = any || need[q];
+                }
+                if (__any(any)) {                                // the slow way: real float32 additions, addend by addend
+                    ++slow;
+                    const i64 row0 = c * PAIR_L;
+                    const int rows = (int)min((i64)PAIR_L, nnz - row0);
+                    for (int j = 0; j < rows; ++j) {
+#pragma unroll
+                        for (int q = 0; q < NZ; ++q) {
+                            const int z = lane + 64 * q;
+                            if (z < kp) {
+                                const float t = pair_addend<HAS_SW>(P, vals, rowidx, sw, row0 + j, kp, z);
+                                const float sum = __uint_as_float(sbits[q]) + t;          // plsa.py:193
+                                if (need[q]) sbits[q] = __float_as_uint(sum);
+                            }
+                        }
+                    }
+                }
+            }
+            fetch(c0 + a + AHEAD, rec[a], ex[a]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NZ; ++q) {
+        const int z = lane + 64 * q;
+        if (z < kp) norm_pwz[z] = __uint_as_float(sbits[q]);
+    }
+    if (lane == 0) { atomicAdd(stats, slow); atomicAdd(stats + 1, (unsigned long long)n_chunks); }
+}
+
+// ------------------------------------------------------------------------------------------------
 // PLSA_REFERENCE_LL: the log-likelihood as the reference's SOURCE states it, plsa.py:372-384 -- p_w_given_d one float32
 // sum over the topics in order, result one float32 running sum over the non-zeros in order (plsa.py:322).  (What a numba
 // user sees is something else: the compiled prange reduction is vectorised and lands within 1e-7 of the float64 sum at

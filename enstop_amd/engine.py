@@ -437,6 +437,13 @@ class Engine:
         self._ok(self._L.plsa_cluster_representatives(self._h, ptr(T), t, m, lab, ptr(w), n_clusters, out))
         return out
 
+    def reference_chain_info(self):
+        """norm_pwz of the reference arithmetic (plsa_reference_chain_info): chunks of the parity-pair walk that took the slow way,
+        chunks walked, and whether this context is on the serial chain for the current corpus."""
+        a, b, c_ = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        self._ok(self._L.plsa_reference_chain_info(self._h, C.byref(a), C.byref(b), C.byref(c_)))
+        return dict(slow_chunks=a.value, chunks=b.value, serial_chain_now=bool(c_.value))
+
     def placement_info(self):
         n, a, b = C.c_int32(0), C.c_double(0.0), C.c_double(0.0)
         self._ok(self._L.plsa_placement_info(self._h, C.byref(n), C.byref(a), C.byref(b)))

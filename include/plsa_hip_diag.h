@@ -53,6 +53,14 @@ int plsa_comm_last_error(plsa_ctx *ctx, char *buf, int64_t cap);
 int plsa_comm_barrier(plsa_ctx *ctx);
 int plsa_comm_allreduce_f64(plsa_ctx *ctx, double *inout, int64_t count, int32_t op);
 
+/* PLSA_REFERENCE_SUMS: norm_pwz[z] -- the reference's one float32 running sum over all non-zeros, enstop/plsa.py:193 -- is evaluated
+ * from per-chunk (parity -> increment) pairs and a walk that checks every chunk; chunks that fail the check (binade crossings, a
+ * chain that has drifted from the real sums) are added addend by addend.  Reports, over the walks finished so far on this
+ * context: chunks that took the slow way, chunks in all, and whether the context has gone back to the serial chain for the
+ * current corpus (more than a quarter slow; PLSA_REF_CHAIN=pairs / serial pins either).  Same bits whichever way.  Waits for
+ * the context's streams.  Any pointer may be NULL. */
+int plsa_reference_chain_info(plsa_ctx *ctx, int64_t *slow_chunks, int64_t *chunks, int32_t *serial_now);
+
 /* The materialised P array is placed by probing: up to PLSA_PLACEMENT_CANDIDATES (default 4)
  * allocations are streamed through once and the fastest is kept (HBM placement alone moves the
  * E-step by ~15 %).  Reports the last probe: candidates tried and the fill

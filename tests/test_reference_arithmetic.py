@@ -271,3 +271,53 @@ def test_estimator_bits(amd, case):
     same_bits(model.components_, g["components"], case + " components_")
     Xt = sp.csr_matrix((g["t_data"], g["t_indices"], g["t_indptr"]), shape=tuple(int(s) for s in g["t_shape"]))
     same_bits(model.transform(Xt), g["transformed"], case + " transform")
+
+
+@pytest.mark.parametrize("k", [8, 20, 70])
+def test_norm_chain_from_parity_pairs_on_tie_heavy_input(amd, k, monkeypatch):
+    """norm_pwz[z] (plsa.py:193, ONE float32 running sum over all non-zeros) evaluated from per-chunk (parity -> increment) pairs
+    (k_ref_pair_*) against the serial chain (k_ref_norm_chain) and the oracle on input built to hit the hard cases: dyadic
+    responsibilities and small integer counts (addends with few significant bits: exact ties in round-to-nearest-even all along
+    the chain), document weights that are powers of two, stretches of zeros, one huge addend that jumps several binades, and
+    enough non-zeros for ~15 binade crossings per topic.  Same bits three ways; the walk reports how many chunks it had to add
+    addend by addend."""
+    import scipy.sparse as sp
+    from oracle.plsa_oracle import Oracle
+    rs = np.random.RandomState(k)
+    n, m = 4000, 300
+    X = sp.random(n, m, density=0.08, format="csr", random_state=rs, dtype=np.float64)
+    X.data = rs.randint(1, 5, size=X.nnz).astype(np.float64)
+    X = X.astype(np.float32)
+    X.data[X.nnz // 2] = 3.0e6                                   # one addend several binades above the running sums
+    r, c, v = coo_arrays(X)
+    P = (rs.randint(0, 9, size=(X.nnz, k)) / np.float32(16.0)).astype(np.float32)     # 0, 1/16, ..., 1/2: dyadic
+    P[1000:3000] = 0.0                                           # a stretch of + 0.0 addends
+    sw = (2.0 ** rs.randint(-2, 3, size=n)).astype(np.float32)
+    U0 = np.full((n, k), 1.0 / k, np.float32); V0 = np.full((k, m), 1.0 / m, np.float32)
+    o = Oracle(variant="strict")
+    want = {}
+    for weighted in (False, True):
+        Vo, Uo = V0.copy(), U0.copy()
+        nw, nd = np.zeros(k, np.float32), np.zeros(n, np.float32)
+        if weighted:
+            o.plsa_m_step_w_sample_weight(r, c, v, Vo, Uo, P, sw, nw, nd)
+        else:
+            o.plsa_m_step(r, c, v, Vo, Uo, P, nw, nd)
+        want[weighted] = (nw, Vo, Uo)
+    for mode in ("pairs", "serial"):
+        monkeypatch.setenv("PLSA_REF_CHAIN", mode)
+        with amd.Engine() as eng:                                # the knob is read when a context is created
+            eng.upload_csr(X)
+            eng.set_arithmetic("reference")
+            for weighted in (False, True):
+                eng.set_factors(U0, V0)
+                eng.set_p(P)
+                nw, nd = eng.m_step(sw if weighted else None)
+                U, V = eng.get_factors()
+                same_bits(nw, want[weighted][0], "norm_pwz, %s, weighted=%s" % (mode, weighted))
+                same_bits(V, want[weighted][1], "P(w|z), %s" % mode); same_bits(U, want[weighted][2], "P(z|d), %s" % mode)
+            info = eng.reference_chain_info()
+            if mode == "pairs":
+                assert info["chunks"] == 2 * ((X.nnz + 63) // 64) and 0 < info["slow_chunks"] < info["chunks"] // 4, info
+            else:
+                assert info["chunks"] == 0 and info["serial_chain_now"], info

@@ -26,6 +26,6 @@ for cfg_id, rows in ((1, 0), (2, 0), (3, 150_000)):
         eng.fit(None, n_iter=4, **kw)
         rep = eng.timing_report()
         eng.timing(False)
-        print(json.dumps({"config": cfg_id, "rows": n, "nnz": nnz, "k": cfg["k"],
+        print(json.dumps({"config": cfg_id, "norm_chain": eng.reference_chain_info(), "rows": n, "nnz": nnz, "k": cfg["k"],
                           "avg_ms": {k: round(v[1] / v[0], 3) for k, v in sorted(rep.items())},
                           "launches": {k: v[0] for k, v in sorted(rep.items())}}), flush=True)
