@@ -1365,7 +1365,7 @@ int run_ref_norm_pwz(plsa_ctx *c, const float *d_sw) {
     const i64 n_super = (n_chunks + plsa::ref::PAIR_SC - 1) / plsa::ref::PAIR_SC, n_pad = n_super * plsa::ref::PAIR_SC;
     CHK(ensure(c, c->ref_csum, sizeof(double) * (size_t)n_pad * kp));
     CHK(ensure(c, c->ref_pairs, sizeof(uint4) * (size_t)n_chunks * kp));
-    CHK(ensure(c, c->ref_exps, sizeof(unsigned short) * (size_t)n_chunks * kp));
+    CHK(ensure(c, c->ref_exps, sizeof(unsigned) * (size_t)n_chunks * kp));
     CHK(ensure(c, c->ref_stats, 16));
     if (!c->h_ref_stats) {
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_ref_stats), 16, hipHostMallocDefault));
@@ -1374,7 +1374,7 @@ int run_ref_norm_pwz(plsa_ctx *c, const float *d_sw) {
     const int grid = grid_for(c, n_super, 4);
     double *csum = c->ref_csum.as<double>();
     uint4 *prs = c->ref_pairs.as<uint4>();
-    unsigned short *exps = c->ref_exps.as<unsigned short>();
+    unsigned *exps = c->ref_exps.as<unsigned>();
     unsigned long long *stats = c->ref_stats.as<unsigned long long>();
     HIPCHK(c, hipMemsetAsync(stats, 0, 16, c->ls));
     by_nz([&](auto NZ) {
@@ -1397,7 +1397,7 @@ int run_ref_norm_pwz(plsa_ctx *c, const float *d_sw) {
             }
             {
                 Scope s(c, "k_ref_pair_walk");
-                hipLaunchKernelGGL((plsa::ref::k_ref_pair_walk<nz, sw>), dim3(1), dim3(64), 0, c->ls, ri, c->val, c->nnz, p_base(c), d_sw,
+                hipLaunchKernelGGL((plsa::ref::k_ref_pair_walk<sw>), dim3((kp + 63) / 64), dim3(plsa::ref::WALK_THREADS), 0, c->ls, ri, c->val, c->nnz, p_base(c), d_sw,
                                    kp, n_chunks, prs, exps, out, stats);
             }
         };

@@ -379,22 +379,28 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__r
 // one rounded addition of t = mt * 2^(Et - 150) (mt the 24-bit significand, Et the biased exponent, 1 for denormals) is
 //     M' = M + q + c,    sh = E - Et,  q = mt >> sh,  r = mt mod 2^sh,  c = [r > 2^(sh-1)] or ([r == 2^(sh-1)] and (M + q) odd)
 // (round to nearest even; sh >= 1: an addend from S's own binade or above pushes S out of it; sh >= 26: t < u / 2 changes
-// nothing): the increment depends on M only through its PARITY.  A chunk of 64 addends therefore maps the parity at its start to
+// nothing): the increment depends on M only through its PARITY.  A chunk of PAIR_L addends therefore maps the parity at its start to
 // a total increment -- a pair (T0, T1) every chunk computes ON ITS OWN (k_ref_pair_build) for the binade the chunk's approximate
-// real prefix sum points at AND for the neighbouring binade when that prefix lies within ~12 % of a binade edge (the float32 chain
-// itself drifts from the real sum by up to a few per cent at BASELINE sizes).  One wave then walks the chunks, lane = topic
+// real prefix sum points at AND for a neighbouring binade: the one below (the float32 chain drifts down from the real sum: a few
+// per cent at BASELINE sizes, a third at the whole of config 3), the one above when the prefix lies within ~12 % of the upper edge.
+// One wave per 64 topics then walks the chunks, lane = topic
 // (k_ref_pair_walk): S's bit pattern takes the pair of the candidate binade that IS S's binade, iff the pair is valid and M + T stays
 // below 2^24 (no crossing inside the chunk: T only grows); otherwise -- the ~25 binade crossings per topic, the first chunk (S = 0), a
-// drift beyond the window, a negative or non-finite addend -- the 64 addends of that chunk are added one by one with real float32
+// drift beyond the window, a negative or non-finite addend -- the addends of that chunk are added one by one with real float32
 // additions (all lanes load the rows, only the lanes that need it add).  The checks make the result independent of the guesses: the
 // bits are those of the sequential chain above (tests: every bitwise test of the mode runs through this path, and both paths are
 // compared on tie-heavy dyadic inputs); the guesses only decide how many chunks take the slow way (counted, reported, and a fit
 // whose chains drift too far -- the whole of config 3, where the reference's sum stops growing -- goes back to the serial chain).
 // ------------------------------------------------------------------------------------------------
-constexpr int PAIR_L = 64;            // addends per chunk
+#ifndef PLSA_PAIR_L
+#define PLSA_PAIR_L 256
+#endif
+constexpr int PAIR_L = PLSA_PAIR_L;   // addends per chunk (a walk step costs ~115 ns whatever the length, a chunk that goes the slow way ~25 ns
+                                      // per addend: 64 / 128 / 256 addends: the four kernels together 39.9 / 27.5 / 24.5 ms at the config-3 sample)
 constexpr int PAIR_SC = 8;            // chunks a wave handles back to back (8 consecutive float64 chunk sums per lane: one 64-B line)
-constexpr unsigned PAIR_INVALID = 0xFFFFFFFFu;
-constexpr unsigned short PAIR_NOOP = 0xFFFFu;                     // exps record of a chunk whose addends are all zero
+constexpr unsigned PAIR_INVALID = 0x7F000000u;                    // a total no valid chunk reaches (64 * 2^24 = 2^30): M + T >= 2^24 by itself
+constexpr unsigned PAIR_NO_BINADE = 0x7FFFu;                      // exps field "no candidate": equals no biased exponent
+constexpr unsigned PAIR_NOOP = 0x80000000u;                       // exps bit: every addend of the chunk is zero (any sum stays what it is)
 
 // t of (row, z) exactly as every other kernel of this file forms it
 template <bool HAS_SW>
@@ -468,8 +474,10 @@ __device__ __forceinline__ void pair_candidates(double prefix, int &ea, int &eb)
     if (e < 1 || e > 252) return;
     ea = e;
     const unsigned frac = b & 0x7FFFFFu;                          // position inside the binade: 0 .. 2^23
-    if (frac < (1u << 20)) eb = e - 1;                            // within 12.5 % above the lower edge: S may still be below it
-    else if (frac > (7u << 20)) eb = e + 1;                       // within 12.5 % below the upper edge: S may already be beyond
+    // the second candidate: the float32 chain drifts DOWN from the real sum (an addend below half a unit of the sum is lost, and at
+    // the whole of config 3 the reference's norms end ~35 % short of the real ones), so the binade below -- except right under the
+    // upper edge, where ties may have carried S across first
+    eb = frac > (7u << 20) ? e + 1 : e - 1;
     if (eb < 1 || eb > 252) eb = 0;
 }
 
@@ -490,14 +498,15 @@ __device__ __forceinline__ void pair_step(PairState &st, int e_cand, unsigned tb
     const unsigned up = r > half ? 1u : 0u, tie = r == half ? 1u : 0u;
     st.t0 += q + (up | (tie & ((st.t0 + q) & 1u)));                // parity of M + q with M even at the chunk's start
     st.t1 += q + (up | (tie & ((st.t1 + 1u + q) & 1u)));           // ... with M odd
+    if ((st.t0 | st.t1) >> 25) st.ok = false;                      // beyond any binade's 2^23 steps: useless, and it must not wrap
 }
 
-// per (chunk, topic): the two candidate binades and their (T0, T1); pairs[c][z] = {T0_A, T1_A, T0_B, T1_B}, exps[c][z] = E_A | E_B << 8
+// per (chunk, topic): the two candidate binades and their (T0, T1); pairs[c][z] = {T0_A, T1_A, T0_B, T1_B}, exps[c][z] = E_A | E_B << 16 [| PAIR_NOOP]
 template <int NZ, bool HAS_SW>
 __global__ __launch_bounds__(256) void k_ref_pair_build(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
                                                         const float *__restrict__ P, const float *__restrict__ sw, int kp,
                                                         i64 n_chunks, i64 n_pad, const double *__restrict__ prefix,
-                                                        uint4 *__restrict__ pairs, unsigned short *__restrict__ exps) {
+                                                        uint4 *__restrict__ pairs, unsigned *__restrict__ exps) {
     const int lane = threadIdx.x & 63;
     const i64 wid = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((i64)gridDim.x * blockDim.x) >> 6;
     const i64 n_super = (n_chunks + PAIR_SC - 1) / PAIR_SC;
@@ -532,87 +541,179 @@ __global__ __launch_bounds__(256) void k_ref_pair_build(const int *__restrict__ 
                 o.x = A.ok ? A.t0 : PAIR_INVALID; o.y = A.ok ? A.t1 : PAIR_INVALID;
                 o.z = B.ok ? B.t0 : PAIR_INVALID; o.w = B.ok ? B.t1 : PAIR_INVALID;
                 pairs[c * kp + z] = o;
-                exps[c * kp + z] = all_zero ? PAIR_NOOP : (unsigned short)((A.ok ? ea : 0) | ((B.ok ? eb : 0) << 8));
+                exps[c * kp + z] = (A.ok ? (unsigned)ea : PAIR_NO_BINADE) | ((B.ok ? (unsigned)eb : PAIR_NO_BINADE) << 16) | (all_zero ? PAIR_NOOP : 0u);
             }
         }
     }
 }
 
-// the walk: ONE wave, lane = topic (z = lane + 64 q).  stats[0] += chunks that took the slow way (per wave, not per lane).
-template <int NZ, bool HAS_SW>
-__global__ __launch_bounds__(64) void k_ref_pair_walk(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
-                                                      const float *__restrict__ P, const float *__restrict__ sw, int kp,
-                                                      i64 n_chunks, const uint4 *__restrict__ pairs,
-                                                      const unsigned short *__restrict__ exps, float *__restrict__ norm_pwz,
-                                                      unsigned long long *__restrict__ stats) {
-    constexpr int AHEAD = 4;                                    // chunk records requested ahead of their use
-    const int lane = threadIdx.x;
-    unsigned sbits[NZ];
+// The walk: one wave per 64 topics follows the chains, lane = topic, the sum kept as (biased exponent, 24-bit significand); per
+// chunk ~30 integer instructions: pick the candidate whose binade IS the sum's, pick the total for the significand's parity, add,
+// check M + T < 2^24.  Workgroup b owns topics 64 b .. 64 b + 63 (chains of different topics never meet: k = 1000 walks in sixteen
+// workgroups side by side).  Like k_ref_norm_chain a workgroup is one walking wave and its suppliers -- eight waves: six stream the chunk records -- WALK_DEPTH tiles
+// ahead in registers, then a double-buffered LDS tile -- wave 0 walks, the wave that shares wave 0's SIMD only keeps the barriers.
+// A chunk that fails the check for any topic of the group is added addend by addend with real float32 additions (all lanes load the
+// rows, only the lanes that need it add).  stats[0] += chunks that went that way, stats[1] += chunks, per workgroup.
+// History (ms per call at config 1 / config 2 / the config-3 150 k sample, the serial chain: 18.9 / 64.1 / 100.3): the walking wave
+// fetching its own records four chunks ahead 12.2 / 44.6 / 78.1 (264 ns per chunk = HBM latency / 4); records staged through LDS
+// 7.3 / 25.2 / 46.2 (the slow way loaded one row per HBM latency: ~30 us per slow chunk, 0.3-0.5 % of the chunks); its loads 32 rows
+// at a time 4.3 / 15.9 / 30.1 (every step began with s_waitcnt lgkmcnt(0) -- the slow path inside the loop is a join -- and the loop
+// unrolled over the tile carried sixteen copies of it: ~100 KB of code); the form below, see the table in DESIGN.md section 4.
+constexpr int WALK_THREADS = 512;                      // eight waves, two per SIMD: 256 registers each (sixteen waves leave 128, and the
+                                                       // producers' tiles in flight then went through copies that waited for every load)
+constexpr int WALK_PRODUCERS = 384;                    // waves 1-3 and 5-7
+constexpr int WALK_DEPTH = 6;                          // tiles in flight in the producers' registers (even)
+constexpr int WALK_TC = 16;                            // chunks per LDS tile: 16 KB of pairs + 4 KB of exponents, two tiles
+constexpr int WALK_SLOTS = (WALK_TC * 64 + WALK_PRODUCERS - 1) / WALK_PRODUCERS;     // records per producer lane and tile (3)
+
+template <bool HAS_SW>
+__global__ __launch_bounds__(WALK_THREADS) void k_ref_pair_walk(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
+                                                                 const float *__restrict__ P, const float *__restrict__ sw, int kp,
+                                                                 i64 n_chunks, const uint4 *__restrict__ pairs_,
+                                                                 const unsigned *__restrict__ exps, float *__restrict__ norm_pwz,
+                                                                 unsigned long long *__restrict__ stats) {
+    // (a native vector type: arrays of HIP's uint4 struct are copied with memcpy and then stay in scratch memory)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *__restrict__ pairs = reinterpret_cast<const u32x4 *>(pairs_);
+    constexpr int TC = WALK_TC;
+    __shared__ u32x4 trec[2][TC * 64];
+    __shared__ unsigned texp[2][TC * 64];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = (wave & 3) != 0;
+    const int ptid = (wave - 1 - (wave >> 2)) * 64 + (tid & 63);
+    const int z0 = 64 * (int)blockIdx.x, width = min(64, kp - z0);   // this workgroup's topics
+    const i64 n_tiles = (n_chunks + TC - 1) / TC;
+    const i64 n_padded = (n_tiles + WALK_DEPTH - 1) / WALK_DEPTH * WALK_DEPTH;
+    if (wave == 0) {
+        unsigned es = 0u, m = 0u;                                // the sum: + 0.0
+        const bool mine = tid < width;
+        const int z = z0 + (mine ? tid : 0);
+        unsigned long long slow = 0;
+        for (i64 t = 0; t < n_padded; ++t) {
+            __syncthreads();
+            const u32x4 *rp = trec[t & 1] + tid;
+            const unsigned *xp = texp[t & 1] + tid;
+            u32x4 ra, rb, rc;
+            unsigned xa, xb, xc;
+            bool need;
+            auto fast_step = [&](const u32x4 &r, unsigned x) {
+                const bool useA = es == (x & 0xFFFFu), useB = es == ((x >> 16) & 0x7FFFu);
+                const unsigned t0 = useA ? r.x : r.z, t1 = useA ? r.y : r.w;
+                const unsigned mn = m + ((m & 1u) ? t1 : t0);
+                const bool fast = (useA || useB) && mn < 0x1000000u;
+                m = fast ? mn : m;
+                need = !fast && (x >> 31) == 0u && mine;
+                return __any(need) != 0;
+            };
+            auto slow_step = [&](int ch) {                       // rare: binade crossings, the first chunk, a drifted guess
+                ++slow;
+                const i64 row0 = (t * TC + ch) * PAIR_L;         // (a chunk past the end is a no-op record: never here)
+                const int rows = (int)min((i64)PAIR_L, nnz - row0);
+                float sum = __uint_as_float(es ? (es << 23) | (m & 0x7FFFFFu) : m);
+                // the addends 32 rows at a time: all the loads, THEN the products and the dependent additions (left to itself the compiler
+                // forms each product as its load arrives and keeps ~12 loads in flight: 55 ns per addend)
+                constexpr int SB = 32;
+                const float *Pc = P + row0 * kp + z, *xc = vals + row0;
+                const int *dc = rowidx + row0;
+                for (int j0 = 0; j0 < rows; j0 += SB) {
+                    float pv[SB], xv[SB], wv[SB];
 #pragma unroll
-    for (int q = 0; q < NZ; ++q) sbits[q] = 0u;                 // + 0.0
-    uint4 rec[AHEAD][NZ];
-    unsigned short ex[AHEAD][NZ];
-    auto fetch = [&](i64 c, uint4 (&r)[NZ], unsigned short (&e)[NZ]) {
-        const i64 cc = min(c, n_chunks - 1);
+                    for (int u = 0; u < SB; ++u) {               // (32-bit offsets from the chunk's bases: 64-bit row * kp per addend
+                        const int jj = min(j0 + u, rows - 1);    //  made the slow way ~25 scalar instructions per addend)
+                        pv[u] = Pc[jj * kp];
+                        xv[u] = xc[jj];
+                        wv[u] = HAS_SW ? sw[dc[jj]] : 1.0f;
+                    }
+                    asm volatile("" ::: "memory");
 #pragma unroll
-        for (int q = 0; q < NZ; ++q) {
-            const int z = lane + 64 * q;
-            const i64 at = cc * kp + (z < kp ? z : 0);
-            r[q] = pairs[at];
-            e[q] = exps[at];
-        }
-    };
-#pragma unroll
-    for (int a = 0; a < AHEAD; ++a) fetch(a, rec[a], ex[a]);
-    unsigned long long slow = 0;
-    for (i64 c0 = 0; c0 < n_chunks; c0 += AHEAD) {
-#pragma unroll
-        for (int a = 0; a < AHEAD; ++a) {
-            const i64 c = c0 + a;
-            if (c < n_chunks) {                                  // (uniform)
-                bool need[NZ];
-                bool any = false;
-#pragma unroll
-                for (int q = 0; q < NZ; ++q) {
-                    const unsigned s = sbits[q];
-                    const unsigned es = s >> 23;                 // sign bit included: a negative sum matches no candidate
-                    const unsigned m = (s & 0x7FFFFFu) | 0x800000u;
-                    const unsigned ea = ex[a][q] & 0xFFu, eb = ex[a][q] >> 8;
-                    const bool useA = ea != 0u && es == ea, useB = eb != 0u && es == eb;
-                    const unsigned t0 = useA ? rec[a][q].x : rec[a][q].z, t1 = useA ? rec[a][q].y : rec[a][q].w;
-                    const unsigned t = (m & 1u) ? t1 : t0;
-                    const unsigned mn = m + t;
-                    const bool fast = (useA || useB) && t != PAIR_INVALID && mn < 0x1000000u;
-                    if (fast) sbits[q] = (es << 23) | (mn & 0x7FFFFFu);
-                    need[q] = !fast && ex[a][q] != PAIR_NOOP && (lane + 64 * q) < kp;
-                    any = any || need[q];
-                }
-                if (__any(any)) {                                // the slow way: real float32 additions, addend by addend
-                    ++slow;
-                    const i64 row0 = c * PAIR_L;
-                    const int rows = (int)min((i64)PAIR_L, nnz - row0);
-                    for (int j = 0; j < rows; ++j) {
-#pragma unroll
-                        for (int q = 0; q < NZ; ++q) {
-                            const int z = lane + 64 * q;
-                            if (z < kp) {
-                                const float t = pair_addend<HAS_SW>(P, vals, rowidx, sw, row0 + j, kp, z);
-                                const float sum = __uint_as_float(sbits[q]) + t;          // plsa.py:193
-                                if (need[q]) sbits[q] = __float_as_uint(sum);
-                            }
-                        }
+                    for (int u = 0; u < SB; ++u) {
+                        float t = xv[u] * pv[u];                 // plsa.py:188
+                        if (HAS_SW) t = t * wv[u];               // plsa.py:294
+                        if (j0 + u < rows) sum = sum + t;        // plsa.py:193   (uniform branch)
                     }
                 }
+                const unsigned b = __float_as_uint(sum), e = b >> 23;
+                if (need) { es = e; m = e ? (b & 0x7FFFFFu) | 0x800000u : b; }
+            };
+            // Runs of fast chunks in a loop whose body has NO join (the slow way sits outside it), the LDS reads two chunks ahead of
+            // their use in three register sets; the empty asm statements keep the read-ahead ahead (the scheduler sinks a read to its
+            // use otherwise).
+            // (three copies of the step, one per register set: rotating the sets with moves would wait for the read just issued)
+            int ch = 0;
+            auto read = [&](u32x4 &r, unsigned &x, int c) { const int cc = min(c, TC - 1) * 64; r = rp[cc]; x = xp[cc]; };
+            while (ch < TC) {
+                bool hit = false;
+                read(ra, xa, ch);
+                read(rb, xb, ch + 1);
+                for (;;) {
+                    read(rc, xc, ch + 2);
+                    asm volatile("" ::: "memory");
+                    if (fast_step(ra, xa)) { hit = true; break; }
+                    if (++ch >= TC) break;
+                    read(ra, xa, ch + 2);
+                    asm volatile("" ::: "memory");
+                    if (fast_step(rb, xb)) { hit = true; break; }
+                    if (++ch >= TC) break;
+                    read(rb, xb, ch + 2);
+                    asm volatile("" ::: "memory");
+                    if (fast_step(rc, xc)) { hit = true; break; }
+                    if (++ch >= TC) break;
+                }
+                if (!hit) break;
+                slow_step(ch);
+                ++ch;
             }
-            fetch(c0 + a + AHEAD, rec[a], ex[a]);
+        }
+        if (mine) norm_pwz[z] = __uint_as_float(es ? (es << 23) | (m & 0x7FFFFFu) : m);
+        if (tid == 0) { atomicAdd(stats, slow); atomicAdd(stats + 1, (unsigned long long)n_chunks); }
+    } else if (!producer) {
+        for (i64 t = 0; t < n_padded; ++t) __syncthreads();
+    } else {
+        // a producer lane's record slots inside a tile (the same for every tile): validity, chunk, offset from the tile's first record
+        // (records of one chunk: kp apart), LDS position
+        bool sval[WALK_SLOTS];
+        int soff[WALK_SLOTS], spos[WALK_SLOTS], sch[WALK_SLOTS];
+#pragma unroll
+        for (int s = 0; s < WALK_SLOTS; ++s) {
+            const int f = ptid + WALK_PRODUCERS * s;
+            sval[s] = f < TC * width;
+            sch[s] = sval[s] ? f / width : 0;
+            const int col = sval[s] ? f - sch[s] * width : 0;
+            soff[s] = sch[s] * kp + z0 + col;
+            spos[s] = sch[s] * 64 + col;
+        }
+        u32x4 rr[WALK_DEPTH][WALK_SLOTS];
+        unsigned rx[WALK_DEPTH][WALK_SLOTS];
+        auto chunks_of = [&](i64 t) { return (int)max((i64)0, min((i64)TC, n_chunks - t * TC)); };
+        auto fetch = [&](i64 t, u32x4 (&dr)[WALK_SLOTS], unsigned (&dx)[WALK_SLOTS]) {
+            const i64 rec0 = min(t, n_tiles - 1) * TC * kp;      // (uniform; a tile past the end re-reads the last one)
+            const int chunks = t < n_tiles ? chunks_of(t) : 0;
+#pragma unroll
+            for (int s = 0; s < WALK_SLOTS; ++s) {
+                const bool ok = sval[s] && sch[s] < chunks;
+                dr[s] = pairs[rec0 + (ok ? soff[s] : z0)];
+                dx[s] = exps[rec0 + (ok ? soff[s] : z0)];
+            }
+        };
+#pragma unroll
+        for (int dd = 0; dd < WALK_DEPTH; ++dd) fetch(dd, rr[dd], rx[dd]);
+        for (i64 t0 = 0; t0 < n_padded; t0 += WALK_DEPTH) {
+#pragma unroll
+            for (int dd = 0; dd < WALK_DEPTH; ++dd) {
+                const i64 t = t0 + dd;
+                const int chunks = chunks_of(t);
+#pragma unroll
+                for (int s = 0; s < WALK_SLOTS; ++s)
+                    if (sval[s]) {
+                        trec[dd & 1][spos[s]] = rr[dd][s];
+                        texp[dd & 1][spos[s]] = sch[s] < chunks ? rx[dd][s] : (PAIR_NOOP | PAIR_NO_BINADE | PAIR_NO_BINADE << 16);   // past the end: no-ops
+                    }
+                __syncthreads();
+                fetch(t + WALK_DEPTH, rr[dd], rx[dd]);
+            }
         }
     }
-#pragma unroll
-    for (int q = 0; q < NZ; ++q) {
-        const int z = lane + 64 * q;
-        if (z < kp) norm_pwz[z] = __uint_as_float(sbits[q]);
-    }
-    if (lane == 0) { atomicAdd(stats, slow); atomicAdd(stats + 1, (unsigned long long)n_chunks); }
 }
 
 // ------------------------------------------------------------------------------------------------
