@@ -323,3 +323,40 @@ def test_norm_chain_from_parity_pairs_on_tie_heavy_input(amd, k, monkeypatch):
                 assert info["chunks"] == 2 * groups * ((X.nnz + 255) // 256) and 0 < info["slow_chunks"] < info["chunks"] // 2, info
             else:
                 assert info["chunks"] == 0 and info["serial_chain_now"], info
+
+
+def test_norm_chain_pairs_with_negative_and_non_finite_addends(amd, monkeypatch):
+    """What the pair path must hand to plain additions: NEGATIVE addends (sample weights are any float32 to the reference,
+    plsa.py:294: the running sum goes down, through zero, below it), an infinite one and a NaN.  With negative weights: pairs =
+    serial = oracle bit for bit; with the non-finite ones pairs = serial (NaN == NaN: the payload of a NaN the host's adder
+    makes is not the GPU's)."""
+    import scipy.sparse as sp
+    from oracle.plsa_oracle import Oracle
+    rs = np.random.RandomState(5)
+    n, m, k = 3000, 200, 12
+    X = sp.random(n, m, density=0.1, format="csr", random_state=rs, dtype=np.float64)
+    X.data = rs.randint(1, 4, size=X.nnz).astype(np.float64)
+    X = X.astype(np.float32)
+    r, c, v = coo_arrays(X)
+    P = rs.rand(X.nnz, k).astype(np.float32)
+    U0 = np.full((n, k), 1.0 / k, np.float32); V0 = np.full((k, m), 1.0 / m, np.float32)
+    sw_neg = rs.randn(n).astype(np.float32)                       # about half of the documents weigh negative
+    sw_neg[n // 2:] *= 3.0                                         # ... and the second half pulls the sums back through zero
+    sw_bad = np.ones(n, np.float32); sw_bad[n // 3] = np.inf; sw_bad[2 * n // 3] = np.nan
+    nw_o, nd_o = np.zeros(k, np.float32), np.zeros(n, np.float32)
+    Vo, Uo = V0.copy(), U0.copy()
+    Oracle(variant="strict").plsa_m_step_w_sample_weight(r, c, v, Vo, Uo, P, sw_neg, nw_o, nd_o)
+    got = {}
+    for mode in ("pairs", "serial"):
+        monkeypatch.setenv("PLSA_REF_CHAIN", mode)
+        with amd.Engine() as eng:
+            eng.upload_csr(X)
+            eng.set_arithmetic("reference")
+            for name, sw in (("negative", sw_neg), ("non-finite", sw_bad)):
+                eng.set_factors(U0, V0)
+                eng.set_p(P)
+                got[mode, name] = eng.m_step(sw)[0].copy()
+    same_bits(got["pairs", "negative"], nw_o, "norm_pwz, negative weights, pairs against the oracle")
+    same_bits(got["serial", "negative"], nw_o, "norm_pwz, negative weights, serial against the oracle")
+    assert np.array_equal(got["pairs", "non-finite"], got["serial", "non-finite"], equal_nan=True)
+    assert np.isnan(got["pairs", "non-finite"]).all()
