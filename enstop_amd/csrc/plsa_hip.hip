@@ -144,7 +144,7 @@ struct plsa_ctx {
     // quarter of the chunks of an iteration took the walk's slow way -- chains that drift too far from the real sums)
     int ref_chain_mode = 0;        // 0 auto, 1 always pairs, 2 always the serial chain
     bool ref_pairs_off = false;    // auto mode: the current corpus went back to the serial chain
-    DevBuf ref_csum, ref_pairs, ref_exps, ref_stats;
+    DevBuf ref_csum, ref_pairs, ref_exps, ref_stats, ref_ll_neg;
     unsigned long long *h_ref_stats = nullptr;   // pinned [2]: chunks that took the slow way / chunks, of the last finished walk
     hipEvent_t ev_ref_stats = nullptr;
     bool ref_stats_pending = false;
@@ -867,6 +867,7 @@ int need_factors(plsa_ctx *c) {
 // ---------------------------------------------------------------------------------------------
 int run_ref_e_step(plsa_ctx *c, float thresh);
 int run_ref_norm_pwz(plsa_ctx *c, const float *d_sw);
+bool ref_pairs_now(const plsa_ctx *c);
 int run_ref_m_step(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_pdz);
 int run_ref_loglik(plsa_ctx *c, const float *d_sw, double *out);
 
@@ -1328,6 +1329,68 @@ int run_ref_e_step(plsa_ctx *c, float thresh) {
 
 // norm_pwz[z] = the reference's ONE float32 running sum over all non-zeros (plsa.py:193) on c->ls: from per-chunk parity pairs and a
 // walk (k_ref_pair_*), or by the serial chain (k_ref_norm_chain); same bits either way.
+// One chain of float32 additions over the non-zeros in order, per "topic" z < kp, WITHOUT the chain (plsa_ref_kernels.hpp: chunk
+// sums -> prefix -> (parity -> increment) pairs -> one checking walk per 64 topics), on c->ls.  kind / P / kp: PAIR_PLAIN or
+// PAIR_WEIGHTED over P(z|w,d) (norm_pwz, plsa.py:193), PAIR_NEG_TERMS over the likelihood terms with kp = 1 (plsa.py:322).
+int run_ref_pair_chain(plsa_ctx *c, int kind, const float *P, int kp, const float *d_sw, float *out, unsigned long long *stats) {
+    const int *ri = c->rowidx.as<int>();
+    const bool ll = kind == plsa::ref::PAIR_NEG_TERMS;              // (timing names: the likelihood's launches apart from norm_pwz's)
+    const i64 n_chunks = (c->nnz + plsa::ref::PAIR_L - 1) / plsa::ref::PAIR_L;
+    const i64 n_super = (n_chunks + plsa::ref::PAIR_SC - 1) / plsa::ref::PAIR_SC, n_pad = n_super * plsa::ref::PAIR_SC;
+    CHK(ensure(c, c->ref_csum, sizeof(double) * (size_t)n_pad * kp));
+    CHK(ensure(c, c->ref_pairs, sizeof(uint4) * (size_t)n_chunks * kp));
+    CHK(ensure(c, c->ref_exps, sizeof(unsigned) * (size_t)n_chunks * kp));
+    const int grid = grid_for(c, n_super, 4);
+    double *csum = c->ref_csum.as<double>();
+    uint4 *prs = c->ref_pairs.as<uint4>();
+    unsigned *exps = c->ref_exps.as<unsigned>();
+    auto by_nz = [&](auto &&go) {
+        using std::integral_constant;
+        if (kp <= 64) go(integral_constant<int, 1>{});
+        else if (kp <= 128) go(integral_constant<int, 2>{});
+        else if (kp <= 256) go(integral_constant<int, 4>{});
+        else if (kp <= 512) go(integral_constant<int, 8>{});
+        else go(integral_constant<int, 16>{});
+    };
+    by_nz([&](auto NZ) {
+        constexpr int nz = decltype(NZ)::value;
+        auto go = [&](auto KIND) {
+            constexpr int kd = decltype(KIND)::value;
+            {
+                Scope s(c, ll ? "k_ref_ll_pair_sums" : "k_ref_pair_sums");
+                hipLaunchKernelGGL((plsa::ref::k_ref_pair_sums<nz, kd>), dim3(grid), dim3(256), 0, c->ls, ri, c->val, c->nnz, P,
+                                   d_sw, kp, n_chunks, n_pad, csum);
+            }
+            {
+                Scope s(c, ll ? "k_ref_ll_pair_prefix" : "k_ref_pair_prefix");
+                hipLaunchKernelGGL(plsa::ref::k_ref_pair_prefix, dim3(kp), dim3(256), 0, c->ls, csum, n_chunks, n_pad);
+            }
+            {
+                Scope s(c, ll ? "k_ref_ll_pair_build" : "k_ref_pair_build");
+                hipLaunchKernelGGL((plsa::ref::k_ref_pair_build<nz, kd>), dim3(grid), dim3(256), 0, c->ls, ri, c->val, c->nnz, P,
+                                   d_sw, kp, n_chunks, n_pad, csum, prs, exps);
+            }
+            {
+                Scope s(c, ll ? "k_ref_ll_pair_walk" : "k_ref_pair_walk");
+                hipLaunchKernelGGL((plsa::ref::k_ref_pair_walk<kd>), dim3((kp + 63) / 64), dim3(plsa::ref::WALK_THREADS), 0, c->ls, ri,
+                                   c->val, c->nnz, P, d_sw, kp, n_chunks, prs, exps, out, stats);
+            }
+        };
+        using std::integral_constant;
+        if (kind == plsa::ref::PAIR_NEG_TERMS) {
+            if constexpr (nz == 1) go(integral_constant<int, plsa::ref::PAIR_NEG_TERMS>{});      // (kp = 1)
+        } else if (kind == plsa::ref::PAIR_WEIGHTED) go(integral_constant<int, plsa::ref::PAIR_WEIGHTED>{});
+        else go(integral_constant<int, plsa::ref::PAIR_PLAIN>{});
+    });
+    return launch_check(c, "k_ref_pair_walk");
+}
+
+// does this context evaluate its long chains from parity pairs right now? (PLSA_REF_CHAIN; auto: from 4096 non-zeros, until a
+// finished walk reported more than a quarter of its chunks on the slow way)
+bool ref_pairs_now(const plsa_ctx *c) {
+    return c->ref_chain_mode == 1 || (c->ref_chain_mode == 0 && !c->ref_pairs_off && c->nnz >= 4096);
+}
+
 int run_ref_norm_pwz(plsa_ctx *c, const float *d_sw) {
     const int kp = c->kp;
     const int *ri = c->rowidx.as<int>();
@@ -1340,7 +1403,7 @@ int run_ref_norm_pwz(plsa_ctx *c, const float *d_sw) {
         c->ref_slow_total += slow; c->ref_chunks_total += chunks;
         if (c->ref_chain_mode == 0 && chunks > 0 && slow * 4 > chunks) c->ref_pairs_off = true;
     }
-    const bool pairs = c->ref_chain_mode == 1 || (c->ref_chain_mode == 0 && !c->ref_pairs_off && c->nnz >= 4096);
+    const bool pairs = ref_pairs_now(c);
     auto by_nz = [&](auto &&go) {
         using std::integral_constant;
         if (kp <= 64) go(integral_constant<int, 1>{});
@@ -1361,48 +1424,14 @@ int run_ref_norm_pwz(plsa_ctx *c, const float *d_sw) {
         });
         return launch_check(c, "k_ref_norm_chain");
     }
-    const i64 n_chunks = (c->nnz + plsa::ref::PAIR_L - 1) / plsa::ref::PAIR_L;
-    const i64 n_super = (n_chunks + plsa::ref::PAIR_SC - 1) / plsa::ref::PAIR_SC, n_pad = n_super * plsa::ref::PAIR_SC;
-    CHK(ensure(c, c->ref_csum, sizeof(double) * (size_t)n_pad * kp));
-    CHK(ensure(c, c->ref_pairs, sizeof(uint4) * (size_t)n_chunks * kp));
-    CHK(ensure(c, c->ref_exps, sizeof(unsigned) * (size_t)n_chunks * kp));
-    CHK(ensure(c, c->ref_stats, 16));
+    CHK(ensure(c, c->ref_stats, 32));
     if (!c->h_ref_stats) {
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_ref_stats), 16, hipHostMallocDefault));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_ref_stats, hipEventDisableTiming));
     }
-    const int grid = grid_for(c, n_super, 4);
-    double *csum = c->ref_csum.as<double>();
-    uint4 *prs = c->ref_pairs.as<uint4>();
-    unsigned *exps = c->ref_exps.as<unsigned>();
     unsigned long long *stats = c->ref_stats.as<unsigned long long>();
     HIPCHK(c, hipMemsetAsync(stats, 0, 16, c->ls));
-    by_nz([&](auto NZ) {
-        constexpr int nz = decltype(NZ)::value;
-        auto go = [&](auto SW) {
-            constexpr bool sw = decltype(SW)::value;
-            {
-                Scope s(c, "k_ref_pair_sums");
-                hipLaunchKernelGGL((plsa::ref::k_ref_pair_sums<nz, sw>), dim3(grid), dim3(256), 0, c->ls, ri, c->val, c->nnz, p_base(c),
-                                   d_sw, kp, n_chunks, n_pad, csum);
-            }
-            {
-                Scope s(c, "k_ref_pair_prefix");
-                hipLaunchKernelGGL(plsa::ref::k_ref_pair_prefix, dim3(kp), dim3(256), 0, c->ls, csum, n_chunks, n_pad);
-            }
-            {
-                Scope s(c, "k_ref_pair_build");
-                hipLaunchKernelGGL((plsa::ref::k_ref_pair_build<nz, sw>), dim3(grid), dim3(256), 0, c->ls, ri, c->val, c->nnz, p_base(c),
-                                   d_sw, kp, n_chunks, n_pad, csum, prs, exps);
-            }
-            {
-                Scope s(c, "k_ref_pair_walk");
-                hipLaunchKernelGGL((plsa::ref::k_ref_pair_walk<sw>), dim3((kp + 63) / 64), dim3(plsa::ref::WALK_THREADS), 0, c->ls, ri, c->val, c->nnz, p_base(c), d_sw,
-                                   kp, n_chunks, prs, exps, out, stats);
-            }
-        };
-        if (d_sw) go(std::true_type{}); else go(std::false_type{});
-    });
+    CHK(run_ref_pair_chain(c, d_sw ? plsa::ref::PAIR_WEIGHTED : plsa::ref::PAIR_PLAIN, p_base(c), kp, d_sw, out, stats));
     CHK(launch_check(c, "k_ref_pair_walk"));
     if (!c->ref_stats_pending) {       // (one read-back in flight at a time; a walk whose count is skipped is simply not counted)
         HIPCHK(c, hipMemcpyAsync(c->h_ref_stats, stats, 16, hipMemcpyDeviceToHost, c->ls));
@@ -1472,7 +1501,14 @@ int run_ref_loglik(plsa_ctx *c, const float *d_sw, double *out) {
                            c->rowidx.as<int>(), c->col, c->val, c->nnz, c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),
                            d_sw, c->kp, c->ref_terms.as<float>());
     }
-    {
+    if (ref_pairs_now(c)) {
+        // the chain of the NEGATED terms from parity pairs (one "topic"); its slow-chunk counts go to their own slots, unread
+        CHK(ensure(c, c->ref_stats, 32));
+        CHK(ensure(c, c->ref_ll_neg, sizeof(float)));
+        unsigned long long *stats = c->ref_stats.as<unsigned long long>();
+        CHK(run_ref_pair_chain(c, plsa::ref::PAIR_NEG_TERMS, c->ref_terms.as<float>(), 1, nullptr, c->ref_ll_neg.as<float>(), stats + 2));
+        hipLaunchKernelGGL(plsa::ref::k_ref_ll_from_walk, dim3(1), dim3(1), 0, c->stream, c->ref_ll_neg.as<float>(), c->ll_out.as<double>());
+    } else {
         Scope s(c, "k_ref_ll_chain");
         hipLaunchKernelGGL(plsa::ref::k_ref_ll_chain, dim3(1), dim3(64), 0, c->stream, c->ref_terms.as<float>(), c->nnz,
                            c->ll_out.as<double>());
@@ -1606,7 +1642,7 @@ void plsa_destroy(plsa_ctx *c) {
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->U[2], &c->Vt[0], &c->Vt[1], &c->Vt[2], &c->Vacc,
                      &c->P, &c->sw, &c->sw_res, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
-                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp, &c->ref_terms, &c->ref_csum, &c->ref_pairs, &c->ref_exps, &c->ref_stats};
+                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp, &c->ref_terms, &c->ref_csum, &c->ref_pairs, &c->ref_exps, &c->ref_stats, &c->ref_ll_neg};
     if (c->p_borrowed) { c->P.p = nullptr; c->P.cap = 0; }      // lent memory is the lender's to free
     for (DevBuf *b : all) release(*b);
     for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -2696,7 +2732,7 @@ int plsa_release_scratch(plsa_ctx *c) {
     // the next materialising call allocate a private full-size array); a LENT one is freed: the caller ends the loans first
     if (!c->p_borrowed) release(c->P);
     c->p_lent = false;
-    release(c->ref_terms); release(c->ref_csum); release(c->ref_pairs); release(c->ref_exps);
+    release(c->ref_terms); release(c->ref_csum); release(c->ref_pairs); release(c->ref_exps); release(c->ref_ll_neg);
     release(c->partial); release(c->tmp0); release(c->tmp1); release(c->tmp2); release(c->cubtmp);
     release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly); release(c->mt_seq);
     // member stack + gather buffers of the ensemble exchange (16 runs x 64 topics x 100 k words = 0.4 GB): re-created

@@ -402,17 +402,23 @@ constexpr unsigned PAIR_INVALID = 0x7F000000u;                    // a total no 
 constexpr unsigned PAIR_NO_BINADE = 0x7FFFu;                      // exps field "no candidate": equals no biased exponent
 constexpr unsigned PAIR_NOOP = 0x80000000u;                       // exps bit: every addend of the chunk is zero (any sum stays what it is)
 
-// t of (row, z) exactly as every other kernel of this file forms it
-template <bool HAS_SW>
+// The addend of (row, z).  KIND 0 / 1: t exactly as every other kernel of this file forms it, without / with sample weights.
+// KIND 2 (the sequential likelihood, plsa.py:322 / :384: ONE chain, kp = 1, P = the terms k_ref_ll_terms wrote): MINUS the term --
+// the terms are x * log(p) <= 0 wherever p <= 1, the pairs want non-negative addends, and rounding to nearest even is symmetric:
+// -(a + b) == (-a) + (-b) bit for bit, so the chain of the negated terms is the negated chain (a positive term -- p > 1, which the
+// reference's unnormalised topics do produce -- is a negative addend here: that chunk goes the slow way).
+constexpr int PAIR_PLAIN = 0, PAIR_WEIGHTED = 1, PAIR_NEG_TERMS = 2;
+template <int KIND>
 __device__ __forceinline__ float pair_addend(const float *__restrict__ P, const float *__restrict__ vals,
                                              const int *__restrict__ rowidx, const float *__restrict__ sw, i64 row, int kp, int z) {
+    if (KIND == PAIR_NEG_TERMS) return -P[row];
     float t = vals[row] * P[row * kp + z];                    // plsa.py:188
-    if (HAS_SW) t = t * sw[rowidx[row]];                      // plsa.py:294
+    if (KIND == PAIR_WEIGHTED) t = t * sw[rowidx[row]];       // plsa.py:294
     return t;
 }
 
 // float64 sum of every chunk's addends per topic: csum[z][c], chunk index fastest (n_pad chunks per topic)
-template <int NZ, bool HAS_SW>
+template <int NZ, int KIND>
 __global__ __launch_bounds__(256) void k_ref_pair_sums(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
                                                        const float *__restrict__ P, const float *__restrict__ sw, int kp,
                                                        i64 n_chunks, i64 n_pad, double *__restrict__ csum) {
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(256) void k_ref_pair_sums(const int *__restrict__ r
 #pragma unroll
                     for (int q = 0; q < NZ; ++q) {
                         const int z = lane + 64 * q;
-                        if (z < kp) sum8[c8][q] += (double)pair_addend<HAS_SW>(P, vals, rowidx, sw, row, kp, z);
+                        if (z < kp) sum8[c8][q] += (double)pair_addend<KIND>(P, vals, rowidx, sw, row, kp, z);
                     }
                 }
             }
@@ -502,7 +508,7 @@ __device__ __forceinline__ void pair_step(PairState &st, int e_cand, unsigned tb
 }
 
 // per (chunk, topic): the two candidate binades and their (T0, T1); pairs[c][z] = {T0_A, T1_A, T0_B, T1_B}, exps[c][z] = E_A | E_B << 16 [| PAIR_NOOP]
-template <int NZ, bool HAS_SW>
+template <int NZ, int KIND>
 __global__ __launch_bounds__(256) void k_ref_pair_build(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
                                                         const float *__restrict__ P, const float *__restrict__ sw, int kp,
                                                         i64 n_chunks, i64 n_pad, const double *__restrict__ prefix,
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(256) void k_ref_pair_build(const int *__restrict__ 
                 for (int j = 0; j < PAIR_L; ++j) {
                     const i64 row = row0 + j;
                     if (row >= nnz) break;
-                    const float t = pair_addend<HAS_SW>(P, vals, rowidx, sw, row, kp, z);
+                    const float t = pair_addend<KIND>(P, vals, rowidx, sw, row, kp, z);
                     const unsigned tb = __float_as_uint(t);
                     if ((tb >> 31) != 0u ? (tb << 1) != 0u : (tb >> 23) == 0xFFu) { A.ok = B.ok = all_zero = false; break; }   // negative (not -0) / inf / nan
                     all_zero = all_zero && (tb << 1) == 0u;
@@ -566,7 +572,7 @@ constexpr int WALK_DEPTH = 6;                          // tiles in flight in the
 constexpr int WALK_TC = 16;                            // chunks per LDS tile: 16 KB of pairs + 4 KB of exponents, two tiles
 constexpr int WALK_SLOTS = (WALK_TC * 64 + WALK_PRODUCERS - 1) / WALK_PRODUCERS;     // records per producer lane and tile (3)
 
-template <bool HAS_SW>
+template <int KIND>
 __global__ __launch_bounds__(WALK_THREADS) void k_ref_pair_walk(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
                                                                  const float *__restrict__ P, const float *__restrict__ sw, int kp,
                                                                  i64 n_chunks, const uint4 *__restrict__ pairs_,
@@ -622,14 +628,14 @@ __global__ __launch_bounds__(WALK_THREADS) void k_ref_pair_walk(const int *__res
                     for (int u = 0; u < SB; ++u) {               // (32-bit offsets from the chunk's bases: 64-bit row * kp per addend
                         const int jj = min(j0 + u, rows - 1);    //  made the slow way ~25 scalar instructions per addend)
                         pv[u] = Pc[jj * kp];
-                        xv[u] = xc[jj];
-                        wv[u] = HAS_SW ? sw[dc[jj]] : 1.0f;
+                        xv[u] = KIND != PAIR_NEG_TERMS ? xc[jj] : 1.0f;
+                        wv[u] = KIND == PAIR_WEIGHTED ? sw[dc[jj]] : 1.0f;
                     }
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int u = 0; u < SB; ++u) {
-                        float t = xv[u] * pv[u];                 // plsa.py:188
-                        if (HAS_SW) t = t * wv[u];               // plsa.py:294
+                        float t = KIND != PAIR_NEG_TERMS ? xv[u] * pv[u] : -pv[u];     // plsa.py:188 (: 322)
+                        if (KIND == PAIR_WEIGHTED) t = t * wv[u];                      // plsa.py:294
                         if (j0 + u < rows) sum = sum + t;        // plsa.py:193   (uniform branch)
                     }
                 }
@@ -716,6 +722,12 @@ __global__ __launch_bounds__(WALK_THREADS) void k_ref_pair_walk(const int *__res
     }
 }
 
+// the walk's sum of the negated terms -> the likelihood (a serial chain starting from + 0.0 never ends on - 0.0)
+__global__ void k_ref_ll_from_walk(const float *__restrict__ neg_sum, double *__restrict__ out) {
+    const float s = neg_sum[0];
+    out[0] = s == 0.0f ? 0.0 : (double)(-s);
+}
+
 // ------------------------------------------------------------------------------------------------
 // PLSA_REFERENCE_LL: the log-likelihood as the reference's SOURCE states it, plsa.py:372-384 -- p_w_given_d one float32
 // sum over the topics in order, result one float32 running sum over the non-zeros in order (plsa.py:322).  (What a numba
@@ -723,6 +735,9 @@ __global__ __launch_bounds__(WALK_THREADS) void k_ref_pair_walk(const int *__res
 // config 1, where this chain is 3.4e-3 away -- DESIGN.md section 2.)  The logarithm: float64 log of the float32 dot,
 // rounded to float32 -- within an ulp of any libm's logf (NumPy's, glibc's and numba's differ from each other in the
 // last place as well).
+// The running sum itself: k_ref_ll_chain below (serial, 3.7 ns per term), or -- from 4096 non-zeros -- the pair kernels above
+// over the negated terms (PAIR_NEG_TERMS; 11 / 37 / 56 / 377 ms -> 3.5 / 7.2 / 10.8 / 70 ms per evaluation at config 1 / config 2 /
+// the config-3 150 k sample / config 3 whole; test_sequential_likelihood_from_parity_pairs: the same float32 either way).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ref_ll_terms(const int *__restrict__ rowidx, const int *__restrict__ colidx,
                                                       const float *__restrict__ vals, i64 nnz,

@@ -360,3 +360,39 @@ def test_norm_chain_pairs_with_negative_and_non_finite_addends(amd, monkeypatch)
     same_bits(got["serial", "negative"], nw_o, "norm_pwz, negative weights, serial against the oracle")
     assert np.array_equal(got["pairs", "non-finite"], got["serial", "non-finite"], equal_nan=True)
     assert np.isnan(got["pairs", "non-finite"]).all()
+
+
+def test_sequential_likelihood_from_parity_pairs(amd, monkeypatch):
+    """plsa.py:322 / :384, ONE float32 running sum of x * log p over the non-zeros, evaluated as the chain of the NEGATED terms from
+    parity pairs against the serial chain (k_ref_ll_chain) on the same terms: the same float32, bit for bit -- with normalised
+    factors (every term <= 0), with topics that sum to more than one (p > 1: positive terms, chunks that must go the slow way), with
+    negative sample weights (terms of both signs) and with a likelihood that is exactly zero."""
+    import struct
+    import scipy.sparse as sp
+    rs = np.random.RandomState(11)
+    n, m, k = 5000, 400, 16
+    X = sp.random(n, m, density=0.06, format="csr", random_state=rs, dtype=np.float64)
+    X.data = rs.randint(1, 6, size=X.nnz).astype(np.float64)
+    X = X.astype(np.float32)
+    U = rs.rand(n, k); U /= U.sum(1, keepdims=True)
+    V = rs.rand(k, m); V /= V.sum(1, keepdims=True)
+    U = U.astype(np.float32); V = V.astype(np.float32)
+    V_big = (V * np.float32(m * 0.9)).astype(np.float32)           # p(w|d) ~ 0.9 on average: about half of the terms positive
+    sw_neg = rs.randn(n).astype(np.float32)
+    X1 = sp.csr_matrix(np.ones((4200, 1), np.float32))              # one word: p = 1, every term + 0.0
+    cases = [("normalised", X, U, V, None), ("weighted", X, U, V, (0.5 + rs.rand(n)).astype(np.float32)),
+             ("p > 1", X, U, V_big, None), ("negative weights", X, U, V, sw_neg),
+             ("all zero", X1, np.ones((4200, 1), np.float32), np.ones((1, 1), np.float32), None)]
+    got = {}
+    for mode in ("pairs", "serial"):
+        monkeypatch.setenv("PLSA_REF_CHAIN", mode)
+        for name, Xc, Uc, Vc, sw in cases:
+            with amd.Engine() as eng:
+                eng.upload_csr(Xc)
+                eng.set_arithmetic("reference_source")
+                eng.set_factors(Uc, Vc)
+                got[mode, name] = np.float32(eng.log_likelihood(sw))
+    for name, *_ in cases:
+        a, b = got["pairs", name], got["serial", name]
+        assert struct.pack("f", a) == struct.pack("f", b), (name, a, b)
+    assert got["pairs", "normalised"] < 0 and struct.pack("f", got["pairs", "all zero"]) == struct.pack("f", np.float32(0.0))
