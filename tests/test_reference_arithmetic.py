@@ -396,3 +396,34 @@ def test_sequential_likelihood_from_parity_pairs(amd, monkeypatch):
         a, b = got["pairs", name], got["serial", name]
         assert struct.pack("f", a) == struct.pack("f", b), (name, a, b)
     assert got["pairs", "normalised"] < 0 and struct.pack("f", got["pairs", "all zero"]) == struct.pack("f", np.float32(0.0))
+
+
+def test_norm_chain_goes_back_to_the_serial_chain_when_the_walk_keeps_failing(amd, monkeypatch):
+    """PLSA_REF_CHAIN unset (auto): a corpus of ~20 chunks whose 64 topics cross a binade in almost every chunk -- the first walk
+    reports most of its chunks on the slow way, the context then uses the serial chain; the bits are the oracle's every time."""
+    import scipy.sparse as sp
+    from oracle.plsa_oracle import Oracle
+    monkeypatch.delenv("PLSA_REF_CHAIN", raising=False)
+    rs = np.random.RandomState(3)
+    n, m, k = 400, 120, 64
+    X = sp.random(n, m, density=0.11, format="csr", random_state=rs, dtype=np.float64)
+    X.data = rs.randint(1, 4, size=X.nnz).astype(np.float64)
+    X = X.astype(np.float32)
+    assert X.nnz >= 4096
+    r, c, v = coo_arrays(X)
+    P = rs.rand(X.nnz, k).astype(np.float32); P /= P.sum(1, keepdims=True)
+    U0 = np.full((n, k), 1.0 / k, np.float32); V0 = np.full((k, m), 1.0 / m, np.float32)
+    nw_o, nd_o = np.zeros(k, np.float32), np.zeros(n, np.float32)
+    Vo, Uo = V0.copy(), U0.copy()
+    Oracle(variant="strict").plsa_m_step(r, c, v, Vo, Uo, P, nw_o, nd_o)
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        eng.set_arithmetic("reference")
+        for _ in range(4):
+            eng.set_factors(U0, V0)
+            eng.set_p(P)
+            nw, _ = eng.m_step(None)
+            eng.synchronize()
+            same_bits(nw, nw_o, "norm_pwz")
+        info = eng.reference_chain_info()
+        assert info["serial_chain_now"] and 4 * info["slow_chunks"] > info["chunks"] > 0, info
