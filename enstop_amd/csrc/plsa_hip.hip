@@ -144,7 +144,9 @@ struct plsa_ctx {
     // quarter of the chunks of an iteration took the walk's slow way -- chains that drift too far from the real sums)
     int ref_chain_mode = 0;        // 0 auto, 1 always pairs, 2 always the serial chain
     bool ref_pairs_off = false;    // auto mode: the current corpus went back to the serial chain
-    DevBuf ref_csum, ref_pairs, ref_exps, ref_stats, ref_ll_neg;
+    DevBuf ref_csum, ref_pairs, ref_exps, ref_stats, ref_ll_neg, ref_heavy;
+    bool ref_heavy_valid = false;
+    int n_ref_heavy = 0, ref_heavy_min = 0;
     unsigned long long *h_ref_stats = nullptr;   // pinned [2]: chunks that took the slow way / chunks, of the last finished walk
     hipEvent_t ev_ref_stats = nullptr;
     bool ref_stats_pending = false;
@@ -555,6 +557,7 @@ void set_active_pointers(plsa_ctx *c) {
     c->eitems_valid = false;
     c->p_valid = false;
     c->ref_pairs_off = false;
+    c->ref_heavy_valid = false;
 }
 
 int ensure_rowidx(plsa_ctx *c) {
@@ -867,6 +870,7 @@ int need_factors(plsa_ctx *c) {
 // ---------------------------------------------------------------------------------------------
 int run_ref_e_step(plsa_ctx *c, float thresh);
 int run_ref_norm_pwz(plsa_ctx *c, const float *d_sw);
+int ensure_ref_heavy(plsa_ctx *c);
 bool ref_pairs_now(const plsa_ctx *c);
 int run_ref_m_step(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_pdz);
 int run_ref_loglik(plsa_ctx *c, const float *d_sw, double *out);
@@ -1329,6 +1333,27 @@ int run_ref_e_step(plsa_ctx *c, float thresh) {
 
 // norm_pwz[z] = the reference's ONE float32 running sum over all non-zeros (plsa.py:193) on c->ls: from per-chunk parity pairs and a
 // walk (k_ref_pair_*), or by the serial chain (k_ref_norm_chain); same bits either way.
+// the reference arithmetic's long columns (PLSA_REF_HEAVY_MIN entries or more, default 2048; 0: none): list [count, columns...]
+int ensure_ref_heavy(plsa_ctx *c) {
+    if (c->ref_heavy_valid) return 0;
+    const char *e = getenv("PLSA_REF_HEAVY_MIN");
+    c->ref_heavy_min = e ? atoi(e) : 2048;
+    c->n_ref_heavy = 0;
+    if (c->ref_heavy_min > 0 && c->nnz > 0) {
+        CHK(ensure(c, c->ref_heavy, sizeof(int) * (size_t)(c->m + 1)));
+        HIPCHK(c, hipMemsetAsync(c->ref_heavy.p, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(plsa::ref::k_ref_heavy_cols, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream,
+                           c->colptr.as<int>(), (int)c->m, c->ref_heavy_min, c->ref_heavy.as<int>() + 1, c->ref_heavy.as<int>());
+        CHK(launch_check(c, "k_ref_heavy_cols"));
+        int n = 0;
+        HIPCHK(c, hipMemcpyAsync(&n, c->ref_heavy.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->n_ref_heavy = n;
+    }
+    c->ref_heavy_valid = true;
+    return 0;
+}
+
 // One chain of float32 additions over the non-zeros in order, per "topic" z < kp, WITHOUT the chain (plsa_ref_kernels.hpp: chunk
 // sums -> prefix -> (parity -> increment) pairs -> one checking walk per 64 topics), on c->ls.  kind / P / kp: PAIR_PLAIN or
 // PAIR_WEIGHTED over P(z|w,d) (norm_pwz, plsa.py:193), PAIR_NEG_TERMS over the likelihood terms with kp = 1 (plsa.py:322).
@@ -1448,9 +1473,12 @@ int run_ref_m_step(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_
     if (c->sharded) return fail(c, "the reference arithmetic has no doc-sharded form (norm_pwz is ONE chain over all non-zeros)");
     const int *order = nullptr;
     CHK(ensure_roworder(c, &order));
+    int heavy_min = INT32_MAX;
     if (update_v) {
         CHK(ensure_csc(c));
         CHK(ensure_rowidx(c));
+        CHK(ensure_ref_heavy(c));
+        if (c->n_ref_heavy > 0) heavy_min = c->ref_heavy_min;
         CHK(ensure(c, c->norm_pwz, sizeof(float) * (size_t)c->kp));
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -1472,9 +1500,32 @@ int run_ref_m_step(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_
             Scope s(c, "k_ref_col_pass");
             hipLaunchKernelGGL((plsa::ref::k_ref_col_pass<g, nz>), dim3(grid_for(c, c->m, 256 / g)), dim3(256), 0, c->stream,
                                c->colptr.as<int>(), c->csc_row.as<int>(), c->csc_val.as<float>(), c->csc_pos.as<int>(),
-                               (int)c->m, p_base(c), d_sw, c->Vacc.as<float>(), c->kp);
+                               (int)c->m, p_base(c), d_sw, c->Vacc.as<float>(), c->kp, heavy_min);
         }
     }));
+    if (update_v && c->n_ref_heavy > 0) {
+        // the long columns: one workgroup each, the norm_pwz chain's kernel over the column's entries (6.4 ns per entry where a
+        // group's own walk costs ~160: the Zipf head was the pass -- 24.6 ms at the config-3 150 k sample, 157 ms at the whole)
+        Scope s(c, "k_ref_col_heavy");
+        const int kp = c->kp;
+        auto go = [&](auto NZ) {
+            constexpr int nz = decltype(NZ)::value;
+            if (d_sw)
+                hipLaunchKernelGGL((plsa::ref::k_ref_norm_chain<nz, true, true>), dim3(c->n_ref_heavy), dim3(plsa::ref::CHAIN_THREADS), 0,
+                                   c->stream, c->csc_row.as<int>(), c->csc_val.as<float>(), (i64)0, p_base(c), d_sw, kp, c->Vacc.as<float>(),
+                                   c->csc_pos.as<int>(), c->ref_heavy.as<int>() + 1, c->colptr.as<int>());
+            else
+                hipLaunchKernelGGL((plsa::ref::k_ref_norm_chain<nz, false, true>), dim3(c->n_ref_heavy), dim3(plsa::ref::CHAIN_THREADS), 0,
+                                   c->stream, c->csc_row.as<int>(), c->csc_val.as<float>(), (i64)0, p_base(c), d_sw, kp, c->Vacc.as<float>(),
+                                   c->csc_pos.as<int>(), c->ref_heavy.as<int>() + 1, c->colptr.as<int>());
+        };
+        using std::integral_constant;
+        if (kp <= 64) go(integral_constant<int, 1>{});
+        else if (kp <= 128) go(integral_constant<int, 2>{});
+        else if (kp <= 256) go(integral_constant<int, 4>{});
+        else if (kp <= 512) go(integral_constant<int, 8>{});
+        else go(integral_constant<int, 16>{});
+    }
     CHK(launch_check(c, "k_ref_row_pass / k_ref_col_pass"));
     if (update_v) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -1642,7 +1693,7 @@ void plsa_destroy(plsa_ctx *c) {
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->U[2], &c->Vt[0], &c->Vt[1], &c->Vt[2], &c->Vacc,
                      &c->P, &c->sw, &c->sw_res, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
-                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp, &c->ref_terms, &c->ref_csum, &c->ref_pairs, &c->ref_exps, &c->ref_stats, &c->ref_ll_neg};
+                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp, &c->ref_terms, &c->ref_csum, &c->ref_pairs, &c->ref_exps, &c->ref_stats, &c->ref_ll_neg, &c->ref_heavy};
     if (c->p_borrowed) { c->P.p = nullptr; c->P.cap = 0; }      // lent memory is the lender's to free
     for (DevBuf *b : all) release(*b);
     for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -2732,7 +2783,7 @@ int plsa_release_scratch(plsa_ctx *c) {
     // the next materialising call allocate a private full-size array); a LENT one is freed: the caller ends the loans first
     if (!c->p_borrowed) release(c->P);
     c->p_lent = false;
-    release(c->ref_terms); release(c->ref_csum); release(c->ref_pairs); release(c->ref_exps); release(c->ref_ll_neg);
+    release(c->ref_terms); release(c->ref_csum); release(c->ref_pairs); release(c->ref_exps); release(c->ref_ll_neg); release(c->ref_heavy);
     release(c->partial); release(c->tmp0); release(c->tmp1); release(c->tmp2); release(c->cubtmp);
     release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly); release(c->mt_seq);
     // member stack + gather buffers of the ensemble exchange (16 runs x 64 topics x 100 k words = 0.4 GB): re-created

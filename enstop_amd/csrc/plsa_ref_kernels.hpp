@@ -155,12 +155,13 @@ template <int G, int NZ>
 __global__ __launch_bounds__(256) void k_ref_col_pass(const int *__restrict__ colptr, const int *__restrict__ csc_row,
                                                       const float *__restrict__ csc_val, const int *__restrict__ csc_pos,
                                                       int m, const float *__restrict__ P, const float *__restrict__ sw,
-                                                      float *__restrict__ Vacc, int kp) {
+                                                      float *__restrict__ Vacc, int kp, int heavy_min) {
     constexpr int GPB = 256 / G;
     constexpr int B = NZ <= 2 ? 16 : 8;         // rows of P in flight per group
     const int li = threadIdx.x % G, gid = threadIdx.x / G;
     for (i64 w = (i64)blockIdx.x * GPB + gid; w < m; w += (i64)gridDim.x * GPB) {
         const int j0 = colptr[w], j1 = colptr[w + 1];
+        if (j1 - j0 >= heavy_min) continue;     // a long column: a workgroup of its own (k_ref_norm_chain<.., GATHER>)
         float acc[NZ];
 #pragma unroll
         for (int t = 0; t < NZ; ++t) acc[t] = 0.0f;
@@ -217,6 +218,12 @@ __global__ __launch_bounds__(256) void k_ref_col_pass(const int *__restrict__ co
     }
 }
 
+// the columns with heavy_min entries or more (any order)
+__global__ void k_ref_heavy_cols(const int *__restrict__ colptr, int m, int heavy_min, int *__restrict__ list, int *__restrict__ count) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < m && colptr[w + 1] - colptr[w] >= heavy_min) list[atomicAdd(count, 1)] = w;
+}
+
 // ------------------------------------------------------------------------------------------------
 // norm_pwz[z] += s over ALL non-zeros, plsa.py:193 (:299 with weights): one float32 accumulator per topic and a chain
 // of nnz dependent additions -- the statement that carries the reference 1e-2 away from exact arithmetic at 3 M
@@ -246,15 +253,30 @@ constexpr int CHAIN_DEPTH = 4;                         // tiles in flight in reg
 // compile-time stride 37 / 132 / 262; loads CHAIN_DEPTH tiles ahead 29 / 98 / 162; dedicated adding wave with its LDS reads one
 // batch ahead of its adds ~21 / 66 / 110 (the kernel alone: 19 / 64 / 101 ms = 6.4 ns per non-zero; a dependent v_add_f32 issues
 // every ~8 cycles, the sequential likelihood chain below runs at 3.7 ns per term).
-template <int NZ, bool HAS_SW>
+//
+// GATHER (the long columns of the vocabulary half, plsa.py:190): the same chain over ONE COLUMN's entries -- workgroup b owns column
+// heavy[b]; `vals` / `rowidx` are the CSC's counts / documents from the column's first entry on (contiguous), the row of P an entry
+// multiplies is found through `pos` (its position in COO order), and the sums go to Vacc[w].  A load that depends on a load in a pipe
+// whose counter retires in order: the positions are requested 2 CHAIN_DEPTH tiles ahead, the rows they point to CHAIN_DEPTH tiles
+// ahead, so that waiting for a position never means waiting for the rows requested after it.
+template <int NZ, bool HAS_SW, bool GATHER = false>
 __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__restrict__ rowidx,
                                                                   const float *__restrict__ vals, i64 nnz,
                                                                   const float *__restrict__ P,
                                                                   const float *__restrict__ sw, int kp,
-                                                                  float *__restrict__ norm_pwz) {
+                                                                  float *__restrict__ norm_pwz,
+                                                                  const int *__restrict__ pos = nullptr,
+                                                                  const int *__restrict__ heavy = nullptr,
+                                                                  const int *__restrict__ colptr = nullptr) {
     constexpr int STRIDE = 64 * NZ;                            // floats between two rows of a tile in LDS
     constexpr int ROWS = CHAIN_TILE / STRIDE;                  // rows per tile (128 / NZ)
     __shared__ float4 tile[2][CHAIN_TILE / 4];
+    if (GATHER) {                                              // (uniform: scalar registers)
+        const int w = heavy[blockIdx.x], j0 = colptr[w];
+        nnz = colptr[w + 1] - j0;
+        rowidx += j0; vals += j0; pos += j0;
+        norm_pwz += (i64)w * kp;
+    }
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform by construction: scalar branches below)
     const bool producer = (wave & 3) != 0;                     // waves 1-3, 5-7, 9-11, 13-15
@@ -265,20 +287,28 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__r
     // a producer lane's float4 slots inside a tile (the same for every tile): validity, tile-relative row, offset into the
     // tile's part of P (floats), LDS position
     bool sval[CHAIN_F4];
-    int srow[CHAIN_F4], soff[CHAIN_F4], spos[CHAIN_F4];
+    int srow[CHAIN_F4], soff[CHAIN_F4], spos[CHAIN_F4], scol[CHAIN_F4];
 #pragma unroll
     for (int s = 0; s < CHAIN_F4; ++s) {
         const int f = ptid + CHAIN_PRODUCERS * s;
         sval[s] = producer && f < f4_per_tile;
         srow[s] = sval[s] ? f / kq : 0;
         soff[s] = sval[s] ? 4 * f : 0;
+        scol[s] = soff[s] - srow[s] * kp;                      // float offset inside the row of P
         spos[s] = srow[s] * (STRIDE / 4) + (sval[s] ? f - srow[s] * kq : 0);
     }
     float4 rp_[CHAIN_DEPTH][CHAIN_F4];
     float rx_[CHAIN_DEPTH][CHAIN_F4], rw_[CHAIN_DEPTH][CHAIN_F4];
+    int rq_[CHAIN_DEPTH][CHAIN_F4];                            // GATHER: positions, 2 CHAIN_DEPTH tiles ahead
     // rows of tile t that exist (0 beyond the corpus); the loads of a tile beyond the end go to the last tile (valid addresses)
     auto rows_of = [&](i64 t) { return (int)max((i64)0, min((i64)ROWS, nnz - t * ROWS)); };
-    auto fetch = [&](i64 t, float4 (&dp)[CHAIN_F4], float (&dx)[CHAIN_F4], float (&dw)[CHAIN_F4]) {
+    auto fetch_pos = [&](i64 t, int (&dq)[CHAIN_F4]) {         // (GATHER)
+        const i64 row0 = min(t, n_tiles - 1) * ROWS;
+        const int rows = t < n_tiles ? rows_of(t) : 0;
+#pragma unroll
+        for (int s = 0; s < CHAIN_F4; ++s) dq[s] = pos[row0 + (sval[s] && srow[s] < rows ? srow[s] : 0)];
+    };
+    auto fetch = [&](i64 t, float4 (&dp)[CHAIN_F4], float (&dx)[CHAIN_F4], float (&dw)[CHAIN_F4], const int (&dq)[CHAIN_F4]) {
         const i64 row0 = min(t, n_tiles - 1) * ROWS;           // (uniform: scalar registers)
         const int rows = t < n_tiles ? rows_of(t) : 0;
         const float *Pt = P + row0 * kp;
@@ -287,7 +317,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__r
 #pragma unroll
         for (int s = 0; s < CHAIN_F4; ++s) {
             const bool ok = sval[s] && srow[s] < rows;
-            dp[s] = *reinterpret_cast<const float4 *>(Pt + (ok ? soff[s] : 0));
+            if (GATHER) dp[s] = *reinterpret_cast<const float4 *>(P + (i64)dq[s] * kp + scol[s]);   // (dq: a valid entry's position always)
+            else dp[s] = *reinterpret_cast<const float4 *>(Pt + (ok ? soff[s] : 0));
             dx[s] = xt[ok ? srow[s] : 0];
             dw[s] = HAS_SW ? sw[rt[ok ? srow[s] : 0]] : 1.0f;
         }
@@ -346,8 +377,15 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__r
     } else if (!producer) {
         for (i64 t = 0; t < n_padded; ++t) __syncthreads();          // waves 4, 8, 12: they would share the adding wave's SIMD
     } else {
+        if (GATHER) {
 #pragma unroll
-        for (int dd = 0; dd < CHAIN_DEPTH; ++dd) fetch(dd, rp_[dd], rx_[dd], rw_[dd]);
+            for (int dd = 0; dd < CHAIN_DEPTH; ++dd) fetch_pos(dd, rq_[dd]);
+        }
+#pragma unroll
+        for (int dd = 0; dd < CHAIN_DEPTH; ++dd) {
+            fetch(dd, rp_[dd], rx_[dd], rw_[dd], rq_[dd]);
+            if (GATHER) fetch_pos(dd + CHAIN_DEPTH, rq_[dd]);
+        }
         for (i64 t0 = 0; t0 < n_padded; t0 += CHAIN_DEPTH) {
 #pragma unroll
             for (int dd = 0; dd < CHAIN_DEPTH; ++dd) {       // static register indices; tile t = t0 + dd
@@ -357,7 +395,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__r
                 for (int s = 0; s < CHAIN_F4; ++s)
                     if (sval[s]) buf[spos[s]] = products(t, rp_[dd][s], rx_[dd][s], rw_[dd][s], s);
                 __syncthreads();
-                fetch(t + CHAIN_DEPTH, rp_[dd], rx_[dd], rw_[dd]);
+                fetch(t + CHAIN_DEPTH, rp_[dd], rx_[dd], rw_[dd], rq_[dd]);
+                if (GATHER) fetch_pos(t + 2 * CHAIN_DEPTH, rq_[dd]);
             }
         }
     }

@@ -427,3 +427,40 @@ def test_norm_chain_goes_back_to_the_serial_chain_when_the_walk_keeps_failing(am
             same_bits(nw, nw_o, "norm_pwz")
         info = eng.reference_chain_info()
         assert info["serial_chain_now"] and 4 * info["slow_chunks"] > info["chunks"] > 0, info
+
+
+@pytest.mark.parametrize("k", [8, 70, 200])
+def test_long_columns_through_the_chain_kernel(amd, k, monkeypatch):
+    """plsa.py:190 / :296: the vocabulary half of the M-step with the long columns handed to k_ref_norm_chain<GATHER> (one
+    workgroup per column, the entries' rows of P found through their COO positions) -- here from 16 entries on, so that most
+    columns of a small corpus go that way, one of them holding every document: Vacc, and with it P(w|z), bit for bit the oracle's,
+    with and without sample weights."""
+    import scipy.sparse as sp
+    from oracle.plsa_oracle import Oracle
+    monkeypatch.setenv("PLSA_REF_HEAVY_MIN", "16")
+    rs = np.random.RandomState(100 + k)
+    n, m = 1500, 90
+    X = sp.random(n, m, density=0.05, format="lil", random_state=rs, dtype=np.float64)
+    X[:, 7] = 1.0                                                  # a word in every document: 1 500 entries, 12 tiles of the chain
+    X[::3, 11] = 2.0
+    X = X.tocsr(); X.data = np.ceil(X.data * 3); X = X.astype(np.float32)
+    r, c, v = coo_arrays(X)
+    P = rs.rand(X.nnz, k).astype(np.float32); P /= P.sum(1, keepdims=True)
+    sw = (0.25 + rs.rand(n)).astype(np.float32)
+    U0 = np.full((n, k), 1.0 / k, np.float32); V0 = np.full((k, m), 1.0 / m, np.float32)
+    o = Oracle(variant="strict")
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        eng.set_arithmetic("reference")
+        for weights in (None, sw):
+            Vo, Uo = V0.copy(), U0.copy()
+            nw_o, nd_o = np.zeros(k, np.float32), np.zeros(n, np.float32)
+            if weights is None:
+                o.plsa_m_step(r, c, v, Vo, Uo, P, nw_o, nd_o)
+            else:
+                o.plsa_m_step_w_sample_weight(r, c, v, Vo, Uo, P, weights, nw_o, nd_o)
+            eng.set_factors(U0, V0)
+            eng.set_p(P)
+            nw, nd = eng.m_step(weights)
+            U, V = eng.get_factors()
+            same_bits(nw, nw_o, "norm_pwz"); same_bits(V, Vo, "P(w|z)"); same_bits(U, Uo, "P(z|d)")
