@@ -1360,7 +1360,9 @@ int ensure_ref_heavy(plsa_ctx *c) {
 int run_ref_pair_chain(plsa_ctx *c, int kind, const float *P, int kp, const float *d_sw, float *out, unsigned long long *stats) {
     const int *ri = c->rowidx.as<int>();
     const bool ll = kind == plsa::ref::PAIR_NEG_TERMS;              // (timing names: the likelihood's launches apart from norm_pwz's)
-    const i64 n_chunks = (c->nnz + plsa::ref::PAIR_L - 1) / plsa::ref::PAIR_L;
+    int L = c->nnz >= plsa::ref::PAIR_L_LARGE_FROM ? plsa::ref::PAIR_L_LARGE : plsa::ref::PAIR_L_SMALL;
+    if (const char *e = getenv("PLSA_REF_CHUNK")) { const int v = atoi(e); if (v >= 64 && v <= 4096 && v % 64 == 0) L = v; }
+    const i64 n_chunks = (c->nnz + L - 1) / L;
     const i64 n_super = (n_chunks + plsa::ref::PAIR_SC - 1) / plsa::ref::PAIR_SC, n_pad = n_super * plsa::ref::PAIR_SC;
     CHK(ensure(c, c->ref_csum, sizeof(double) * (size_t)n_pad * kp));
     CHK(ensure(c, c->ref_pairs, sizeof(uint4) * (size_t)n_chunks * kp));
@@ -1384,7 +1386,7 @@ int run_ref_pair_chain(plsa_ctx *c, int kind, const float *P, int kp, const floa
             {
                 Scope s(c, ll ? "k_ref_ll_pair_sums" : "k_ref_pair_sums");
                 hipLaunchKernelGGL((plsa::ref::k_ref_pair_sums<nz, kd>), dim3(grid), dim3(256), 0, c->ls, ri, c->val, c->nnz, P,
-                                   d_sw, kp, n_chunks, n_pad, csum);
+                                   d_sw, kp, L, n_chunks, n_pad, csum);
             }
             {
                 Scope s(c, ll ? "k_ref_ll_pair_prefix" : "k_ref_pair_prefix");
@@ -1393,12 +1395,12 @@ int run_ref_pair_chain(plsa_ctx *c, int kind, const float *P, int kp, const floa
             {
                 Scope s(c, ll ? "k_ref_ll_pair_build" : "k_ref_pair_build");
                 hipLaunchKernelGGL((plsa::ref::k_ref_pair_build<nz, kd>), dim3(grid), dim3(256), 0, c->ls, ri, c->val, c->nnz, P,
-                                   d_sw, kp, n_chunks, n_pad, csum, prs, exps);
+                                   d_sw, kp, L, n_chunks, n_pad, csum, prs, exps);
             }
             {
                 Scope s(c, ll ? "k_ref_ll_pair_walk" : "k_ref_pair_walk");
                 hipLaunchKernelGGL((plsa::ref::k_ref_pair_walk<kd>), dim3((kp + 63) / 64), dim3(plsa::ref::WALK_THREADS), 0, c->ls, ri,
-                                   c->val, c->nnz, P, d_sw, kp, n_chunks, prs, exps, out, stats);
+                                   c->val, c->nnz, P, d_sw, kp, L, n_chunks, prs, exps, out, stats);
             }
         };
         using std::integral_constant;

@@ -431,11 +431,13 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__r
 // compared on tie-heavy dyadic inputs); the guesses only decide how many chunks take the slow way (counted, reported, and a fit
 // whose chains drift too far -- the whole of config 3, where the reference's sum stops growing -- goes back to the serial chain).
 // ------------------------------------------------------------------------------------------------
-#ifndef PLSA_PAIR_L
-#define PLSA_PAIR_L 256
-#endif
-constexpr int PAIR_L = PLSA_PAIR_L;   // addends per chunk (a walk step costs ~115 ns whatever the length, a chunk that goes the slow way ~25 ns
-                                      // per addend: 64 / 128 / 256 addends: the four kernels together 39.9 / 27.5 / 24.5 ms at the config-3 sample)
+// Addends per chunk: a kernel argument (a multiple of 64).  A walk step costs ~115 ns whatever the length, a chunk that goes the
+// slow way ~22 ns per addend, and the number of such chunks hardly depends on the corpus (~25 binade crossings per topic, most of them
+// shared by the 64 topics of a group: ~600 chunks per walk at k = 64), so the best length grows with sqrt(nnz): the host picks 256
+// below 48 M non-zeros and 1024 from there on (config-3 sample, 15 M: 64 / 128 / 256 -> the four kernels together 39.9 / 27.5 / 24.5 ms
+// in their first form; config 3 whole, 100 M: the walk 49 ms at 256, 27 ms at 1024).
+constexpr int PAIR_L_SMALL = 256, PAIR_L_LARGE = 1024;
+constexpr long long PAIR_L_LARGE_FROM = 48000000;
 constexpr int PAIR_SC = 8;            // chunks a wave handles back to back (8 consecutive float64 chunk sums per lane: one 64-B line)
 constexpr unsigned PAIR_INVALID = 0x7F000000u;                    // a total no valid chunk reaches (64 * 2^24 = 2^30): M + T >= 2^24 by itself
 constexpr unsigned PAIR_NO_BINADE = 0x7FFFu;                      // exps field "no candidate": equals no biased exponent
@@ -456,39 +458,71 @@ __device__ __forceinline__ float pair_addend(const float *__restrict__ P, const 
     return t;
 }
 
+// SB addends of a chunk for this lane's NZ topics, the loads all issued before the first product is formed (the compiler left to itself
+// multiplies each value as it arrives and keeps a handful of loads in flight: both kernels below ran at 0.8 TB/s that way).
+// rows: the chunk's rows that exist (>= 1); rows beyond repeat the last one (the callers skip them).
+template <int NZ, int KIND, int SB>
+__device__ __forceinline__ void pair_addend_batch(const float *__restrict__ Pc, const float *__restrict__ xc, const int *__restrict__ dc,
+                                                  const float *__restrict__ sw, int kp, int lane, int j0, int rows, float (&t)[SB][NZ]) {
+    float xv[SB], wv[SB];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+        const int jj = min(j0 + u, rows - 1);
+        xv[u] = KIND != PAIR_NEG_TERMS ? xc[jj] : 1.0f;
+        wv[u] = KIND == PAIR_WEIGHTED ? sw[dc[jj]] : 1.0f;
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) {
+            const int z = lane + 64 * q;
+            t[u][q] = Pc[jj * kp + (z < kp ? z : 0)];
+        }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < SB; ++u)
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) {
+            float v = KIND != PAIR_NEG_TERMS ? xv[u] * t[u][q] : -t[u][q];     // plsa.py:188 (: 322)
+            if (KIND == PAIR_WEIGHTED) v = v * wv[u];                          // plsa.py:294
+            t[u][q] = v;
+        }
+}
+constexpr int pair_batch(int nz) { return nz >= 8 ? 4 : (nz == 4 ? 8 : (nz == 2 ? 16 : 32)); }
+
 // float64 sum of every chunk's addends per topic: csum[z][c], chunk index fastest (n_pad chunks per topic)
 template <int NZ, int KIND>
 __global__ __launch_bounds__(256) void k_ref_pair_sums(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
-                                                       const float *__restrict__ P, const float *__restrict__ sw, int kp,
+                                                       const float *__restrict__ P, const float *__restrict__ sw, int kp, int PAIR_L,
                                                        i64 n_chunks, i64 n_pad, double *__restrict__ csum) {
+    constexpr int SB = pair_batch(NZ);
     const int lane = threadIdx.x & 63;
     const i64 wid = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((i64)gridDim.x * blockDim.x) >> 6;
     const i64 n_super = (n_chunks + PAIR_SC - 1) / PAIR_SC;
     for (i64 sc = wid; sc < n_super; sc += nw) {
-        double sum8[PAIR_SC][NZ];
-#pragma unroll
         for (int c8 = 0; c8 < PAIR_SC; ++c8) {
+            const i64 c = sc * PAIR_SC + c8;
+            double sum[NZ];
 #pragma unroll
-            for (int q = 0; q < NZ; ++q) sum8[c8][q] = 0.0;
-            const i64 row0 = (sc * PAIR_SC + c8) * PAIR_L;
-#pragma unroll 8
-            for (int j = 0; j < PAIR_L; ++j) {
-                const i64 row = row0 + j;
-                if (row < nnz) {                                 // (uniform)
+            for (int q = 0; q < NZ; ++q) sum[q] = 0.0;
+            if (c < n_chunks) {                                  // (uniform)
+                const i64 row0 = c * PAIR_L;
+                const int rows = (int)min((i64)PAIR_L, nnz - row0);
+                const float *Pc = P + row0 * kp, *xc = vals + row0;
+                const int *dc = rowidx + row0;
+                for (int j0 = 0; j0 < rows; j0 += SB) {
+                    float t[SB][NZ];
+                    pair_addend_batch<NZ, KIND, SB>(Pc, xc, dc, sw, kp, lane, j0, rows, t);
 #pragma unroll
-                    for (int q = 0; q < NZ; ++q) {
-                        const int z = lane + 64 * q;
-                        if (z < kp) sum8[c8][q] += (double)pair_addend<KIND>(P, vals, rowidx, sw, row, kp, z);
-                    }
+                    for (int u = 0; u < SB; ++u)
+                        if (j0 + u < rows) {                     // (uniform)
+#pragma unroll
+                            for (int q = 0; q < NZ; ++q) sum[q] += (double)t[u][q];
+                        }
                 }
             }
-        }
 #pragma unroll
-        for (int q = 0; q < NZ; ++q) {
-            const int z = lane + 64 * q;
-            if (z < kp) {
-#pragma unroll
-                for (int c8 = 0; c8 < PAIR_SC; ++c8) csum[(i64)z * n_pad + sc * PAIR_SC + c8] = sum8[c8][q];
+            for (int q = 0; q < NZ; ++q) {
+                const int z = lane + 64 * q;
+                if (z < kp) csum[(i64)z * n_pad + c] = sum[q];
             }
         }
     }
@@ -549,44 +583,59 @@ __device__ __forceinline__ void pair_step(PairState &st, int e_cand, unsigned tb
 // per (chunk, topic): the two candidate binades and their (T0, T1); pairs[c][z] = {T0_A, T1_A, T0_B, T1_B}, exps[c][z] = E_A | E_B << 16 [| PAIR_NOOP]
 template <int NZ, int KIND>
 __global__ __launch_bounds__(256) void k_ref_pair_build(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
-                                                        const float *__restrict__ P, const float *__restrict__ sw, int kp,
+                                                        const float *__restrict__ P, const float *__restrict__ sw, int kp, int PAIR_L,
                                                         i64 n_chunks, i64 n_pad, const double *__restrict__ prefix,
                                                         uint4 *__restrict__ pairs, unsigned *__restrict__ exps) {
+    constexpr int SB = pair_batch(NZ);
     const int lane = threadIdx.x & 63;
     const i64 wid = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((i64)gridDim.x * blockDim.x) >> 6;
     const i64 n_super = (n_chunks + PAIR_SC - 1) / PAIR_SC;
     for (i64 sc = wid; sc < n_super; sc += nw) {
+        for (int c8 = 0; c8 < PAIR_SC; ++c8) {
+            const i64 c = sc * PAIR_SC + c8;
+            if (c >= n_chunks) break;                            // (uniform)
+            int ea[NZ], eb[NZ];
+            PairState A[NZ], B[NZ];
+            bool all_zero[NZ];                                   // a chunk of + 0.0 addends leaves ANY sum as it is (padding topics, topics
+#pragma unroll                                                   // the E-step threshold emptied, stretches of zero responsibilities)
+            for (int q = 0; q < NZ; ++q) {
+                const int z = lane + 64 * q;
+                pair_candidates(prefix[(i64)(z < kp ? z : 0) * n_pad + c], ea[q], eb[q]);
+                A[q] = {0u, 0u, ea[q] != 0}; B[q] = {0u, 0u, eb[q] != 0};
+                all_zero[q] = true;
+            }
+            const i64 row0 = c * PAIR_L;
+            const int rows = (int)min((i64)PAIR_L, nnz - row0);
+            const float *Pc = P + row0 * kp, *xc = vals + row0;
+            const int *dc = rowidx + row0;
+            for (int j0 = 0; j0 < rows; j0 += SB) {
+                float t[SB][NZ];
+                pair_addend_batch<NZ, KIND, SB>(Pc, xc, dc, sw, kp, lane, j0, rows, t);
 #pragma unroll
-        for (int q = 0; q < NZ; ++q) {
-            const int z = lane + 64 * q;
-            if (z >= kp) continue;
-            double pre[PAIR_SC];
+                for (int u = 0; u < SB; ++u)
+                    if (j0 + u < rows) {                         // (uniform)
 #pragma unroll
-            for (int c8 = 0; c8 < PAIR_SC; ++c8) pre[c8] = prefix[(i64)z * n_pad + sc * PAIR_SC + c8];
-            for (int c8 = 0; c8 < PAIR_SC; ++c8) {
-                const i64 c = sc * PAIR_SC + c8;
-                if (c >= n_chunks) break;
-                int ea, eb;
-                pair_candidates(pre[c8], ea, eb);
-                PairState A = {0u, 0u, ea != 0}, B = {0u, 0u, eb != 0};
-                bool all_zero = true;                            // a chunk of + 0.0 addends leaves ANY sum as it is (padding topics,
-                const i64 row0 = c * PAIR_L;                     // topics the E-step threshold emptied, stretches of zero responsibilities)
-#pragma unroll 4
-                for (int j = 0; j < PAIR_L; ++j) {
-                    const i64 row = row0 + j;
-                    if (row >= nnz) break;
-                    const float t = pair_addend<KIND>(P, vals, rowidx, sw, row, kp, z);
-                    const unsigned tb = __float_as_uint(t);
-                    if ((tb >> 31) != 0u ? (tb << 1) != 0u : (tb >> 23) == 0xFFu) { A.ok = B.ok = all_zero = false; break; }   // negative (not -0) / inf / nan
-                    all_zero = all_zero && (tb << 1) == 0u;
-                    if (A.ok) pair_step(A, ea, tb & 0x7FFFFFFFu);
-                    if (B.ok) pair_step(B, eb, tb & 0x7FFFFFFFu);
+                        for (int q = 0; q < NZ; ++q) {
+                            const unsigned tb = __float_as_uint(t[u][q]);
+                            const bool bad = (tb >> 31) != 0u ? (tb << 1) != 0u : (tb >> 23) == 0xFFu;     // negative (not -0) / inf / nan
+                            if (bad) A[q].ok = B[q].ok = false;
+                            all_zero[q] = all_zero[q] && (tb << 1) == 0u;
+                            if (A[q].ok) pair_step(A[q], ea[q], tb & 0x7FFFFFFFu);
+                            if (B[q].ok) pair_step(B[q], eb[q], tb & 0x7FFFFFFFu);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) {
+                const int z = lane + 64 * q;
+                if (z < kp) {
+                    uint4 o;
+                    o.x = A[q].ok ? A[q].t0 : PAIR_INVALID; o.y = A[q].ok ? A[q].t1 : PAIR_INVALID;
+                    o.z = B[q].ok ? B[q].t0 : PAIR_INVALID; o.w = B[q].ok ? B[q].t1 : PAIR_INVALID;
+                    pairs[c * kp + z] = o;
+                    exps[c * kp + z] = (A[q].ok ? (unsigned)ea[q] : PAIR_NO_BINADE) | ((B[q].ok ? (unsigned)eb[q] : PAIR_NO_BINADE) << 16) |
+                                       (all_zero[q] ? PAIR_NOOP : 0u);
                 }
-                uint4 o;
-                o.x = A.ok ? A.t0 : PAIR_INVALID; o.y = A.ok ? A.t1 : PAIR_INVALID;
-                o.z = B.ok ? B.t0 : PAIR_INVALID; o.w = B.ok ? B.t1 : PAIR_INVALID;
-                pairs[c * kp + z] = o;
-                exps[c * kp + z] = (A.ok ? (unsigned)ea : PAIR_NO_BINADE) | ((B.ok ? (unsigned)eb : PAIR_NO_BINADE) << 16) | (all_zero ? PAIR_NOOP : 0u);
             }
         }
     }
@@ -613,7 +662,7 @@ constexpr int WALK_SLOTS = (WALK_TC * 64 + WALK_PRODUCERS - 1) / WALK_PRODUCERS;
 
 template <int KIND>
 __global__ __launch_bounds__(WALK_THREADS) void k_ref_pair_walk(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
-                                                                 const float *__restrict__ P, const float *__restrict__ sw, int kp,
+                                                                 const float *__restrict__ P, const float *__restrict__ sw, int kp, int PAIR_L,
                                                                  i64 n_chunks, const uint4 *__restrict__ pairs_,
                                                                  const unsigned *__restrict__ exps, float *__restrict__ norm_pwz,
                                                                  unsigned long long *__restrict__ stats) {
@@ -656,26 +705,35 @@ __global__ __launch_bounds__(WALK_THREADS) void k_ref_pair_walk(const int *__res
                 const i64 row0 = (t * TC + ch) * PAIR_L;         // (a chunk past the end is a no-op record: never here)
                 const int rows = (int)min((i64)PAIR_L, nnz - row0);
                 float sum = __uint_as_float(es ? (es << 23) | (m & 0x7FFFFFu) : m);
-                // the addends 32 rows at a time: all the loads, THEN the products and the dependent additions (left to itself the compiler
-                // forms each product as its load arrives and keeps ~12 loads in flight: 55 ns per addend)
-                constexpr int SB = 32;
                 const float *Pc = P + row0 * kp + z, *xc = vals + row0;
                 const int *dc = rowidx + row0;
-                for (int j0 = 0; j0 < rows; j0 += SB) {
-                    float pv[SB], xv[SB], wv[SB];
+                if (rows == PAIR_L) {
+                    // a whole chunk, 64 rows at a time: the 64 counts (and weights) in ONE load, lane u holding row u's, handed out with
+                    // v_readlane; the 64 values of P from a scalar row base + the lane's topic offset; all loads, THEN the products and
+                    // the dependent additions (left to itself the compiler forms each product as its load arrives and keeps ~12 loads in
+                    // flight; with a scalar load and 64-bit row * kp arithmetic per addend the slow way cost 45 ns per addend)
+#pragma unroll 1
+                    for (int j0 = 0; j0 < PAIR_L; j0 += 64) {
+                        float pv[64];
+                        const float xl = KIND != PAIR_NEG_TERMS ? xc[j0 + tid] : 1.0f;
+                        const float wl = KIND == PAIR_WEIGHTED ? sw[dc[j0 + tid]] : 1.0f;
 #pragma unroll
-                    for (int u = 0; u < SB; ++u) {               // (32-bit offsets from the chunk's bases: 64-bit row * kp per addend
-                        const int jj = min(j0 + u, rows - 1);    //  made the slow way ~25 scalar instructions per addend)
-                        pv[u] = Pc[jj * kp];
-                        xv[u] = KIND != PAIR_NEG_TERMS ? xc[jj] : 1.0f;
-                        wv[u] = KIND == PAIR_WEIGHTED ? sw[dc[jj]] : 1.0f;
+                        for (int u = 0; u < 64; ++u) pv[u] = Pc[(j0 + u) * kp];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int u = 0; u < 64; ++u) {
+                            const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(xl), u));
+                            float a = KIND != PAIR_NEG_TERMS ? x * pv[u] : -pv[u];       // plsa.py:188 (: 322)
+                            if (KIND == PAIR_WEIGHTED) a = a * __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wl), u));   // plsa.py:294
+                            sum = sum + a;                                               // plsa.py:193
+                        }
                     }
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int u = 0; u < SB; ++u) {
-                        float t = KIND != PAIR_NEG_TERMS ? xv[u] * pv[u] : -pv[u];     // plsa.py:188 (: 322)
-                        if (KIND == PAIR_WEIGHTED) t = t * wv[u];                      // plsa.py:294
-                        if (j0 + u < rows) sum = sum + t;        // plsa.py:193   (uniform branch)
+                } else {
+                    // the last chunk of the corpus
+                    for (int j = 0; j < rows; ++j) {
+                        float a = KIND != PAIR_NEG_TERMS ? xc[j] * Pc[j * kp] : -Pc[j * kp];
+                        if (KIND == PAIR_WEIGHTED) a = a * sw[dc[j]];
+                        sum = sum + a;
                     }
                 }
                 const unsigned b = __float_as_uint(sum), e = b >> 23;
