@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void k_ref_row_pass(const int *__restrict__ in
 // Vocabulary half, plsa.py:190 (296 with weights): p_w_given_z[z, w] += s over the non-zeros in COO order.  For one
 // word those are its column's entries in document order -- what the stable CSC holds -- so a group that owns the WHOLE
 // column (no items, no partial sums) and adds entry by entry reproduces the reference's accumulator bit for bit.
-// Un-normalised sums -> Vacc [m, kp]; B rows of P are in flight per group.
+// Un-normalised sums -> Vacc [m, kp]; B rows of P are in flight per group.  Columns of heavy_min entries and more are left to
+// k_ref_norm_chain<.., GATHER> (one workgroup per column: ~6 ns per entry where this walk costs ~160).
 // ------------------------------------------------------------------------------------------------
 template <int G, int NZ>
 __global__ __launch_bounds__(256) void k_ref_col_pass(const int *__restrict__ colptr, const int *__restrict__ csc_row,
