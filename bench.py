@@ -507,6 +507,31 @@ def _pick(d, *keys):
     return {k_: d[k_] for k_ in keys if isinstance(d, dict) and k_ in d}
 
 
+def reference_arithmetic_leg(eng, seed):
+    """The opt-in PARITY mode (PLSA_REFERENCE_SUMS: every sum of the E- and M-step the reference's float32 chain, DESIGN.md
+    section 2.1) at the two BASELINE sizes the reference itself is run at: EM iterations/s, the likelihood every ten iterations
+    like the reference's default.  Not `value`: the bits it returns are the subject of tests/test_reference_arithmetic.py."""
+    from enstop_amd.engine import PLSA_REFERENCE_SUMS
+    out = {"unit": "iter/s", "arithmetic": "reference (float32 sums in the reference's order)"}
+    for cfg_id, kw in ((1, dict(TOPICAL_20NG)), (2, {})):
+        cfg = CONFIGS[cfg_id]
+        eng.release_scratch()
+        eng.generate_synthetic(cfg["n"], cfg["m"], cfg["nnz"], zipf_s=1.07, seed=seed, **kw)
+        eng.init_factors_numpy_stream(cfg["k"], np.random.RandomState(42))
+        fit = dict(n_iter_per_test=10, tolerance=0.0, e_step_thresh=1e-32, flags=PLSA_REFERENCE_SUMS)
+        eng.fit(None, n_iter=10, **fit)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        it, _ = eng.fit(None, n_iter=30, **fit)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        key = "value" if cfg_id == 1 else "config2_value"
+        out[key] = round(it / dt, 1)
+        out["ms_per_step" if cfg_id == 1 else "config2_ms_per_step"] = round(dt / it * 1e3, 3)
+    out["chain"] = eng.reference_chain_info()
+    return out
+
+
 def compact_line(out, full_path=None):
     """The ONE JSON line of a default run: the contract keys, `roofline` (north-star kernel + `timed_loop` = the dominant
     kernel of the loop `value` times), `cpu_baseline`, every other BASELINE configuration and the ensemble legs as one
@@ -539,15 +564,17 @@ def compact_line(out, full_path=None):
                 short[name] = str(v)[:60]
                 continue
             e = _pick(v, "value", "steps", "ms_per_step")
+            if name == "reference_arithmetic":
+                e = _pick(v, "value", "config2_value")
             if "iter/s" not in str(v.get("unit", "iter/s")):
-                e["unit"] = str(v.get("unit"))[:24]
+                e["unit"] = str(v.get("unit"))[:15]
             if isinstance(v.get("e_step"), dict):
                 e["e_step_frac"] = v["e_step"].get("frac")
             if isinstance(v.get("cpu_baseline"), dict):
                 e["cpu_port_iter_s"] = v["cpu_baseline"].get("value")
             if str(v.get("corpus", "")).startswith("topical"):
                 e["corpus"] = "topical"
-            for extra in ("wall_s", "topics_found", "documents_on_their_planted_topic"):
+            for extra in ("wall_s", "topics_found", "documents_on_their_planted_topic", "config2_value"):
                 if extra in v:
                     e[extra] = v[extra]
             short[name] = e
@@ -875,6 +902,7 @@ def main():
         if isinstance(out.get("cpu_baseline"), dict) and isinstance(c2, dict) and isinstance(c2.get("cpu_baseline"), dict):
             out["cpu_baseline"]["whole_config2"] = c2["cpu_baseline"]
         leg("config1", lambda: quick_config(eng, 1, args.steps, args.warmup, args.seed, min_steps=1000, corpus_kw=dict(TOPICAL_20NG)))
+        leg("reference_arithmetic", lambda: reference_arithmetic_leg(eng, args.seed))
         leg("ensemble_20ng_shape", lambda: ensemble_20ng_shape(eng, args.seed))
         leg("ensemble_topics_estimator_20ng_shape", lambda: ensemble_topics_estimator_20ng_shape(eng, args.seed))
         leg("config3_topical", lambda: quick_config(eng, 3, args.steps, args.warmup, args.seed, e_step=False, min_steps=50,
