@@ -144,7 +144,7 @@ struct plsa_ctx {
     // quarter of the chunks of an iteration took the walk's slow way -- chains that drift too far from the real sums)
     int ref_chain_mode = 0;        // 0 auto, 1 always pairs, 2 always the serial chain
     bool ref_pairs_off = false;    // auto mode: the current corpus went back to the serial chain
-    DevBuf ref_csum, ref_pairs, ref_exps, ref_stats, ref_ll_neg, ref_heavy;
+    DevBuf ref_csum, ref_pairs, ref_exps, ref_pairs2, ref_exps2, ref_stats, ref_ll_neg, ref_heavy;
     bool ref_heavy_valid = false;
     int n_ref_heavy = 0, ref_heavy_min = 0;
     unsigned long long *h_ref_stats = nullptr;   // pinned [2]: chunks that took the slow way / chunks, of the last finished walk
@@ -1360,9 +1360,17 @@ int ensure_ref_heavy(plsa_ctx *c) {
 int run_ref_pair_chain(plsa_ctx *c, int kind, const float *P, int kp, const float *d_sw, float *out, unsigned long long *stats) {
     const int *ri = c->rowidx.as<int>();
     const bool ll = kind == plsa::ref::PAIR_NEG_TERMS;              // (timing names: the likelihood's launches apart from norm_pwz's)
-    int L = c->nnz >= plsa::ref::PAIR_L_LARGE_FROM ? plsa::ref::PAIR_L_LARGE : plsa::ref::PAIR_L_SMALL;
+    // two levels (default): chunks of 256 addends, walked in groups of PAIR_R; PLSA_REF_LEVELS=1: chunks only, longer on large corpora
+    bool two = true;
+    if (const char *e = getenv("PLSA_REF_LEVELS")) two = atoi(e) != 1;
+    int L = !two && c->nnz >= plsa::ref::PAIR_L_LARGE_FROM ? plsa::ref::PAIR_L_LARGE : plsa::ref::PAIR_L_SMALL;
     if (const char *e = getenv("PLSA_REF_CHUNK")) { const int v = atoi(e); if (v >= 64 && v <= 4096 && v % 64 == 0) L = v; }
     const i64 n_chunks = (c->nnz + L - 1) / L;
+    const i64 n_groups = (n_chunks + plsa::ref::PAIR_R - 1) / plsa::ref::PAIR_R;
+    if (two) {
+        CHK(ensure(c, c->ref_pairs2, sizeof(uint4) * (size_t)n_groups * kp));
+        CHK(ensure(c, c->ref_exps2, sizeof(unsigned) * (size_t)n_groups * kp));
+    }
     const i64 n_super = (n_chunks + plsa::ref::PAIR_SC - 1) / plsa::ref::PAIR_SC, n_pad = n_super * plsa::ref::PAIR_SC;
     CHK(ensure(c, c->ref_csum, sizeof(double) * (size_t)n_pad * kp));
     CHK(ensure(c, c->ref_pairs, sizeof(uint4) * (size_t)n_chunks * kp));
@@ -1397,10 +1405,20 @@ int run_ref_pair_chain(plsa_ctx *c, int kind, const float *P, int kp, const floa
                 hipLaunchKernelGGL((plsa::ref::k_ref_pair_build<nz, kd>), dim3(grid), dim3(256), 0, c->ls, ri, c->val, c->nnz, P,
                                    d_sw, kp, L, n_chunks, n_pad, csum, prs, exps);
             }
-            {
+            if (two) {
+                {
+                    Scope s(c, ll ? "k_ref_ll_pair_compose" : "k_ref_pair_compose");
+                    hipLaunchKernelGGL(plsa::ref::k_ref_pair_compose, dim3(grid_for(c, n_groups * kp, 256)), dim3(256), 0, c->ls, prs, exps,
+                                       kp, n_chunks, n_groups, c->ref_pairs2.as<uint4>(), c->ref_exps2.as<unsigned>());
+                }
                 Scope s(c, ll ? "k_ref_ll_pair_walk" : "k_ref_pair_walk");
-                hipLaunchKernelGGL((plsa::ref::k_ref_pair_walk<kd>), dim3((kp + 63) / 64), dim3(plsa::ref::WALK_THREADS), 0, c->ls, ri,
-                                   c->val, c->nnz, P, d_sw, kp, L, n_chunks, prs, exps, out, stats);
+                hipLaunchKernelGGL((plsa::ref::k_ref_pair_walk<kd, true>), dim3((kp + 63) / 64), dim3(plsa::ref::WALK_THREADS), 0, c->ls, ri,
+                                   c->val, c->nnz, P, d_sw, kp, L, n_groups, c->ref_pairs2.as<uint4>(), c->ref_exps2.as<unsigned>(), out,
+                                   stats, n_chunks, prs, exps);
+            } else {
+                Scope s(c, ll ? "k_ref_ll_pair_walk" : "k_ref_pair_walk");
+                hipLaunchKernelGGL((plsa::ref::k_ref_pair_walk<kd, false>), dim3((kp + 63) / 64), dim3(plsa::ref::WALK_THREADS), 0, c->ls, ri,
+                                   c->val, c->nnz, P, d_sw, kp, L, n_chunks, prs, exps, out, stats, n_chunks, prs, exps);
             }
         };
         using std::integral_constant;
@@ -1695,7 +1713,7 @@ void plsa_destroy(plsa_ctx *c) {
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->U[2], &c->Vt[0], &c->Vt[1], &c->Vt[2], &c->Vacc,
                      &c->P, &c->sw, &c->sw_res, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
-                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp, &c->ref_terms, &c->ref_csum, &c->ref_pairs, &c->ref_exps, &c->ref_stats, &c->ref_ll_neg, &c->ref_heavy};
+                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp, &c->ref_terms, &c->ref_csum, &c->ref_pairs, &c->ref_exps, &c->ref_stats, &c->ref_ll_neg, &c->ref_heavy, &c->ref_pairs2, &c->ref_exps2};
     if (c->p_borrowed) { c->P.p = nullptr; c->P.cap = 0; }      // lent memory is the lender's to free
     for (DevBuf *b : all) release(*b);
     for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -2785,7 +2803,7 @@ int plsa_release_scratch(plsa_ctx *c) {
     // the next materialising call allocate a private full-size array); a LENT one is freed: the caller ends the loans first
     if (!c->p_borrowed) release(c->P);
     c->p_lent = false;
-    release(c->ref_terms); release(c->ref_csum); release(c->ref_pairs); release(c->ref_exps); release(c->ref_ll_neg); release(c->ref_heavy);
+    release(c->ref_terms); release(c->ref_csum); release(c->ref_pairs); release(c->ref_exps); release(c->ref_ll_neg); release(c->ref_heavy); release(c->ref_pairs2); release(c->ref_exps2);
     release(c->partial); release(c->tmp0); release(c->tmp1); release(c->tmp2); release(c->cubtmp);
     release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly); release(c->mt_seq);
     // member stack + gather buffers of the ensemble exchange (16 runs x 64 topics x 100 k words = 0.4 GB): re-created

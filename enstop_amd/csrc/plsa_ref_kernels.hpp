@@ -642,6 +642,65 @@ __global__ __launch_bounds__(256) void k_ref_pair_build(const int *__restrict__ 
     }
 }
 
+// GROUPS of PAIR_R consecutive chunks: parity maps compose -- (p -> p + T_a[p]) then (q -> q + T_b[q]) is again a map from the starting
+// parity to a total increment, for as long as every chunk of the group has a valid pair for the SAME binade (a chunk of zeros fits any).
+// The walk then takes one step per group, PAIR_R times fewer, and falls back to the group's chunks where the group has no valid pair
+// (a crossing inside it, chunks that guessed different binades).  Candidates: those of the group's first chunk that has any.
+constexpr int PAIR_R = 16;
+__global__ __launch_bounds__(256) void k_ref_pair_compose(const uint4 *__restrict__ pairs, const unsigned *__restrict__ exps, int kp,
+                                                          i64 n_chunks, i64 n_groups, uint4 *__restrict__ pairs2,
+                                                          unsigned *__restrict__ exps2) {
+    const i64 total = n_groups * kp;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+        const i64 g = idx / kp;
+        const int z = (int)(idx - g * kp);
+        const i64 first = g * PAIR_R;
+        const int cnt = (int)min((i64)PAIR_R, n_chunks - first);
+        uint4 r[PAIR_R];
+        unsigned x[PAIR_R];
+#pragma unroll
+        for (int i = 0; i < PAIR_R; ++i) {
+            const i64 at = min(first + i, n_chunks - 1) * kp + z;
+            r[i] = pairs[at];
+            x[i] = i < cnt ? exps[at] : (PAIR_NOOP | PAIR_NO_BINADE | PAIR_NO_BINADE << 16);
+        }
+        unsigned cand[2] = {PAIR_NO_BINADE, PAIR_NO_BINADE};
+        bool all_noop = true, have = false;
+#pragma unroll
+        for (int i = 0; i < PAIR_R; ++i) {
+            const bool noop = (x[i] >> 31) != 0u;
+            all_noop = all_noop && noop;
+            const unsigned a = x[i] & 0xFFFFu, b = (x[i] >> 16) & 0x7FFFu;
+            if (!have && !noop && (a != PAIR_NO_BINADE || b != PAIR_NO_BINADE)) { cand[0] = a; cand[1] = b; have = true; }
+        }
+        unsigned out[4];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const unsigned e = cand[k2];
+            bool ok = e != PAIR_NO_BINADE;
+            unsigned inc0 = 0u, inc1 = 0u;
+#pragma unroll
+            for (int i = 0; i < PAIR_R; ++i) {
+                if ((x[i] >> 31) != 0u) continue;                  // zeros: any sum stays what it is
+                const bool isA = (x[i] & 0xFFFFu) == e, isB = ((x[i] >> 16) & 0x7FFFu) == e;
+                const unsigned t0 = isA ? r[i].x : r[i].z, t1 = isA ? r[i].y : r[i].w;
+                ok = ok && (isA || isB) && t0 != PAIR_INVALID;
+                if (ok) {
+                    inc0 += (inc0 & 1u) ? t1 : t0;
+                    inc1 += ((inc1 + 1u) & 1u) ? t1 : t0;
+                    if ((inc0 | inc1) >> 25) ok = false;
+                }
+            }
+            out[2 * k2] = ok ? inc0 : PAIR_INVALID;
+            out[2 * k2 + 1] = ok ? inc1 : PAIR_INVALID;
+            if (!ok) cand[k2] = PAIR_NO_BINADE;
+        }
+        uint4 o; o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3];
+        pairs2[idx] = o;
+        exps2[idx] = cand[0] | (cand[1] << 16) | (all_noop ? PAIR_NOOP : 0u);
+    }
+}
+
 // The walk: one wave per 64 topics follows the chains, lane = topic, the sum kept as (biased exponent, 24-bit significand); per
 // chunk ~30 integer instructions: pick the candidate whose binade IS the sum's, pick the total for the significand's parity, add,
 // check M + T < 2^24.  Workgroup b owns topics 64 b .. 64 b + 63 (chains of different topics never meet: k = 1000 walks in sixteen
@@ -661,18 +720,26 @@ constexpr int WALK_DEPTH = 6;                          // tiles in flight in the
 constexpr int WALK_TC = 16;                            // chunks per LDS tile: 16 KB of pairs + 4 KB of exponents, two tiles
 constexpr int WALK_SLOTS = (WALK_TC * 64 + WALK_PRODUCERS - 1) / WALK_PRODUCERS;     // records per producer lane and tile (3)
 
-template <int KIND>
+template <int KIND, bool TWO>
 __global__ __launch_bounds__(WALK_THREADS) void k_ref_pair_walk(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
                                                                  const float *__restrict__ P, const float *__restrict__ sw, int kp, int PAIR_L,
                                                                  i64 n_chunks, const uint4 *__restrict__ pairs_,
                                                                  const unsigned *__restrict__ exps, float *__restrict__ norm_pwz,
-                                                                 unsigned long long *__restrict__ stats) {
+                                                                 unsigned long long *__restrict__ stats,
+                                                                 i64 n_chunks1, const uint4 *__restrict__ pairs1_,
+                                                                 const unsigned *__restrict__ exps1) {
+    // TWO: the records streamed and walked are those of GROUPS of PAIR_R chunks (k_ref_pair_compose; n_chunks = groups); a group that
+    // fails its check is walked chunk by chunk from the chunks' own records (pairs1_ / exps1, n_chunks1 chunks of PAIR_L addends),
+    // and only a chunk that fails there is added addend by addend.
     // (a native vector type: arrays of HIP's uint4 struct are copied with memcpy and then stay in scratch memory)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 *__restrict__ pairs = reinterpret_cast<const u32x4 *>(pairs_);
     constexpr int TC = WALK_TC;
     __shared__ u32x4 trec[2][TC * 64];
     __shared__ unsigned texp[2][TC * 64];
+    __shared__ u32x4 mid_rec[TWO ? PAIR_R * 64 : 1];               // the walking wave's own: a failed group's chunk records
+    __shared__ unsigned mid_exp[TWO ? PAIR_R * 64 : 1];
+    const u32x4 *__restrict__ pairs1 = reinterpret_cast<const u32x4 *>(pairs1_);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = (wave & 3) != 0;
@@ -692,18 +759,22 @@ __global__ __launch_bounds__(WALK_THREADS) void k_ref_pair_walk(const int *__res
             u32x4 ra, rb, rc;
             unsigned xa, xb, xc;
             bool need;
-            auto fast_step = [&](const u32x4 &r, unsigned x) {
+            // one record into the sum of the lanes in `active`: true for the lanes it could not be applied to
+            auto apply = [&](const u32x4 &r, unsigned x, bool active) {
                 const bool useA = es == (x & 0xFFFFu), useB = es == ((x >> 16) & 0x7FFFu);
                 const unsigned t0 = useA ? r.x : r.z, t1 = useA ? r.y : r.w;
                 const unsigned mn = m + ((m & 1u) ? t1 : t0);
-                const bool fast = (useA || useB) && mn < 0x1000000u;
+                const bool fast = active && (useA || useB) && mn < 0x1000000u;
                 m = fast ? mn : m;
-                need = !fast && (x >> 31) == 0u && mine;
+                return !fast && (x >> 31) == 0u && active;
+            };
+            auto fast_step = [&](const u32x4 &r, unsigned x) {
+                need = apply(r, x, mine);
                 return __any(need) != 0;
             };
-            auto slow_step = [&](int ch) {                       // rare: binade crossings, the first chunk, a drifted guess
+            auto slow_chunk = [&](i64 c1, bool need) {           // rare: binade crossings, the first chunk, a drifted guess
                 ++slow;
-                const i64 row0 = (t * TC + ch) * PAIR_L;         // (a chunk past the end is a no-op record: never here)
+                const i64 row0 = c1 * PAIR_L;                    // (a chunk past the end is a no-op record: never here)
                 const int rows = (int)min((i64)PAIR_L, nnz - row0);
                 float sum = __uint_as_float(es ? (es << 23) | (m & 0x7FFFFFu) : m);
                 const float *Pc = P + row0 * kp + z, *xc = vals + row0;
@@ -740,6 +811,25 @@ __global__ __launch_bounds__(WALK_THREADS) void k_ref_pair_walk(const int *__res
                 const unsigned b = __float_as_uint(sum), e = b >> 23;
                 if (need) { es = e; m = e ? (b & 0x7FFFFFu) | 0x800000u : b; }
             };
+            auto slow_step = [&](int ch) {
+                const i64 c = t * TC + ch;
+                if (!TWO) { slow_chunk(c, need); return; }
+                // the group's chunks, their records fetched in one go and parked in LDS (every lane reads back its own)
+                const i64 first = c * PAIR_R;
+                const int cnt = (int)min((i64)PAIR_R, n_chunks1 - first);
+#pragma unroll
+                for (int i = 0; i < PAIR_R; ++i) {
+                    const i64 at = min(first + i, n_chunks1 - 1) * kp + z;
+                    mid_rec[i * 64 + tid] = pairs1[at];
+                    mid_exp[i * 64 + tid] = exps1[at];
+                }
+                const bool need2 = need;
+#pragma unroll 1
+                for (int i = 0; i < cnt; ++i) {
+                    const bool need1 = apply(mid_rec[i * 64 + tid], mid_exp[i * 64 + tid], need2);
+                    if (__any(need1)) slow_chunk(first + i, need1);
+                }
+            };
             // Runs of fast chunks in a loop whose body has NO join (the slow way sits outside it), the LDS reads two chunks ahead of
             // their use in three register sets; the empty asm statements keep the read-ahead ahead (the scheduler sinks a read to its
             // use otherwise).
@@ -770,7 +860,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_ref_pair_walk(const int *__res
             }
         }
         if (mine) norm_pwz[z] = __uint_as_float(es ? (es << 23) | (m & 0x7FFFFFu) : m);
-        if (tid == 0) { atomicAdd(stats, slow); atomicAdd(stats + 1, (unsigned long long)n_chunks); }
+        if (tid == 0) { atomicAdd(stats, slow); atomicAdd(stats + 1, (unsigned long long)n_chunks1); }     // (in chunks, whatever is walked)
     } else if (!producer) {
         for (i64 t = 0; t < n_padded; ++t) __syncthreads();
     } else {
