@@ -1320,7 +1320,24 @@ int dispatch_ref_group(plsa_ctx *c, Fn &&fn) {
 // plsa.py:91-105 with one float32 norm per entry, topics in order (P allocated by run_e_step)
 int run_ref_e_step(plsa_ctx *c, float thresh) {
     CHK(ensure_rowidx(c));
-    {
+    static const bool tiled = [] { const char *e = getenv("PLSA_REF_E_TILED"); return !e || atoi(e) != 0; }();
+    if (tiled && c->nnz > 0) {
+        Scope s(c, "k_ref_e_step");
+        const int kp = c->kp;
+        auto go = [&](auto NZ) {
+            constexpr int nz = decltype(NZ)::value;
+            const i64 tiles = (c->nnz + 64 / nz - 1) / (64 / nz);
+            hipLaunchKernelGGL((plsa::ref::k_ref_e_step_tiled<nz>), dim3(grid_for(c, tiles, 2)), dim3(128),
+                               sizeof(float) * 2 * (64 / nz) * (size_t)(kp + 1), c->stream, c->rowidx.as<int>(), c->col, c->nnz,
+                               c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(), p_base(c), kp, thresh);
+        };
+        using std::integral_constant;
+        if (kp <= 64) go(integral_constant<int, 1>{});
+        else if (kp <= 128) go(integral_constant<int, 2>{});
+        else if (kp <= 256) go(integral_constant<int, 4>{});
+        else if (kp <= 512) go(integral_constant<int, 8>{});
+        else go(integral_constant<int, 16>{});
+    } else {
         Scope s(c, "k_ref_e_step");
         hipLaunchKernelGGL(plsa::ref::k_ref_e_step, dim3(grid_for(c, c->nnz, 256)), dim3(256), 0, c->stream,
                            c->rowidx.as<int>(), c->col, c->nnz, c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(),

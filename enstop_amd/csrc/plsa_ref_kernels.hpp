@@ -77,6 +77,77 @@ __global__ __launch_bounds__(256) void k_ref_e_step(const int *__restrict__ rowi
     }
 }
 
+// The same statements with the memory traffic of a streaming kernel.  The lane-per-non-zero form above reads its two factor rows
+// and writes its row of P 16 bytes at a time from 64 different rows per instruction (and reads the factors twice): 0.8 TB/s.  Here a
+// wave takes TJ = 64 / NZ non-zeros: (A) lane = topic, the factor rows loaded and the products formed, thresholded and written to
+// an LDS tile row by row -- every access a whole row; (B) lane = non-zero, the tile read back TRANSPOSED (row stride kp + 1: no bank
+// conflicts) and the norm summed over the topics in order, one float32, exactly the loop of plsa.py:96-100 (a product the threshold
+// drops is stored as + 0.0: adding it changes nothing); (C) lane = topic again, every row divided by its norm (v_readlane) and
+// stored, 256 bytes per instruction.
+template <int NZ>
+__global__ __launch_bounds__(128) void k_ref_e_step_tiled(const int *__restrict__ rowidx, const int *__restrict__ colidx,
+                                                          i64 nnz, const float *__restrict__ U, const float *__restrict__ Vt,
+                                                          float *__restrict__ P, int kp, float thresh) {
+    constexpr int TJ = 64 / NZ;                                  // non-zeros per wave tile
+    constexpr int HB = TJ >= 32 ? 32 : TJ;                       // rows whose loads are in flight together (2 HB NZ <= 64 loads)
+    extern __shared__ float e_lds[];                             // [2 waves][TJ][kp + 1]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int stride = kp + 1;
+    float *tile = e_lds + wv * TJ * stride;
+    const i64 n_tiles = (nnz + TJ - 1) / TJ;
+    for (i64 ti = (i64)blockIdx.x * 2 + wv; ti < n_tiles; ti += (i64)gridDim.x * 2) {
+        const i64 nz0 = ti * TJ;
+        const int cnt = (int)min((i64)TJ, nnz - nz0);            // (uniform)
+        const int jl = min(lane, cnt - 1);
+        const int dl = rowidx[nz0 + jl], wl = colidx[nz0 + jl];  // lane j: the document and the word of non-zero j
+        float pr[TJ][NZ];
+#pragma unroll
+        for (int h = 0; h < TJ; h += HB) {
+            float ua[HB][NZ], va[HB][NZ];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const i64 d = __builtin_amdgcn_readlane(dl, h + j), w = __builtin_amdgcn_readlane(wl, h + j);
+#pragma unroll
+                for (int q = 0; q < NZ; ++q) {
+                    const int z = lane + 64 * q, zz = z < kp ? z : 0;
+                    ua[j][q] = U[d * kp + zz];
+                    va[j][q] = Vt[w * kp + zz];
+                }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < HB; ++j)
+#pragma unroll
+                for (int q = 0; q < NZ; ++q) {
+                    const int z = lane + 64 * q;
+                    float t = va[j][q] * ua[j][q];               // plsa.py:96
+                    t = t > thresh ? t : 0.0f;                   // plsa.py:97 / :101-102
+                    pr[h + j][q] = t;
+                    if (z < kp) tile[(h + j) * stride + z] = t;
+                }
+        }
+        wave_lds_fence();
+        float norm = 0.0f;
+        {
+            const float *row = tile + (lane < TJ ? lane : 0) * stride;
+#pragma unroll 8
+            for (int z = 0; z < kp; ++z) norm += row[z];         // plsa.py:98-100: one float32 sum, z ascending
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const float nj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(norm), j));
+            if (j < cnt) {                                       // (uniform)
+#pragma unroll
+                for (int q = 0; q < NZ; ++q) {
+                    const int z = lane + 64 * q;
+                    if (z < kp) P[(nz0 + j) * kp + z] = nj > 0.0f ? pr[j][q] / nj : pr[j][q];     // plsa.py:104-105
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Document half of the M-step, plsa.py:188, 191, 194, 200-202 (and the refit M-step, :806-814).  A group of G lanes
 // owns a document; lane li holds the topics z = li + G t (t < NZ).  Per entry: s = x * P(z|w,d) (rounded), the
