@@ -8,24 +8,28 @@
 // statement (the fixtures under tests/golden, produced by the reference itself, are met bit for bit):
 //
 //   reference statement (enstop/plsa.py)                       here
-//   :96-105  v = P(w|z) P(z|d); norm += v (z = 0 .. k-1);      k_ref_e_step     one lane per non-zero walks the topics in
-//            P(z|w,d) = v / norm                                                order; true division
+//   :96-105  v = P(w|z) P(z|d); norm += v (z = 0 .. k-1);      k_ref_e_step_tiled  one lane per non-zero adds the products in
+//            P(z|w,d) = v / norm                                                topic order (from an LDS tile); true division
 //   :188     s = x * P(z|w,d)          (:294 t = s * sw[d])    every kernel     product rounded BEFORE it is added: the whole
 //                                                                               file is compiled with fp contraction off
 //   :190     p_w_given_z[z, w] += s    over nz = 0 .. nnz-1    k_ref_col_pass   a group owns a whole column; its entries in
-//                                                                               document order (stable CSC) = COO order
+//                                                                               document order (stable CSC) = COO order; long
+//                                                                               columns: k_ref_norm_chain<GATHER>, one each
 //   :191     p_z_given_d[d, z] += s                            k_ref_row_pass   a group owns a document, entries in order
 //   :194     norm_pdz[d] += s          (entry-major, z-minor)  k_ref_row_pass   the row's k * len products added one by one
 //                                                                               (through LDS, every lane of the group)
-//   :193     norm_pwz[z] += s          over ALL nz             k_ref_norm_chain ONE chain of nnz dependent adds per topic:
-//                                                                               lane = topic, a workgroup streams x * P
-//                                                                               through LDS for its one adding wave
+//   :193     norm_pwz[z] += s          over ALL nz             k_ref_pair_*     the chain's BITS without the chain: chunks ->
+//                                                                               (parity -> increment) pairs, one checking walk
+//                                                              k_ref_norm_chain ... or the chain itself (small corpora, the
+//                                                                               fallback): lane = topic, a workgroup streams
+//                                                                               x * P through LDS for its one adding wave
 //   :196-202 division by the norms where positive              k_v_normalise (plsa_kernels.hpp) / k_ref_row_pass
-//   :378-384 dot += P(w|z) P(z|d); result += x log(dot) sw     k_ref_ll_terms + k_ref_ll_chain (PLSA_REFERENCE_LL only): one
-//                                                                               float32 running sum over all non-zeros
+//   :378-384 dot += P(w|z) P(z|d); result += x log(dot) sw     k_ref_ll_terms + k_ref_pair_* / k_ref_ll_chain (PLSA_REFERENCE_LL
+//                                                                               only): one float32 running sum over all non-zeros
 //
-// None of this is fast (the chains are the point); it is a PARITY mode: 20-110 ms per iteration at the BASELINE sizes the
-// tests run it on.  Layouts are the engine's (U [n,kp], Vt [m,kp] word-major, P [nnz,kp], pad entries zero: a zero product
+// A PARITY mode (sums in a prescribed order are the point): 2.7 / 6 / 12 / 51 ms per iteration at BASELINE config 1 / config 2 /
+// the config-3 150 k sample / config 3 whole -- 20 ... 35 times the default arithmetic's; the numba-compiled reference takes ~490 /
+// 1 900 / ~9 000 ms on the build container's 8 cores (DESIGN.md section 4 has the table and how each kernel got there).  Layouts are the engine's (U [n,kp], Vt [m,kp] word-major, P [nnz,kp], pad entries zero: a zero product
 // adds +0.0, which changes no sum).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -632,26 +636,12 @@ __device__ __forceinline__ void pair_candidates(double prefix, int &ea, int &eb)
     if (eb < 1 || eb > 252) eb = 0;
 }
 
-// one addend into the four running (candidate, starting parity) totals; returns false if the addend rules a candidate out
-struct PairState {
-    unsigned t0, t1;      // totals for starting parity 0 / 1
-    bool ok;
-};
-__device__ __forceinline__ void pair_step(PairState &st, int e_cand, unsigned tb) {
-    // tb: bit pattern of a non-negative finite addend (checked by the caller)
-    const int et_raw = (int)(tb >> 23);
-    const unsigned mt = et_raw ? ((tb & 0x7FFFFFu) | 0x800000u) : (tb & 0x7FFFFFu);
-    if (mt == 0u) return;                                          // + 0.0
-    const int sh = e_cand - (et_raw ? et_raw : 1);
-    if (sh < 1) { st.ok = false; return; }                         // an addend from S's binade or above: S leaves the binade
-    if (sh > 25) return;                                           // t < u / 2: the rounded sum is S
-    const unsigned q = mt >> sh, r = mt & ((1u << sh) - 1u), half = 1u << (sh - 1);
-    const unsigned up = r > half ? 1u : 0u, tie = r == half ? 1u : 0u;
-    st.t0 += q + (up | (tie & ((st.t0 + q) & 1u)));                // parity of M + q with M even at the chunk's start
-    st.t1 += q + (up | (tie & ((st.t1 + 1u + q) & 1u)));           // ... with M odd
-    if ((st.t0 | st.t1) >> 25) st.ok = false;                      // beyond any binade's 2^23 steps: useless, and it must not wrap
-}
-
+// The pairs of a chunk are computed BY THE ADDER: inside binade E the chain's increments depend on the sum only through the parity of
+// its significand, so two proxy sums -- 2^E (M = 2^23, even) and 2^E (1 + 2^-23) (odd) -- are carried through the chunk's addends with
+// plain v_add_f32; while a proxy stays in the binade its significand has moved by exactly T0 (T1).  A proxy that leaves the binade
+// (an addend from the sum's own binade or above, 2^23 steps, an infinity, a NaN) or a negative addend makes the pair invalid.  (The
+// first version evaluated q, r, the half-way test and the tie rule in integer arithmetic: ~45 instructions per addend and candidate
+// pair where this takes 4 additions; same pairs.)
 // per (chunk, topic): the two candidate binades and their (T0, T1); pairs[c][z] = {T0_A, T1_A, T0_B, T1_B}, exps[c][z] = E_A | E_B << 16 [| PAIR_NOOP]
 template <int NZ, int KIND>
 __global__ __launch_bounds__(256) void k_ref_pair_build(const int *__restrict__ rowidx, const float *__restrict__ vals, i64 nnz,
@@ -667,14 +657,15 @@ __global__ __launch_bounds__(256) void k_ref_pair_build(const int *__restrict__ 
             const i64 c = sc * PAIR_SC + c8;
             if (c >= n_chunks) break;                            // (uniform)
             int ea[NZ], eb[NZ];
-            PairState A[NZ], B[NZ];
-            bool all_zero[NZ];                                   // a chunk of + 0.0 addends leaves ANY sum as it is (padding topics, topics
-#pragma unroll                                                   // the E-step threshold emptied, stretches of zero responsibilities)
+            float a0[NZ], a1[NZ], b0[NZ], b1[NZ];                // the proxies: candidate A / B, starting parity 0 / 1
+            unsigned sgn[NZ], nzb[NZ];                           // OR of the addends' bits (sign) / of their bits without the sign
+#pragma unroll
             for (int q = 0; q < NZ; ++q) {
                 const int z = lane + 64 * q;
                 pair_candidates(prefix[(i64)(z < kp ? z : 0) * n_pad + c], ea[q], eb[q]);
-                A[q] = {0u, 0u, ea[q] != 0}; B[q] = {0u, 0u, eb[q] != 0};
-                all_zero[q] = true;
+                a0[q] = __uint_as_float((unsigned)ea[q] << 23); a1[q] = __uint_as_float(((unsigned)ea[q] << 23) | 1u);
+                b0[q] = __uint_as_float((unsigned)eb[q] << 23); b1[q] = __uint_as_float(((unsigned)eb[q] << 23) | 1u);
+                sgn[q] = nzb[q] = 0u;
             }
             const i64 row0 = c * PAIR_L;
             const int rows = (int)min((i64)PAIR_L, nnz - row0);
@@ -688,12 +679,9 @@ __global__ __launch_bounds__(256) void k_ref_pair_build(const int *__restrict__ 
                     if (j0 + u < rows) {                         // (uniform)
 #pragma unroll
                         for (int q = 0; q < NZ; ++q) {
-                            const unsigned tb = __float_as_uint(t[u][q]);
-                            const bool bad = (tb >> 31) != 0u ? (tb << 1) != 0u : (tb >> 23) == 0xFFu;     // negative (not -0) / inf / nan
-                            if (bad) A[q].ok = B[q].ok = false;
-                            all_zero[q] = all_zero[q] && (tb << 1) == 0u;
-                            if (A[q].ok) pair_step(A[q], ea[q], tb & 0x7FFFFFFFu);
-                            if (B[q].ok) pair_step(B[q], eb[q], tb & 0x7FFFFFFFu);
+                            const float v = t[u][q];
+                            a0[q] = a0[q] + v; a1[q] = a1[q] + v; b0[q] = b0[q] + v; b1[q] = b1[q] + v;      // plsa.py:193, four times
+                            sgn[q] |= __float_as_uint(v); nzb[q] |= __float_as_uint(v) << 1;
                         }
                     }
             }
@@ -701,12 +689,19 @@ __global__ __launch_bounds__(256) void k_ref_pair_build(const int *__restrict__ 
             for (int q = 0; q < NZ; ++q) {
                 const int z = lane + 64 * q;
                 if (z < kp) {
+                    // a chunk of + 0.0 addends leaves ANY sum as it is (padding topics, topics the E-step threshold emptied, stretches of
+                    // zero responsibilities); a negative addend (-0.0 included: cheap, and only a negative weight makes one) rules both out
+                    const bool all_zero = nzb[q] == 0u && (sgn[q] >> 31) == 0u, neg = (sgn[q] >> 31) != 0u;
+                    const unsigned ua0 = __float_as_uint(a0[q]), ua1 = __float_as_uint(a1[q]);
+                    const unsigned ub0 = __float_as_uint(b0[q]), ub1 = __float_as_uint(b1[q]);
+                    const bool okA = ea[q] != 0 && !neg && (ua0 >> 23) == (unsigned)ea[q] && (ua1 >> 23) == (unsigned)ea[q];
+                    const bool okB = eb[q] != 0 && !neg && (ub0 >> 23) == (unsigned)eb[q] && (ub1 >> 23) == (unsigned)eb[q];
                     uint4 o;
-                    o.x = A[q].ok ? A[q].t0 : PAIR_INVALID; o.y = A[q].ok ? A[q].t1 : PAIR_INVALID;
-                    o.z = B[q].ok ? B[q].t0 : PAIR_INVALID; o.w = B[q].ok ? B[q].t1 : PAIR_INVALID;
+                    o.x = okA ? (ua0 & 0x7FFFFFu) : PAIR_INVALID; o.y = okA ? (ua1 & 0x7FFFFFu) - 1u : PAIR_INVALID;
+                    o.z = okB ? (ub0 & 0x7FFFFFu) : PAIR_INVALID; o.w = okB ? (ub1 & 0x7FFFFFu) - 1u : PAIR_INVALID;
                     pairs[c * kp + z] = o;
-                    exps[c * kp + z] = (A[q].ok ? (unsigned)ea[q] : PAIR_NO_BINADE) | ((B[q].ok ? (unsigned)eb[q] : PAIR_NO_BINADE) << 16) |
-                                       (all_zero[q] ? PAIR_NOOP : 0u);
+                    exps[c * kp + z] = (okA ? (unsigned)ea[q] : PAIR_NO_BINADE) | ((okB ? (unsigned)eb[q] : PAIR_NO_BINADE) << 16) |
+                                       (all_zero ? PAIR_NOOP : 0u);
                 }
             }
         }
