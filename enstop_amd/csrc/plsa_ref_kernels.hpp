@@ -27,12 +27,13 @@
 //   :378-384 dot += P(w|z) P(z|d); result += x log(dot) sw     k_ref_ll_terms + k_ref_pair_* / k_ref_ll_chain (PLSA_REFERENCE_LL
 //                                                                               only): one float32 running sum over all non-zeros
 //
-// A PARITY mode (sums in a prescribed order are the point): 2.7 / 6 / 12 / 51 ms per iteration at BASELINE config 1 / config 2 /
+// A PARITY mode (sums in a prescribed order are the point): 2.0 / 4.7 / 10 / 44 ms per iteration at BASELINE config 1 / config 2 /
 // the config-3 150 k sample / config 3 whole -- 20 ... 35 times the default arithmetic's; the numba-compiled reference takes ~490 /
 // 1 900 / ~9 000 ms on the build container's 8 cores (DESIGN.md section 4 has the table and how each kernel got there).  Layouts are the engine's (U [n,kp], Vt [m,kp] word-major, P [nnz,kp], pad entries zero: a zero product
 // adds +0.0, which changes no sum).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
 #pragma clang fp contract(off)   // s = x * p is rounded, THEN added (plsa.py:188-194): no fused multiply-add in this file
@@ -604,19 +605,27 @@ __global__ __launch_bounds__(256) void k_ref_pair_sums(const int *__restrict__ r
     }
 }
 
-// csum[z][:] -> its exclusive prefix sums, in place; one workgroup per topic (any summation order will do: the walk checks every guess)
+// csum[z][:] -> its exclusive prefix sums, in place; one workgroup per topic, tiles of 2048 chunks (8 consecutive sums per lane, a
+// block-wide scan of the lanes' totals, a running carry).  Any summation order will do: the walk checks every guess.  (First
+// version: every lane scanned a slab of its own, then added up the slabs in front of it: 4 ms for the 392 k chunks of config 3.)
 __global__ __launch_bounds__(256) void k_ref_pair_prefix(double *__restrict__ csum, i64 n_chunks, i64 n_pad) {
-    __shared__ double slab_sum[256];
+    typedef hipcub::BlockScan<double, 256> Scan;
+    __shared__ typename Scan::TempStorage tmp;
     double *a = csum + (i64)blockIdx.x * n_pad;
-    const i64 slab = (n_chunks + 255) / 256;
-    const i64 lo = min(n_chunks, (i64)threadIdx.x * slab), hi = min(n_chunks, lo + slab);
-    double s = 0.0;
-    for (i64 i = lo; i < hi; ++i) s += a[i];
-    slab_sum[threadIdx.x] = s;
-    __syncthreads();
-    double run = 0.0;
-    for (int t = 0; t < (int)threadIdx.x; ++t) run += slab_sum[t];
-    for (i64 i = lo; i < hi; ++i) { const double v = a[i]; a[i] = run; run += v; }
+    double carry = 0.0;
+    for (i64 base = 0; base < n_chunks; base += 2048) {
+        const i64 i0 = base + (i64)threadIdx.x * 8;
+        double v[8], tot = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { v[u] = i0 + u < n_chunks ? a[i0 + u] : 0.0; tot += v[u]; }
+        double before, tile_total;
+        Scan(tmp).ExclusiveSum(tot, before, tile_total);
+        __syncthreads();
+        double run = carry + before;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { if (i0 + u < n_chunks) a[i0 + u] = run; run += v[u]; }
+        carry += tile_total;
+    }
 }
 
 // binade candidates of a chunk from its approximate prefix: biased float32 exponents, 0 = none
