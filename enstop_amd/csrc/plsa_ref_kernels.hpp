@@ -505,18 +505,21 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ref_norm_chain(const int *__r
 // drift beyond the window, a negative or non-finite addend -- the addends of that chunk are added one by one with real float32
 // additions (all lanes load the rows, only the lanes that need it add).  The checks make the result independent of the guesses: the
 // bits are those of the sequential chain above (tests: every bitwise test of the mode runs through this path, and both paths are
-// compared on tie-heavy dyadic inputs); the guesses only decide how many chunks take the slow way (counted, reported, and a fit
-// whose chains drift too far -- the whole of config 3, where the reference's sum stops growing -- goes back to the serial chain).
+// compared on tie-heavy dyadic inputs); the guesses only decide how many chunks take the slow way (counted, reported, and a context
+// whose walks fail on more than a quarter of their chunks goes back to the serial chain).  Two refinements below: the pairs of 16
+// consecutive chunks COMPOSE into one (k_ref_pair_compose: the walk steps through groups and descends into a group only where it has no
+// valid pair), and a chunk's pairs are computed by the adder itself (two proxy sums per binade, k_ref_pair_build).
 // ------------------------------------------------------------------------------------------------
 // Addends per chunk: a kernel argument (a multiple of 64).  A walk step costs ~115 ns whatever the length, a chunk that goes the
 // slow way ~22 ns per addend, and the number of such chunks hardly depends on the corpus (~25 binade crossings per topic, most of them
-// shared by the 64 topics of a group: ~600 chunks per walk at k = 64), so the best length grows with sqrt(nnz): the host picks 256
-// below 48 M non-zeros and 1024 from there on (config-3 sample, 15 M: 64 / 128 / 256 -> the four kernels together 39.9 / 27.5 / 24.5 ms
-// in their first form; config 3 whole, 100 M: the walk 49 ms at 256, 27 ms at 1024).
+// shared by the 64 topics of a group: ~600 chunks per walk at k = 64).  With the groups of PAIR_R chunks the length is 256 everywhere;
+// walking chunks only (PLSA_REF_LEVELS=1) the best length grows with sqrt(nnz) and the host takes 1024 from 48 M non-zeros on
+// (config-3 sample, 15 M: 64 / 128 / 256 -> the four kernels together 39.9 / 27.5 / 24.5 ms in their first form; config 3 whole,
+// 100 M: the walk 49 ms at 256, 24 ms at 1024, 9 ms with the groups).
 constexpr int PAIR_L_SMALL = 256, PAIR_L_LARGE = 1024;
 constexpr long long PAIR_L_LARGE_FROM = 48000000;
 constexpr int PAIR_SC = 8;            // chunks a wave handles back to back (8 consecutive float64 chunk sums per lane: one 64-B line)
-constexpr unsigned PAIR_INVALID = 0x7F000000u;                    // a total no valid chunk reaches (64 * 2^24 = 2^30): M + T >= 2^24 by itself
+constexpr unsigned PAIR_INVALID = 0x7F000000u;                    // a total no valid pair holds (those stay below 2^25): M + T >= 2^24 by itself
 constexpr unsigned PAIR_NO_BINADE = 0x7FFFu;                      // exps field "no candidate": equals no biased exponent
 constexpr unsigned PAIR_NOOP = 0x80000000u;                       // exps bit: every addend of the chunk is zero (any sum stays what it is)
 
