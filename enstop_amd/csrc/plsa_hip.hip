@@ -1525,9 +1525,19 @@ int run_ref_m_step(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_
         CHK(launch_check(c, "k_ref_norm_chain"));
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
     }
+    // the tiled document pass pays from ~300 k documents on (config 3 whole: 22 -> 10 ms); below, the wave tile that holds the few
+    // longest documents is the pass, and the group kernel walks a long document faster (PLSA_REF_ROW_TILED=1 / 0 pins either)
+    const char *row_tiled_env = getenv("PLSA_REF_ROW_TILED");
+    const bool row_tiled = row_tiled_env ? atoi(row_tiled_env) != 0 : c->n >= 300000;
     CHK(dispatch_ref_group(c, [&](auto G, auto NZ) {
         constexpr int g = decltype(G)::value, nz = decltype(NZ)::value;
-        {
+        if (row_tiled) {
+            Scope s(c, "k_ref_row_pass");
+            constexpr int tj = 64 / nz;
+            hipLaunchKernelGGL((plsa::ref::k_ref_row_pass_tiled<nz>), dim3(grid_for(c, (c->n + tj - 1) / tj, 2)), dim3(128),
+                               sizeof(float) * 2 * tj * (size_t)(c->kp + 1), c->stream, c->indptr, c->val, (int)c->n, order,
+                               p_base(c), c->U[out_u(c)].as<float>(), d_norm_pdz, c->kp);
+        } else {
             Scope s(c, "k_ref_row_pass");
             hipLaunchKernelGGL((plsa::ref::k_ref_row_pass<g, nz>), dim3(grid_for(c, c->n, 256 / g)), dim3(256),
                                sizeof(float) * (size_t)(256 / g) * c->kp, c->stream, c->indptr, c->val, (int)c->n, order,

@@ -27,7 +27,7 @@
 //   :378-384 dot += P(w|z) P(z|d); result += x log(dot) sw     k_ref_ll_terms + k_ref_pair_* / k_ref_ll_chain (PLSA_REFERENCE_LL
 //                                                                               only): one float32 running sum over all non-zeros
 //
-// A PARITY mode (sums in a prescribed order are the point): 2.0 / 4.7 / 10 / 44 ms per iteration at BASELINE config 1 / config 2 /
+// A PARITY mode (sums in a prescribed order are the point): 2.0 / 4.7 / 10 / 38 ms per iteration at BASELINE config 1 / config 2 /
 // the config-3 150 k sample / config 3 whole -- 20 ... 35 times the default arithmetic's; the numba-compiled reference takes ~490 /
 // 1 900 / ~9 000 ms on the build container's 8 cores (DESIGN.md section 4 has the table and how each kernel got there).  Layouts are the engine's (U [n,kp], Vt [m,kp] word-major, P [nnz,kp], pad entries zero: a zero product
 // adds +0.0, which changes no sum).
@@ -217,6 +217,107 @@ __global__ __launch_bounds__(256) void k_ref_row_pass(const int *__restrict__ in
         for (int t = 0; t < NZ; ++t) {
             const int z = li + G * t;
             if (z < kp) U_new[(i64)d * kp + z] = npdz > 0.0f ? acc[t] / npdz : acc[t];   // plsa.py:200-202
+        }
+    }
+}
+
+// The document half with the tile of the E-step above: a wave takes TJ = 64 / NZ documents (neighbours in the length-sorted order);
+// per entry slot e: (A) lane = topic -- for every document that has an e-th entry its row of P is loaded whole, s = x * P(z|w,d)
+// formed, added to the document's own accumulators (registers, lane = topic) and parked in the LDS tile, a document past its end
+// parks + 0.0; (B) lane = document -- norm_pdz[d] += s over the tile row, z ascending: the reference's chain (entry-major, z-minor),
+// ONE lane per document adding it where the group kernel above has all its lanes carry the same chain, sixteen documents' worth of
+// dependent additions per wave instruction instead of four (config 3 whole: 22 ms at 1.1 TB/s).
+template <int NZ>
+__global__ __launch_bounds__(128) void k_ref_row_pass_tiled(const int *__restrict__ indptr, const float *__restrict__ vals,
+                                                            int n, const int *__restrict__ row_order,
+                                                            const float *__restrict__ P, float *__restrict__ U_new,
+                                                            float *__restrict__ norm_pdz_out, int kp) {
+    constexpr int TJ = 64 / NZ;
+    extern __shared__ float r_lds[];                             // [2 waves][TJ][kp + 1]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int stride = kp + 1;
+    float *tile = r_lds + wv * TJ * stride;
+    const i64 n_tiles = ((i64)n + TJ - 1) / TJ;
+    for (i64 ti = (i64)blockIdx.x * 2 + wv; ti < n_tiles; ti += (i64)gridDim.x * 2) {
+        const i64 r0 = ti * TJ;
+        const int cnt = (int)min((i64)TJ, (i64)n - r0);          // (uniform)
+        // lane j < cnt: its document, first entry, length
+        const bool has = lane < cnt;
+        const int dj = has ? (row_order ? row_order[r0 + lane] : (int)(r0 + lane)) : 0;
+        const int j0 = has ? indptr[dj] : 0;
+        const int len = has ? indptr[dj + 1] - j0 : 0;
+        int maxlen = len;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
+        float acc[TJ][NZ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) acc[j][q] = 0.0f;
+        float npdz = 0.0f;
+        const float *row = tile + (lane < TJ ? lane : 0) * stride;
+        // software pipeline over the entry slots: slot e + 1's rows and counts are requested before slot e's chain is added
+        float pn[TJ][NZ], xn;
+        auto request = [&](int e, float (&pv)[TJ][NZ], float &xl) {
+            xl = e < len ? vals[j0 + e] : 0.0f;                  // lane = document: the count of its e-th entry
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int lj = __builtin_amdgcn_readlane(len, j);
+                const i64 at = (i64)(__builtin_amdgcn_readlane(j0, j) + (e < lj ? e : 0)) * kp;   // (a finished document: its first row
+#pragma unroll                                                                                    //  again -- cached, never used)
+                for (int q = 0; q < NZ; ++q) {
+                    const int z = lane + 64 * q;
+                    pv[j][q] = P[at + (z < kp ? z : 0)];
+                }
+            }
+        };
+        request(0, pn, xn);
+        for (int e = 0; e < maxlen; ++e) {
+            float pv[TJ][NZ];
+            const float xl = xn;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int q = 0; q < NZ; ++q) pv[j][q] = pn[j][q];
+            request(e + 1 < maxlen ? e + 1 : e, pn, xn);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const bool live = e < __builtin_amdgcn_readlane(len, j);                          // (uniform)
+                if (live) {
+                    const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(xl), j));
+#pragma unroll
+                    for (int q = 0; q < NZ; ++q) {
+                        const int z = lane + 64 * q;
+                        const float sv = x * pv[j][q];           // plsa.py:188
+                        acc[j][q] += sv;                         // plsa.py:191
+                        if (z < kp) tile[j * stride + z] = sv;
+                    }
+                } else if (e == __builtin_amdgcn_readlane(len, j)) {                              // just finished: its tile row becomes + 0.0
+#pragma unroll
+                    for (int q = 0; q < NZ; ++q) {
+                        const int z = lane + 64 * q;
+                        if (z < kp) tile[j * stride + z] = 0.0f;
+                    }
+                }
+            }
+            wave_lds_fence();
+#pragma unroll 8
+            for (int z = 0; z < kp; ++z) npdz += row[z];         // plsa.py:194, z ascending (a finished document adds + 0.0)
+            wave_lds_fence();
+        }
+        if (norm_pdz_out && has) norm_pdz_out[dj] = npdz;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            if (j < cnt) {                                       // (uniform)
+                const float nj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(npdz), j));
+                const i64 d = __builtin_amdgcn_readlane(dj, j);
+#pragma unroll
+                for (int q = 0; q < NZ; ++q) {
+                    const int z = lane + 64 * q;
+                    if (z < kp) U_new[d * kp + z] = nj > 0.0f ? acc[j][q] / nj : acc[j][q];       // plsa.py:200-202
+                }
+            }
         }
     }
 }

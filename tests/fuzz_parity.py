@@ -16,11 +16,12 @@ sys.path.insert(0, ROOT)
 from oracle.plsa_oracle import Oracle                          # noqa: E402   (checker only)
 
 # (PLSA_REF_HEAVY_MIN: the reference arithmetic's long-column kernel from 24 / 100 entries on -- these corpora have no column of 2048;
-#  PLSA_REF_CHUNK: 64- and 1024-addend chunks of the parity-pair chains beside the default 256)
-KNOBS = [{}, {"PLSA_E_ROWS": "1", "PLSA_E_SEG": "0", "PLSA_REF_HEAVY_MIN": "24"},
+#  PLSA_REF_CHUNK: 64- and 1024-addend chunks of the parity-pair chains beside the default 256; PLSA_REF_ROW_TILED: the document
+#  pass of the large corpora on these small ones)
+KNOBS = [{"PLSA_REF_ROW_TILED": "1"}, {"PLSA_E_ROWS": "1", "PLSA_E_SEG": "0", "PLSA_REF_HEAVY_MIN": "24"},
          {"PLSA_E_ROWS": "1", "PLSA_E_SEG": "8", "PLSA_ROW_ITEMS": "1", "PLSA_ROW_SEG": "8", "PLSA_REF_CHUNK": "64"},
          {"PLSA_COL_SEG": "4", "PLSA_HEAVY_ITEMS": "2", "PLSA_E_ROWS": "1", "PLSA_REF_HEAVY_MIN": "100"},
-         {"PLSA_OVERLAP": "0", "PLSA_SORT_ROWS": "0", "PLSA_XCD_SPLIT": "0", "PLSA_ITEM_ORDER": "0", "PLSA_REF_CHUNK": "1024"}]
+         {"PLSA_OVERLAP": "0", "PLSA_SORT_ROWS": "0", "PLSA_XCD_SPLIT": "0", "PLSA_ITEM_ORDER": "0", "PLSA_REF_CHUNK": "1024", "PLSA_REF_ROW_TILED": "1"}]
 
 
 def main():

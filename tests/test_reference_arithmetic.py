@@ -464,3 +464,42 @@ def test_long_columns_through_the_chain_kernel(amd, k, monkeypatch):
             nw, nd = eng.m_step(weights)
             U, V = eng.get_factors()
             same_bits(nw, nw_o, "norm_pwz"); same_bits(V, Vo, "P(w|z)"); same_bits(U, Uo, "P(z|d)")
+
+
+@pytest.mark.parametrize("k", [5, 64, 130])
+def test_tiled_document_pass(amd, k, monkeypatch):
+    """plsa.py:188-202 through k_ref_row_pass_tiled (the form large corpora take: a wave per 64 / NZ documents, norm_pdz one lane
+    per document over an LDS tile), forced onto a small corpus with empty documents, one very long document and ragged lengths
+    inside every tile: P(z|d) and norm_pdz bit for bit the oracle's, M-step and refit M-step, with and without weights."""
+    import scipy.sparse as sp
+    from oracle.plsa_oracle import Oracle
+    monkeypatch.setenv("PLSA_REF_ROW_TILED", "1")
+    rs = np.random.RandomState(300 + k)
+    n, m = 777, 210
+    X = sp.random(n, m, density=0.04, format="lil", random_state=rs, dtype=np.float64)
+    X[5, :] = 1.0                                                  # one document with every word
+    X[9, :] = 0.0; X[n - 1, :] = 0.0                               # empty documents, the last one included
+    X = X.tocsr(); X.data = np.ceil(X.data * 3); X.eliminate_zeros(); X = X.astype(np.float32)
+    r, c, v = coo_arrays(X)
+    P = rs.rand(X.nnz, k).astype(np.float32); P /= P.sum(1, keepdims=True)
+    sw = (0.25 + rs.rand(n)).astype(np.float32)
+    U0 = np.full((n, k), 1.0 / k, np.float32); V0 = np.full((k, m), 1.0 / m, np.float32)
+    o = Oracle(variant="strict")
+    with amd.Engine() as eng:
+        eng.upload_csr(X)
+        eng.set_arithmetic("reference")
+        for weights in (None, sw):
+            for update_v in (True, False):
+                Vo, Uo = V0.copy(), U0.copy()
+                nw_o, nd_o = np.zeros(k, np.float32), np.zeros(n, np.float32)
+                if not update_v:
+                    o.plsa_refit_m_step(r, c, v, Vo, Uo, P, np.ones(n, np.float32) if weights is None else weights, nd_o)
+                elif weights is None:
+                    o.plsa_m_step(r, c, v, Vo, Uo, P, nw_o, nd_o)
+                else:
+                    o.plsa_m_step_w_sample_weight(r, c, v, Vo, Uo, P, weights, nw_o, nd_o)
+                eng.set_factors(U0, V0)
+                eng.set_p(P)
+                nw, nd = eng.m_step(weights, update_v=update_v)
+                U, V = eng.get_factors()
+                same_bits(nd, nd_o, "norm_pdz"); same_bits(U, Uo, "P(z|d)"); same_bits(V, Vo, "P(w|z)")
