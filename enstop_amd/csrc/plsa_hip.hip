@@ -144,7 +144,12 @@ struct plsa_ctx {
     // quarter of the chunks of an iteration took the walk's slow way -- chains that drift too far from the real sums)
     int ref_chain_mode = 0;        // 0 auto, 1 always pairs, 2 always the serial chain
     bool ref_pairs_off = false;    // auto mode: the current corpus went back to the serial chain
-    DevBuf ref_csum, ref_pairs, ref_exps, ref_pairs2, ref_exps2, ref_stats, ref_ll_neg, ref_heavy;
+    DevBuf ref_csum, ref_pairs, ref_exps, ref_pairs2, ref_exps2, ref_stats, ref_ll_neg, ref_heavy, ref_tsum;
+    // tile sums of x * P(z|w,d) [* sw] left by the last reference-arithmetic E-step (valid for THAT P and THOSE weights only)
+    bool ref_tsum_valid = false;
+    const float *ref_tsum_sw = nullptr, *ref_e_sw = nullptr;   // weights the sums were formed with / the next E-step should use
+    int ref_tsum_tj = 0;
+    bool ref_e_no_sums = false;      // the E-steps of a refit: no norm_pwz chain follows
     bool ref_heavy_valid = false;
     int n_ref_heavy = 0, ref_heavy_min = 0;
     unsigned long long *h_ref_stats = nullptr;   // pinned [2]: chunks that took the slow way / chunks, of the last finished walk
@@ -558,6 +563,7 @@ void set_active_pointers(plsa_ctx *c) {
     c->p_valid = false;
     c->ref_pairs_off = false;
     c->ref_heavy_valid = false;
+    c->ref_tsum_valid = false;
 }
 
 int ensure_rowidx(plsa_ctx *c) {
@@ -876,6 +882,7 @@ int run_ref_m_step(plsa_ctx *c, const float *d_sw, bool update_v, float *d_norm_
 int run_ref_loglik(plsa_ctx *c, const float *d_sw, double *out);
 
 int run_e_step(plsa_ctx *c, float thresh) {
+    c->ref_tsum_valid = false;          // (a new P(z|w,d): the tile sums of the last reference-arithmetic E-step are history)
     {   // the materialised schedule needs the whole nnz x kp array: say so instead of a bare OOM
         const size_t need = sizeof(float) * (size_t)(c->nnz + 64) * (size_t)c->kp;
         size_t free_b = 0, total_b = 0;
@@ -1324,12 +1331,24 @@ int run_ref_e_step(plsa_ctx *c, float thresh) {
     if (tiled && c->nnz > 0) {
         Scope s(c, "k_ref_e_step");
         const int kp = c->kp;
+        // (PLSA_REF_FUSE_SUMS=0: no tile sums, the chain's k_ref_pair_sums reads P itself)
+        const char *fe = getenv("PLSA_REF_FUSE_SUMS");
+        const bool fuse = (!fe || atoi(fe) != 0) && ref_pairs_now(c) && !c->ref_e_no_sums;
+        int rc_alloc = 0;
         auto go = [&](auto NZ) {
             constexpr int nz = decltype(NZ)::value;
             const i64 tiles = (c->nnz + 64 / nz - 1) / (64 / nz);
-            hipLaunchKernelGGL((plsa::ref::k_ref_e_step_tiled<nz>), dim3(grid_for(c, tiles, 2)), dim3(128),
-                               sizeof(float) * 2 * (64 / nz) * (size_t)(kp + 1), c->stream, c->rowidx.as<int>(), c->col, c->nnz,
-                               c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(), p_base(c), kp, thresh);
+            if (fuse && (rc_alloc = ensure(c, c->ref_tsum, sizeof(float) * (size_t)tiles * kp)) == 0) {
+                hipLaunchKernelGGL((plsa::ref::k_ref_e_step_tiled<nz, true>), dim3(grid_for(c, tiles, 2)), dim3(128),
+                                   sizeof(float) * 2 * (64 / nz) * (size_t)(kp + 1), c->stream, c->rowidx.as<int>(), c->col, c->nnz,
+                                   c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(), p_base(c), kp, thresh, c->val, c->ref_e_sw,
+                                   c->ref_tsum.as<float>());
+                c->ref_tsum_valid = true; c->ref_tsum_sw = c->ref_e_sw; c->ref_tsum_tj = 64 / nz;
+            } else if (!rc_alloc) {
+                hipLaunchKernelGGL((plsa::ref::k_ref_e_step_tiled<nz, false>), dim3(grid_for(c, tiles, 2)), dim3(128),
+                                   sizeof(float) * 2 * (64 / nz) * (size_t)(kp + 1), c->stream, c->rowidx.as<int>(), c->col, c->nnz,
+                                   c->U[c->cu].as<float>(), c->Vt[c->cv].as<float>(), p_base(c), kp, thresh, nullptr, nullptr, nullptr);
+            }
         };
         using std::integral_constant;
         if (kp <= 64) go(integral_constant<int, 1>{});
@@ -1337,6 +1356,7 @@ int run_ref_e_step(plsa_ctx *c, float thresh) {
         else if (kp <= 256) go(integral_constant<int, 4>{});
         else if (kp <= 512) go(integral_constant<int, 8>{});
         else go(integral_constant<int, 16>{});
+        if (rc_alloc) return rc_alloc;
     } else {
         Scope s(c, "k_ref_e_step");
         hipLaunchKernelGGL(plsa::ref::k_ref_e_step, dim3(grid_for(c, c->nnz, 256)), dim3(256), 0, c->stream,
@@ -1408,7 +1428,13 @@ int run_ref_pair_chain(plsa_ctx *c, int kind, const float *P, int kp, const floa
         constexpr int nz = decltype(NZ)::value;
         auto go = [&](auto KIND) {
             constexpr int kd = decltype(KIND)::value;
-            {
+            if (!ll && c->ref_tsum_valid && c->ref_tsum_sw == d_sw && P == p_base(c) && c->p_valid && L % c->ref_tsum_tj == 0) {
+                // the E-step that wrote this P left the sums of its tiles: no second pass over P
+                Scope s(c, "k_ref_pair_sums");
+                const i64 n_tiles = (c->nnz + c->ref_tsum_tj - 1) / c->ref_tsum_tj;
+                hipLaunchKernelGGL(plsa::ref::k_ref_pair_sums_from_tiles, dim3(grid_for(c, n_chunks * kp, 256)), dim3(256), 0, c->ls,
+                                   c->ref_tsum.as<float>(), kp, L / c->ref_tsum_tj, n_tiles, n_chunks, n_pad, csum);
+            } else {
                 Scope s(c, ll ? "k_ref_ll_pair_sums" : "k_ref_pair_sums");
                 hipLaunchKernelGGL((plsa::ref::k_ref_pair_sums<nz, kd>), dim3(grid), dim3(256), 0, c->ls, ri, c->val, c->nnz, P,
                                    d_sw, kp, L, n_chunks, n_pad, csum);
@@ -1740,7 +1766,7 @@ void plsa_destroy(plsa_ctx *c) {
                      &c->colptr, &c->csc_row, &c->csc_val, &c->csc_pos, &c->item_first, &c->item_col,
                      &c->item_start, &c->item_order, &c->partial, &c->heavy_cols, &c->row_order, &c->ritem_first, &c->ritem_row, &c->ritem_start, &c->rpartial, &c->eitem_row, &c->eitem_start, &c->U[0], &c->U[1], &c->U[2], &c->Vt[0], &c->Vt[1], &c->Vt[2], &c->Vacc,
                      &c->P, &c->sw, &c->sw_res, &c->ll_partials, &c->ll_out, &c->colsum_partials, &c->norm_pwz,
-                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp, &c->ref_terms, &c->ref_csum, &c->ref_pairs, &c->ref_exps, &c->ref_stats, &c->ref_ll_neg, &c->ref_heavy, &c->ref_pairs2, &c->ref_exps2};
+                     &c->norm_pdz, &c->tmp0, &c->tmp1, &c->tmp2, &c->cubtmp, &c->ref_terms, &c->ref_csum, &c->ref_pairs, &c->ref_exps, &c->ref_stats, &c->ref_ll_neg, &c->ref_heavy, &c->ref_pairs2, &c->ref_exps2, &c->ref_tsum};
     if (c->p_borrowed) { c->P.p = nullptr; c->P.cap = 0; }      // lent memory is the lender's to free
     for (DevBuf *b : all) release(*b);
     for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -2137,6 +2163,7 @@ int plsa_set_p(plsa_ctx *c, const float *P) {
                                    sizeof(float) * c->k, (size_t)c->nnz, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->p_valid = true;
+    c->ref_tsum_valid = false;
     return 0;
 }
 
@@ -2209,6 +2236,8 @@ int plsa_fit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_te
     }
 
     if (!fused) {
+        struct ESw { plsa_ctx *c; ~ESw() { c->ref_e_sw = nullptr; } } e_sw_guard{c};
+        c->ref_e_sw = d_sw_m;               // (reference arithmetic: the E-step leaves its tile sums with the weights the M-step will use)
         for (int i = 0; i < n_iter; ++i) {
             CHK(run_e_step(c, thresh));                              // plsa.py:597
             CHK(run_m_step_from_p(c, d_sw_m, true, nullptr));       // plsa.py:606-628
@@ -2466,6 +2495,8 @@ int plsa_refit(plsa_ctx *c, const float *sw, int32_t n_iter, int32_t n_iter_per_
         return false;
     };
     if (!fused) {
+        struct NoSums { plsa_ctx *c; ~NoSums() { c->ref_e_no_sums = false; } } no_sums_guard{c};
+        c->ref_e_no_sums = true;            // (reference arithmetic: no norm_pwz chain follows these E-steps, their tile sums would be wasted)
         for (int i = 0; i < n_iter; ++i) {
             CHK(run_e_step(c, thresh));
             CHK(run_m_step_from_p(c, nullptr, false, nullptr));
@@ -2830,7 +2861,7 @@ int plsa_release_scratch(plsa_ctx *c) {
     // the next materialising call allocate a private full-size array); a LENT one is freed: the caller ends the loans first
     if (!c->p_borrowed) release(c->P);
     c->p_lent = false;
-    release(c->ref_terms); release(c->ref_csum); release(c->ref_pairs); release(c->ref_exps); release(c->ref_ll_neg); release(c->ref_heavy); release(c->ref_pairs2); release(c->ref_exps2);
+    release(c->ref_terms); release(c->ref_csum); release(c->ref_pairs); release(c->ref_exps); release(c->ref_ll_neg); release(c->ref_heavy); release(c->ref_pairs2); release(c->ref_exps2); release(c->ref_tsum);
     release(c->partial); release(c->tmp0); release(c->tmp1); release(c->tmp2); release(c->cubtmp);
     release(c->mt_words); release(c->mt_state); release(c->mt_fin); release(c->mt_poly); release(c->mt_seq);
     // member stack + gather buffers of the ensemble exchange (16 runs x 64 topics x 100 k words = 0.4 GB): re-created

@@ -27,7 +27,7 @@
 //   :378-384 dot += P(w|z) P(z|d); result += x log(dot) sw     k_ref_ll_terms + k_ref_pair_* / k_ref_ll_chain (PLSA_REFERENCE_LL
 //                                                                               only): one float32 running sum over all non-zeros
 //
-// A PARITY mode (sums in a prescribed order are the point): 2.0 / 4.7 / 10 / 38 ms per iteration at BASELINE config 1 / config 2 /
+// A PARITY mode (sums in a prescribed order are the point): 1.9 / 4.4 / 10 / 35 ms per iteration at BASELINE config 1 / config 2 /
 // the config-3 150 k sample / config 3 whole -- 20 ... 35 times the default arithmetic's; the numba-compiled reference takes ~490 /
 // 1 900 / ~9 000 ms on the build container's 8 cores (DESIGN.md section 4 has the table and how each kernel got there).  Layouts are the engine's (U [n,kp], Vt [m,kp] word-major, P [nnz,kp], pad entries zero: a zero product
 // adds +0.0, which changes no sum).
@@ -89,10 +89,16 @@ __global__ __launch_bounds__(256) void k_ref_e_step(const int *__restrict__ rowi
 // conflicts) and the norm summed over the topics in order, one float32, exactly the loop of plsa.py:96-100 (a product the threshold
 // drops is stored as + 0.0: adding it changes nothing); (C) lane = topic again, every row divided by its norm (v_readlane) and
 // stored, 256 bytes per instruction.
-template <int NZ>
+// SUMS: the wave also leaves the sums of its tile's addends t = x * P(z|w,d) [* sw[d]] per topic (tsum[tile][z], float32) -- what
+// k_ref_pair_sums would read the whole of P again for (the chunk sums that guess the binades of the norm_pwz chain: any order, any
+// precision will do for a guess).  The counts and weights are requested at the top of the tile: asked for where they are used, their
+// latency stood exposed once per tile and the kernel took 1.8 times as long.
+template <int NZ, bool SUMS>
 __global__ __launch_bounds__(128) void k_ref_e_step_tiled(const int *__restrict__ rowidx, const int *__restrict__ colidx,
                                                           i64 nnz, const float *__restrict__ U, const float *__restrict__ Vt,
-                                                          float *__restrict__ P, int kp, float thresh) {
+                                                          float *__restrict__ P, int kp, float thresh,
+                                                          const float *__restrict__ vals, const float *__restrict__ sw,
+                                                          float *__restrict__ tsum) {
     constexpr int TJ = 64 / NZ;                                  // non-zeros per wave tile
     constexpr int HB = TJ >= 32 ? 32 : TJ;                       // rows whose loads are in flight together (2 HB NZ <= 64 loads)
     extern __shared__ float e_lds[];                             // [2 waves][TJ][kp + 1]
@@ -105,6 +111,11 @@ __global__ __launch_bounds__(128) void k_ref_e_step_tiled(const int *__restrict_
         const int cnt = (int)min((i64)TJ, nnz - nz0);            // (uniform)
         const int jl = min(lane, cnt - 1);
         const int dl = rowidx[nz0 + jl], wl = colidx[nz0 + jl];  // lane j: the document and the word of non-zero j
+        float xs = 0.0f, ws = 1.0f;                              // ... (SUMS) its count and its document's weight
+        if (SUMS) {
+            xs = vals[nz0 + jl];
+            if (sw) ws = sw[dl];
+        }
         float pr[TJ][NZ];
 #pragma unroll
         for (int h = 0; h < TJ; h += HB) {
@@ -139,17 +150,51 @@ __global__ __launch_bounds__(128) void k_ref_e_step_tiled(const int *__restrict_
             for (int z = 0; z < kp; ++z) norm += row[z];         // plsa.py:98-100: one float32 sum, z ascending
         }
         wave_lds_fence();
+        float ts[NZ];
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) ts[q] = 0.0f;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const float nj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(norm), j));
             if (j < cnt) {                                       // (uniform)
+                const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(xs), j));
+                const float w = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ws), j));
 #pragma unroll
                 for (int q = 0; q < NZ; ++q) {
                     const int z = lane + 64 * q;
-                    if (z < kp) P[(nz0 + j) * kp + z] = nj > 0.0f ? pr[j][q] / nj : pr[j][q];     // plsa.py:104-105
+                    const float pz = nj > 0.0f ? pr[j][q] / nj : pr[j][q];                        // plsa.py:104-105
+                    if (z < kp) P[(nz0 + j) * kp + z] = pz;
+                    if (SUMS) {
+                        float t = x * pz;                        // plsa.py:188
+                        if (sw) t = t * w;                       // plsa.py:294
+                        ts[q] += t;
+                    }
                 }
             }
         }
+        if (SUMS) {
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) {
+                const int z = lane + 64 * q;
+                if (z < kp) tsum[ti * kp + z] = ts[q];
+            }
+        }
+    }
+}
+
+// chunk sums from the E-step's tile sums: csum[z][c] = the sum of the chunk's tiles (tiles_per_chunk = PAIR_L / TJ)
+__global__ __launch_bounds__(256) void k_ref_pair_sums_from_tiles(const float *__restrict__ tsum, int kp, int tiles_per_chunk, i64 n_tiles,
+                                                                  i64 n_chunks, i64 n_pad, double *__restrict__ csum) {
+    const i64 total = n_chunks * kp;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+        const i64 c = idx / kp;
+        const int z = (int)(idx - c * kp);
+        double s2 = 0.0;
+        for (int i = 0; i < tiles_per_chunk; ++i) {
+            const i64 tile = c * tiles_per_chunk + i;
+            if (tile < n_tiles) s2 += (double)tsum[tile * kp + z];
+        }
+        csum[(i64)z * n_pad + c] = s2;
     }
 }
 
