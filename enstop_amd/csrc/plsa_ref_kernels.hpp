@@ -27,7 +27,7 @@
 //   :378-384 dot += P(w|z) P(z|d); result += x log(dot) sw     k_ref_ll_terms + k_ref_pair_* / k_ref_ll_chain (PLSA_REFERENCE_LL
 //                                                                               only): one float32 running sum over all non-zeros
 //
-// A PARITY mode (sums in a prescribed order are the point): 1.9 / 4.4 / 10 / 35 ms per iteration at BASELINE config 1 / config 2 /
+// A PARITY mode (sums in a prescribed order are the point): 1.8 / 4.3 / 9.4 / 35 ms per iteration at BASELINE config 1 / config 2 /
 // the config-3 150 k sample / config 3 whole -- 20 ... 35 times the default arithmetic's; the numba-compiled reference takes ~490 /
 // 1 900 / ~9 000 ms on the build container's 8 cores (DESIGN.md section 4 has the table and how each kernel got there).  Layouts are the engine's (U [n,kp], Vt [m,kp] word-major, P [nnz,kp], pad entries zero: a zero product
 // adds +0.0, which changes no sum).
@@ -1004,25 +1004,40 @@ __global__ __launch_bounds__(WALK_THREADS) void k_ref_pair_walk(const int *__res
                 const float *Pc = P + row0 * kp + z, *xc = vals + row0;
                 const int *dc = rowidx + row0;
                 if (rows == PAIR_L) {
-                    // a whole chunk, 64 rows at a time: the 64 counts (and weights) in ONE load, lane u holding row u's, handed out with
-                    // v_readlane; the 64 values of P from a scalar row base + the lane's topic offset; all loads, THEN the products and
-                    // the dependent additions (left to itself the compiler forms each product as its load arrives and keeps ~12 loads in
-                    // flight; with a scalar load and 64-bit row * kp arithmetic per addend the slow way cost 45 ns per addend)
+                    // a whole chunk: the counts (and weights) of 64 rows in ONE load, lane u holding row u's, handed out with v_readlane;
+                    // the values of P from a scalar row base + the lane's topic offset, 32 rows per batch in two register sets -- the
+                    // next batch is requested BEFORE the current one is added, so the chunk costs one memory latency, not one per
+                    // batch (5.7 -> ~3 us per slow chunk; left to itself the compiler forms each product as its load arrives and keeps
+                    // ~12 loads in flight; with a scalar load and 64-bit row * kp arithmetic per addend it was 45 ns per addend)
+                    float pa[32], pb[32];
+                    auto load32 = [&](float (&pv)[32], int r0) {
+#pragma unroll
+                        for (int u = 0; u < 32; ++u) pv[u] = Pc[(r0 + u) * kp];
+                    };
+                    auto add32 = [&](const float (&pv)[32], float xl, float wl, int l0) {
+#pragma unroll
+                        for (int u = 0; u < 32; ++u) {
+                            const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(xl), l0 + u));
+                            float a2 = KIND != PAIR_NEG_TERMS ? x * pv[u] : -pv[u];      // plsa.py:188 (: 322)
+                            if (KIND == PAIR_WEIGHTED) a2 = a2 * __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wl), l0 + u));   // plsa.py:294
+                            sum = sum + a2;                                              // plsa.py:193
+                        }
+                    };
+                    float xl = KIND != PAIR_NEG_TERMS ? xc[tid] : 1.0f;
+                    float wl = KIND == PAIR_WEIGHTED ? sw[dc[tid]] : 1.0f;
+                    load32(pa, 0);
 #pragma unroll 1
                     for (int j0 = 0; j0 < PAIR_L; j0 += 64) {
-                        float pv[64];
-                        const float xl = KIND != PAIR_NEG_TERMS ? xc[j0 + tid] : 1.0f;
-                        const float wl = KIND == PAIR_WEIGHTED ? sw[dc[j0 + tid]] : 1.0f;
-#pragma unroll
-                        for (int u = 0; u < 64; ++u) pv[u] = Pc[(j0 + u) * kp];
+                        const int jn = min(j0 + 64, PAIR_L - 64);              // (the last round requests its own rows again: no branch)
+                        const float xn = KIND != PAIR_NEG_TERMS ? xc[jn + tid] : 1.0f;
+                        const float wn = KIND == PAIR_WEIGHTED ? sw[dc[jn + tid]] : 1.0f;
+                        load32(pb, j0 + 32);
                         asm volatile("" ::: "memory");
-#pragma unroll
-                        for (int u = 0; u < 64; ++u) {
-                            const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(xl), u));
-                            float a = KIND != PAIR_NEG_TERMS ? x * pv[u] : -pv[u];       // plsa.py:188 (: 322)
-                            if (KIND == PAIR_WEIGHTED) a = a * __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wl), u));   // plsa.py:294
-                            sum = sum + a;                                               // plsa.py:193
-                        }
+                        add32(pa, xl, wl, 0);
+                        load32(pa, jn);
+                        asm volatile("" ::: "memory");
+                        add32(pb, xl, wl, 32);
+                        xl = xn; wl = wn;
                     }
                 } else {
                     // the last chunk of the corpus
